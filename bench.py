@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path of SubspaceInference.jl on MI355X at BASELINE.json's cfg2.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is ONE posterior sample: propose z' -> W_swa + P z' -> Dense-chain forward over the full data in fp64
+-> Gaussian log-likelihood -> Metropolis accept (reference src/space_inference.jl:90-95,111-116), all on the
+device with inputs resident in HBM.  Each GPU runs its own independent chain (weak scaling, no data-path
+collective); `value` = samples of all ranks / max-over-ranks time.  The subspace-construct wall-clock (the
+metric's second half: K=100 SWA/deviation pushes from device-resident snapshots + Gram + eigensolve +
+projection) is measured before sampling and reported as `construct_wall_ms`.
+
+One JSON line on stdout (rank 0).  `roofline` is computed live from the library's own hipEvent pairs around
+the dominant kernel (the 960x960 Dense layer GEMM on the fp64 matrix cores) inside the timed region;
+`cpu_baseline` times the NumPy/OpenBLAS oracle on the same workload on this box's host cores (bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "posterior samples/sec (whole node) + subspace-construct wall-clock, 1M-param MLP M=20"
+DIMS, ACTS = [128, 960, 960, 1], [1, 1, 0]  # Chain(Dense(128,960,relu), Dense(960,960,relu), Dense(960,1))
+B, M, K_SNAP = 100000, 20, 100
+SIGMA_Z, SIGMA_M = 0.1, 1.0
+PEAK_F64_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet; the guide's table has no f64 row -- DESIGN.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def layer_table():
+    table, off = [], 0
+    for fin, fout, act in zip(DIMS[:-1], DIMS[1:], ACTS):
+        table.append((fin, fout, act, off, off + fin * fout))
+        off += fin * fout + fout
+    return table, off
+
+
+def glorot_flat(seed):
+    rng = np.random.default_rng(seed)
+    parts = []
+    for fin, fout in zip(DIMS[:-1], DIMS[1:]):
+        w = ((rng.random((fout, fin)) - 0.5) * np.sqrt(24.0 / (fin + fout))).astype(np.float32)
+        parts += [w.reshape(-1, order="F"), np.zeros(fout, dtype=np.float32)]
+    return np.concatenate(parts)
+
+
+def cpu_baseline(table, w_swa, p, x, y, z0, budget_s):
+    """The NumPy/OpenBLAS restatement (oracle) timed on the host: bounded sample of the same workload."""
+    from oracle import subspace_oracle as so
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    lp0 = so.logdensity(table, w_swa, p, x, y, SIGMA_M, z0)
+    t1 = time.perf_counter() - t0
+    n = int(max(1, min(50, (budget_s - t1) // max(t1, 1e-3))))
+    rng = np.random.default_rng(123)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        so.logdensity(table, w_swa, p, x, y, SIGMA_M, z0 + SIGMA_Z * rng.standard_normal(M))
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
+            "sample": "%d density evaluations (W_swa+P*z, fp64 forward over X 128x%d, SSE) of the cfg2 workload with "
+                      "NumPy+OpenBLAS (oracle/subspace_oracle.py), %.1f s" % (n, B, dt)}, lp0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import subspaceinference_jl_amd as si
+    table, n_par = layer_table()
+    assert n_par == 1047361
+
+    # ---- synthetic inputs (deterministic), made resident in HBM before any timed region
+    rng = np.random.default_rng(0)
+    x = np.asfortranarray(rng.standard_normal((DIMS[0], B)))
+    y = np.asfortranarray(rng.standard_normal((DIMS[-1], B)))
+    w0 = torch.from_numpy(glorot_flat(1).astype(np.float64)).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    steps = torch.randn(K_SNAP, n_par, generator=gen, device="cuda", dtype=torch.float64) * 0.01
+    snaps = (w0[None, :] + torch.cumsum(steps, dim=0)).to(torch.float32).contiguous()  # K x N fp32, random walk
+    del steps
+    torch.cuda.synchronize()
+
+    ctx = si.Context(local_rank)
+    ctx.set_profiling(True)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # ---- subspace construction (K pushes + Gram + eig + project), results stay on the device
+    def construct():
+        ctx.construct_begin(n_par, K_SNAP)
+        for k in range(K_SNAP):
+            ctx.construct_push_dev(snaps[k].data_ptr(), 0, float(k + 1))  # T=100 epochs, full batch, c=1: n = i
+        return ctx.construct_finish(M, want_swa=False, want_p=False)
+    construct()  # warm-up (allocations, code-object load)
+    barrier()
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    _, _, svals, _ = construct()
+    ctx.synchronize()
+    construct_ms = (time.perf_counter() - t0) * 1e3
+    cst = ctx.stats()
+
+    # ---- sampling
+    ctx.infer_setup(table, n_par, M, None, None, x, y, SIGMA_M)
+    ctx.sample_rwmh(max(1, args.warmup), SIGMA_Z, seed=100 + rank, chain_id0=rank, want_z=False)
+    barrier()
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    z, lp, acc = ctx.sample_rwmh(args.steps, SIGMA_Z, seed=100 + rank, chain_id0=rank)
+    barrier()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    value = world * args.steps / dt
+
+    if rank == 0:
+        dm = st["dense_main"]
+        avg_ms = dm["ms"] / max(1, dm["launches"])
+        fl = dm["flops"] / max(1, dm["launches"])
+        achieved = fl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_dense_main.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cfg2: Chain(Dense(128,960,relu),Dense(960,960,relu),Dense(960,1)) N=1047361, "
+                                   "X 128x100000 Y 1x100000 fp64, M=20, K=100 fp32 snapshots, RWMH sigma_z=0.1 sigma_m=1",
+                       "chains_per_gpu": 1, "parallelism": "independent chains x%d (one per GPU), no data-path collective" % world},
+            "construct_wall_ms": construct_ms,
+            "construct_device_ms": {k: round(cst[k]["ms"], 4) for k in ("push", "gram", "gram_reduce", "project")},
+            "sample_device_ms_per_step": {k: round(st[k]["ms"] / args.steps, 4) for k in ("reconstruct", "dense", "sse", "rwmh")},
+            "accept_rate": float(acc[0]), "lp_last": float(lp[-1, 0]),
+            "roofline": {"kernel": "dense_f64_kernel<128,128> layer 960x960 (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+                         "achieved": achieved, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F64_TFLOPS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "flops_per_launch": fl, "launches": dm["launches"]},
+            "device": ctx.device_name(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # W_swa / P of the construction just timed, brought to the host only for the CPU leg (outside all timers)
+            w_swa, p, _, _ = ctx.construct_finish(M)
+            cb, lp_cpu = cpu_baseline(table, w_swa, p, x, y, z[:, 0, 0], args.cpu_budget)
+            out["cpu_baseline"] = cb
+            out["parity_lp_rel_err_vs_oracle"] = abs(lp_cpu - float(lp[0, 0])) / abs(lp_cpu)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

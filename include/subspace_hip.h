@@ -1,0 +1,149 @@
+/* subspace_hip.h -- C ABI of libsubspace_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the ONE hot path of efmanu/SubspaceInference.jl: subspace construction
+ * (SWA mean -> deviation matrix -> tall-skinny Gram/eigen -> projection P) and subspace sampling
+ * (W_swa + P*z -> Dense-chain forward -> Gaussian log-likelihood -> random-walk Metropolis).
+ *
+ * The reference is inline Julia with no FFI seam of its own; each entry point below cites the
+ * reference expression it replaces (paths relative to the reference repository root).  A Julia
+ * `ccall` wrapper and a Python `ctypes` binding over exactly these symbols are shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns int32 status: 0 = SI_OK, negative = error; si_last_error(ctx) gives the
+ *     message (owned by the library, valid until the next call on that ctx).  The host wrappers turn a
+ *     non-zero status into the reference's error convention, `throw(::String)`.
+ *   - host pointers are caller-owned, contiguous, COLUMN-MAJOR (Julia layout); they are only read or
+ *     written during the call and never retained.  "_dev" variants take device pointers instead.
+ *   - device memory is owned by the opaque si_ctx and released by si_destroy.
+ *   - one ctx drives ONE GPU (one process per GPU); a ctx is used by one host thread at a time.
+ *   - there is NO CPU backend: si_create fails when no gfx950 device is usable.
+ */
+#ifndef SUBSPACE_HIP_H
+#define SUBSPACE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct si_ctx si_ctx;
+
+enum {
+  SI_OK = 0,
+  SI_ERR_INVALID = -1,  /* bad argument                                         */
+  SI_ERR_STATE = -2,    /* call out of order (e.g. push before begin)           */
+  SI_ERR_HIP = -3,      /* HIP runtime error, message has the hipError string   */
+  SI_ERR_NOMEM = -4,    /* device or host allocation failed                     */
+  SI_ERR_BOUNDS = -5,   /* M > rank(A): the reference's BoundsError at U[:,1:M] */
+  SI_ERR_NODEVICE = -6  /* no usable GPU                                        */
+};
+
+enum { SI_F32 = 0, SI_F64 = 1 };                                  /* dtype of a weight snapshot */
+enum { SI_ACT_IDENTITY = 0, SI_ACT_RELU = 1, SI_ACT_TANH = 2, SI_ACT_SIGMOID = 3 };
+enum { SI_LAYER_DENSE = 0 };
+
+/* One Dense layer of a Flux Chain inside the flat weight vector.  Layout contract of the whole path
+ * (src/libs.jl:19-22 extract_params, src/libs.jl:55-57 Flux.destructure/re):
+ *   [vec(W1) (out x in, column-major); b1; vec(W2); b2; ...]                                          */
+typedef struct {
+  int32_t kind;  /* SI_LAYER_DENSE */
+  int32_t in;    /* input features  */
+  int32_t out;   /* output features */
+  int32_t act;   /* SI_ACT_*        */
+  int64_t w_off; /* offset of vec(W) in the flat vector (elements) */
+  int64_t b_off; /* offset of b                                     */
+} si_layer;
+
+/* kernel classes timed by the library's own hipEvents (si_set_profiling) */
+enum {
+  SI_K_PUSH = 0,     /* K1 swa_dev_push                       */
+  SI_K_GRAM = 1,     /* K2 gram A'A partials (MFMA f64)       */
+  SI_K_GRAM_RED = 2, /* K2 partial-slab reduction             */
+  SI_K_PROJECT = 3,  /* K3 P = A*V_M                          */
+  SI_K_RECON = 4,    /* K4 w = W_swa + P*z                    */
+  SI_K_DENSE = 5,    /* K5 dense layer GEMM (MFMA f64), all layers */
+  SI_K_SSE = 6,      /* K5 sum of squared errors              */
+  SI_K_RWMH = 7,     /* K6 propose / accept kernels           */
+  SI_K_DENSE_MAIN = 8, /* K5 the largest layer only (dominant kernel) */
+  SI_K_COUNT = 9
+};
+
+typedef struct {
+  double ms[SI_K_COUNT];        /* accumulated device time per class (hipEvent), milliseconds */
+  int64_t launches[SI_K_COUNT]; /* launches per class                                          */
+  double flops[SI_K_COUNT];     /* accumulated ALGORITHMIC flops per class                     */
+  double bytes[SI_K_COUNT];     /* accumulated ALGORITHMIC HBM bytes per class                 */
+} si_stats;
+
+int32_t si_version(void);
+
+/* ---- context ------------------------------------------------------------------------------- */
+int32_t si_create(si_ctx** out, int32_t device_id);
+int32_t si_destroy(si_ctx* ctx);
+const char* si_last_error(si_ctx* ctx); /* ctx may be NULL: message of the last failed si_create */
+/* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream */
+int32_t si_set_stream(si_ctx* ctx, void* hip_stream);
+int32_t si_synchronize(si_ctx* ctx);
+int32_t si_set_profiling(si_ctx* ctx, int32_t on); /* hipEvent pair around every kernel launch */
+int32_t si_get_stats(si_ctx* ctx, si_stats* out);  /* synchronizes; resolves pending events   */
+int32_t si_reset_stats(si_ctx* ctx);
+int32_t si_device_name(si_ctx* ctx, char* buf, int32_t buflen);
+
+/* ---- subspace construction: replaces src/subspace_construction.jl:31-33,45-52,61-65 ---------- */
+/* :31-33  W_swa = zeros(N) (Float64), A = empty.  K_capacity = number of pushes that will follow.
+ * max_cols = 0 keeps every deviation column (the reference's behaviour: the shift at :48-50 is
+ * commented out); max_cols = M keeps only the newest M columns (the paper's column shift).        */
+int32_t si_construct_begin(si_ctx* ctx, int64_t N, int64_t K_capacity, int32_t max_cols);
+/* :45-52  W = extract_params(ps); n = i/c; W_swa = (n.*W_swa + W)./(n+1); W_dev = W - W_swa;
+ * append!(A, W_dev).  `n` is supplied by the caller (it is the EPOCH counter i/c, repeated for every
+ * batch of the epoch).  w has N elements of w_dtype.                                                */
+int32_t si_construct_push(si_ctx* ctx, const void* w_host, int32_t w_dtype, double n);
+int32_t si_construct_push_dev(si_ctx* ctx, const void* w_dev, int32_t w_dtype, double n);
+/* Gram matrix G = A'A (K x K, fp64) of the columns pushed so far, computed on the device.
+ * get/set exist so that a row-sharded construction (each rank holds a row block of w, W_swa, A, P) can
+ * all-reduce G across ranks (RCCL via the host wrapper) before si_construct_finish.                  */
+int32_t si_construct_gram(si_ctx* ctx);
+int32_t si_construct_gram_get(si_ctx* ctx, double* G_host /* K*K */, int64_t* K_out);
+int32_t si_construct_gram_set(si_ctx* ctx, const double* G_host /* K*K */);
+/* :61-65  A = reshape(A, N, :); U,s,V = psvd(A); P = U[:,1:M]*Diagonal(s[1:M])  ==  A*V[:,1:M].
+ * Outputs may be NULL (results stay on the device for si_infer_setup).  s_out receives the M largest
+ * singular values.  Column signs of P are fixed so that the entry of largest magnitude in each column
+ * of V is positive (deterministic; the reference's signs are arbitrary).  Returns SI_ERR_BOUNDS when M
+ * exceeds the numerical rank of A -- the reference's BoundsError at U[:,1:M].                         */
+int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out /* N */,
+                            double* P_out /* N x M col-major */, double* s_out /* M */,
+                            int64_t* K_out);
+/* read back deviation columns [k0, k0+nk) (N x nk col-major) -- parity tests of :51-52 */
+int32_t si_construct_get_A(si_ctx* ctx, int64_t k0, int64_t nk, double* A_out);
+
+/* ---- density + sampling: replaces src/space_inference.jl:88-95,111-116,125 ------------------- */
+/* :88 split_data (full X, Y), :90-95 density closure.  W_swa / P may both be NULL: the result of the
+ * ctx's finished construction is used in place (no host round trip).  X is in_dim x B, Y is out_dim x B,
+ * column-major fp64.  compute_dtype: SI_F64 (the reference's arithmetic; the only one implemented).   */
+int32_t si_infer_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, int32_t M,
+                       const double* W_swa, const double* P, const double* X, const double* Y,
+                       int32_t in_dim, int32_t out_dim, int64_t B, double sigma_m,
+                       int32_t compute_dtype);
+/* :90-95  lp[c] = logpdf(MvNormal(vec(f_{W_swa+P z_c}(X)), sigma_m), vec(Y)),  Z is M x C          */
+int32_t si_logdensity(si_ctx* ctx, const double* Z, int32_t C, double* lp_out /* C */);
+/* same, additionally returning the model output (out_dim x B) of the LAST z -- forward-pass parity  */
+int32_t si_forward(si_ctx* ctx, const double* z /* M */, double* Yhat_out /* out_dim x B */);
+/* :111-116  DensityModel + RWMH(MvNormal(zeros(M), sigma_z)) + sample(model, spl, itr): `itr` samples
+ * per chain INCLUDING the initial draw z0 ~ proposal; accept iff -randexp() < lp' - lp.  Chains
+ * chain_id0 .. chain_id0+nchains-1 use the library's Philox4x32-10 streams (seed, chain, step).
+ * Z_out is M x itr x nchains, lp_out is itr x nchains (column-major), accept_rate_out nchains.        */
+int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0,
+                       int32_t nchains, double* Z_out, double* lp_out, double* accept_rate_out);
+/* :91 / :125  W_out[:, c] = W_swa + P * Z[:, c]   (N x C col-major)                                  */
+int32_t si_reconstruct(si_ctx* ctx, const double* Z /* M x C */, int64_t C, double* W_out);
+
+/* ---- host utility (no GPU needed): the K x K symmetric eigensolver used inside si_construct_finish.
+ * a: n x n symmetric column-major, overwritten by the eigenvectors (columns); w: eigenvalues ascending. */
+int si_host_sym_eig(int n, double* a, double* w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUBSPACE_HIP_H */

@@ -1,0 +1,180 @@
+"""CPU restatement (NumPy, fp64) of SubspaceInference.jl's hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product (subspaceinference.jl_amd) never does; it fails loudly without its HIP library.
+
+PARITY UNPINNED.  The reference (/root/reference, Julia) ships an empty test-suite
+(test/runtests.jl is 0 bytes), no fixtures and no golden vectors, and Julia is not
+installed in this image, so the reference itself cannot be run.  This restatement follows
+the reference SOURCE line by line (citations below) and is cross-checked only by identities
+that do not depend on it being right (tests/test_oracle.py: closed-form EMA, LAPACK SVD
+identities, scipy.stats logpdf, a hand-computed forward pass, RWMH on a Gaussian target).
+
+Every function cites the reference file:line it restates (paths relative to /root/reference).
+Quirks of the reference CODE are reproduced on purpose:
+  Q1 W_swa starts at zero                      src/subspace_construction.jl:31
+  Q2 n = i/c is the EPOCH counter, per batch   src/subspace_construction.jl:44-47
+  Q3 no column shift, A keeps every column     src/subspace_construction.jl:48-52
+  Q4 prior term is dead code                   src/space_inference.jl:94-95
+  Q5 density uses the full (X, Y)              src/libs.jl:75-77
+  Q6 W_swa / A / P / density are Float64       src/subspace_construction.jl:31,33
+"""
+import math
+
+import numpy as np
+
+from . import philox
+
+ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+
+
+# --------------------------------------------------------------------------- layout
+def layer_table(dims, acts):
+    """Flat-vector layout of a Dense chain: [vec(W1) (out x in, column-major); b1; vec(W2); b2; ...].
+
+    Restates the ordering produced by `extract_params` (src/libs.jl:19-22, Flux.params order: W then b
+    per Dense layer) and consumed by `Flux.destructure`/`re` in `model_re` (src/libs.jl:55-57).
+    dims = [in, h1, ..., out]; returns list of (in, out, act, w_off, b_off) and total N.
+    """
+    table, off = [], 0
+    for l in range(len(dims) - 1):
+        fin, fout = dims[l], dims[l + 1]
+        w_off = off
+        off += fin * fout
+        b_off = off
+        off += fout
+        table.append((fin, fout, acts[l], w_off, b_off))
+    return table, off
+
+
+def extract_params(weights):
+    """src/libs.jl:19-22 -- `mapreduce(i -> vec(ps.order.data[i]), vcat, ...)`: column-major vec of each
+    array, concatenated; dtype follows the arrays (Float32 for Flux 0.11 default init)."""
+    return np.concatenate([np.asarray(a).reshape(-1, order="F") for a in weights])
+
+
+# --------------------------------------------------------------------------- construction
+def swa_dev_push(w_swa, w, n):
+    """src/subspace_construction.jl:46-47,51.
+
+        W_swa = (n.*W_swa + W)./(n+1)     # three separate rounded ops per element: mul, add, div
+        W_dev = W - W_swa                 # uses the UPDATED mean
+
+    `w` may be float32 (promoted exactly to float64, as Julia's `+` does).  No FMA: Julia materialises
+    `n.*W_swa` before the `+`.  Returns (new W_swa, W_dev)."""
+    w64 = np.asarray(w).astype(np.float64)
+    t = np.float64(n) * w_swa
+    u = t + w64
+    new = u / (np.float64(n) + 1.0)
+    return new, w64 - new
+
+
+def construct_stream(snapshots, ns):
+    """src/subspace_construction.jl:31-33,44-52,61: W_swa0 = zeros (Q1), push every snapshot with its
+    caller-supplied n (Q2), keep every deviation column (Q3).  Returns (W_swa, A) with A N x K col-major."""
+    n_par = len(snapshots[0])
+    w_swa = np.zeros(n_par, dtype=np.float64)
+    cols = []
+    for w, n in zip(snapshots, ns):
+        w_swa, dev = swa_dev_push(w_swa, w, n)
+        cols.append(dev)
+    a = np.stack(cols, axis=1) if cols else np.zeros((n_par, 0))
+    return w_swa, np.asfortranarray(a)
+
+
+def projection_from_A(a, m):
+    """src/subspace_construction.jl:63,65:  U,s,V = psvd(A);  P = U[:,1:M]*Diagonal(s[1:M]).
+
+    `psvd` is LowRankApprox 0.5.0 (Manifest.toml:786; NOT vendored).  Its published contract: a partial
+    SVD accurate to rtol = 5*eps, singular values descending -- restated here as LAPACK's exact thin SVD.
+    Column signs are arbitrary in both.  Raises like Julia's BoundsError when rank < M."""
+    u, s, _ = np.linalg.svd(a, full_matrices=False)
+    if m > len(s):
+        raise IndexError("BoundsError: M=%d exceeds min(N,K)=%d" % (m, len(s)))
+    return u[:, :m] * s[:m][None, :], s
+
+
+# --------------------------------------------------------------------------- density
+def _act(a, kind):
+    if kind == ACT_IDENTITY:
+        return a
+    if kind == ACT_RELU:
+        return np.maximum(a, 0.0)
+    if kind == ACT_TANH:
+        return np.tanh(a)
+    if kind == ACT_SIGMOID:
+        return 1.0 / (1.0 + np.exp(-a))
+    raise ValueError(kind)
+
+
+def forward(table, wflat, x):
+    """src/libs.jl:55-57 (`re(W)`: reshape consecutive slices, column-major) followed by the Flux 0.11.2
+    Dense forward `sigma.(W*x .+ b)` for every layer (src/space_inference.jl:94 `new_model(in_data)`)."""
+    h = x
+    for (fin, fout, act, w_off, b_off) in table:
+        w = wflat[w_off:w_off + fin * fout].reshape((fout, fin), order="F")
+        b = wflat[b_off:b_off + fout]
+        h = _act(w @ h + b[:, None], act)
+    return h
+
+
+def mvnormal_logpdf_iso(y, mu, sigma):
+    """Distributions 0.24.18 `logpdf(MvNormal(mu, sigma::Real), y)` (Manifest.toml:382; not vendored):
+    isotropic, sigma is a STANDARD DEVIATION: -(d*log(2pi) + d*log(sigma^2))/2 - ||y-mu||^2/(2 sigma^2)."""
+    d = y.size
+    r = (y - mu).reshape(-1)
+    sse = float(np.dot(r, r))
+    return lp_from_sse(sse, d, sigma), sse
+
+
+def lp_from_sse(sse, d, sigma):
+    c0 = -(d * math.log(2.0 * math.pi) + d * math.log(sigma * sigma)) / 2.0
+    return c0 - (sse / (sigma * sigma)) / 2.0
+
+
+def logdensity(table, w_swa, p, x, y, sigma_m, z):
+    """src/space_inference.jl:90-95 `density(z)` for a Chain: new_W = W_swa + P*z; forward over the FULL
+    data (Q5); Gaussian log-likelihood only -- the prior line after `return` is dead code (Q4)."""
+    new_w = w_swa + p @ z
+    yhat = forward(table, new_w, x)
+    lp, _ = mvnormal_logpdf_iso(y.reshape(-1, order="F"), yhat.reshape(-1, order="F"), sigma_m)
+    return lp
+
+
+def reconstruct(w_swa, p, z):
+    """src/space_inference.jl:91 and :125  `W_swa + P*z`."""
+    return w_swa + p @ z
+
+
+# --------------------------------------------------------------------------- sampler
+def rwmh(density, m, itr, sigma_z, seed, chain=0):
+    """src/space_inference.jl:111-116 -- DensityModel + RWMH(MvNormal(zeros(M), sigma_z)) + sample(.., itr).
+
+    AdvancedMH 0.6.2 / AbstractMCMC 3.2.1 semantics (Manifest.toml:38,9; not vendored):
+      step 1 : z0 ~ proposal (no init_params), lp0 = density(z0)                -> sample 1
+      step t : z' = z + rand(proposal); accept iff -randexp() < lp' - lp        -> sample t
+    `itr` samples INCLUDING the initial draw; one density call per sample.  The random stream is the
+    build's Philox stream (oracle/philox.py), not Julia's MersenneTwister.  Returns (Z (M x itr), lp, n_accept)."""
+    zs = np.empty((m, itr), dtype=np.float64, order="F")
+    lps = np.empty(itr, dtype=np.float64)
+    z = sigma_z * philox.normals(seed, chain, 0, m)
+    lp = density(z)
+    zs[:, 0], lps[0] = z, lp
+    nacc = 0
+    for t in range(1, itr):
+        zp = z + sigma_z * philox.normals(seed, chain, t, m)
+        lpp = density(zp)
+        if -philox.randexp(seed, chain, t) < lpp - lp:
+            z, lp = zp, lpp
+            nacc += 1
+        zs[:, t], lps[t] = z, lp
+    return zs, lps, nacc
+
+
+def sub_inference(table, x, y, w_swa, p, sigma_z, sigma_m, itr, seed, chain=0):
+    """src/space_inference.jl:82-125 for `alg = :rwmh`, Chain model.  Returns (Z, lp, weights) where
+    weights[:, t] = W_swa + P*Z[:, t] (the reference's `map(z -> W_swa + P*z.params, chm)`, :125)."""
+    m = p.shape[1]
+    dens = lambda z: logdensity(table, w_swa, p, x, y, sigma_m, z)
+    zs, lps, nacc = rwmh(dens, m, itr, sigma_z, seed, chain)
+    return zs, lps, w_swa[:, None] + p @ zs, nacc

@@ -1,0 +1,283 @@
+"""ctypes binding of libsubspace_hip.so -- the same C ABI the Julia `ccall` wrapper binds
+(include/subspace_hip.h; julia/SubspaceInferenceHIP.jl).  No arithmetic happens in this file.
+
+Errors follow the reference's convention (`throw(::String)`, e.g. src/space_inference.jl:42,103,162):
+a non-zero status raises `SubspaceError(message)`.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_int, c_int32, c_int64, c_uint64,
+                    c_void_p)
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsubspace_hip.so")
+
+SI_OK, SI_ERR_INVALID, SI_ERR_STATE, SI_ERR_HIP, SI_ERR_NOMEM, SI_ERR_BOUNDS, SI_ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6
+SI_F32, SI_F64 = 0, 1
+ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+K_NAMES = ["push", "gram", "gram_reduce", "project", "reconstruct", "dense", "sse", "rwmh", "dense_main"]
+K_COUNT = len(K_NAMES)
+
+
+class SubspaceError(RuntimeError):
+    """The host-side image of the reference's `throw("...")`."""
+
+    def __init__(self, msg, code=SI_ERR_INVALID):
+        super().__init__(msg)
+        self.code = code
+
+
+class BoundsError(SubspaceError, IndexError):
+    """Julia's BoundsError at `U[:,1:M]` (src/subspace_construction.jl:65) when rank(A) < M."""
+
+
+class SiLayer(Structure):
+    _fields_ = [("kind", c_int32), ("in_", c_int32), ("out", c_int32), ("act", c_int32),
+                ("w_off", c_int64), ("b_off", c_int64)]
+
+
+class SiStats(Structure):
+    _fields_ = [("ms", c_double * K_COUNT), ("launches", c_int64 * K_COUNT),
+                ("flops", c_double * K_COUNT), ("bytes", c_double * K_COUNT)]
+
+
+# every symbol include/subspace_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "si_version": (c_int32, []),
+    "si_create": (c_int32, [POINTER(c_void_p), c_int32]),
+    "si_destroy": (c_int32, [c_void_p]),
+    "si_last_error": (c_char_p, [c_void_p]),
+    "si_set_stream": (c_int32, [c_void_p, c_void_p]),
+    "si_synchronize": (c_int32, [c_void_p]),
+    "si_set_profiling": (c_int32, [c_void_p, c_int32]),
+    "si_get_stats": (c_int32, [c_void_p, POINTER(SiStats)]),
+    "si_reset_stats": (c_int32, [c_void_p]),
+    "si_device_name": (c_int32, [c_void_p, c_char_p, c_int32]),
+    "si_construct_begin": (c_int32, [c_void_p, c_int64, c_int64, c_int32]),
+    "si_construct_push": (c_int32, [c_void_p, c_void_p, c_int32, c_double]),
+    "si_construct_push_dev": (c_int32, [c_void_p, c_void_p, c_int32, c_double]),
+    "si_construct_gram": (c_int32, [c_void_p]),
+    "si_construct_gram_get": (c_int32, [c_void_p, c_void_p, POINTER(c_int64)]),
+    "si_construct_gram_set": (c_int32, [c_void_p, c_void_p]),
+    "si_construct_finish": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, POINTER(c_int64)]),
+    "si_construct_get_A": (c_int32, [c_void_p, c_int64, c_int64, c_void_p]),
+    "si_infer_setup": (c_int32, [c_void_p, POINTER(SiLayer), c_int32, c_int64, c_int32, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_int32, c_int32, c_int64, c_double, c_int32]),
+    "si_logdensity": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
+    "si_forward": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "si_sample_rwmh": (c_int32, [c_void_p, c_int64, c_double, c_uint64, c_int32, c_int32, c_void_p, c_void_p,
+                                 c_void_p]),
+    "si_reconstruct": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "si_host_sym_eig": (c_int, [c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library.  Fails loudly when it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SubspaceError(
+            "libsubspace_hip.so is missing (%s): build it with `python __graft_entry__.py` -- "
+            "this package has no CPU or PyTorch fallback" % LIB_PATH, SI_ERR_NODEVICE)
+    if os.environ.get("SI_PRELOAD_TORCH", "1") != "0":
+        # torch wheels bundle their own libamdhip64.so.7; when both live in one process the HIP runtime
+        # must be loaded once.  Importing torch first makes the library bind to the already loaded runtime.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is plumbing only; the library itself does not need it
+            pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the header disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+def _f64(a, order="F"):
+    return np.require(a, dtype=np.float64, requirements=[order, "A"])
+
+
+class Context:
+    """Owns one `si_ctx` (one GPU).  Thin: argument marshalling + status -> exception."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = c_void_p()
+        rc = self.lib.si_create(byref(h), int(device))
+        if rc != SI_OK:
+            msg = self.lib.si_last_error(None).decode()
+            raise SubspaceError(msg, rc)
+        self.h = h
+        self.device = int(device)
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc == SI_OK:
+            return
+        msg = self.lib.si_last_error(self.h).decode()
+        if rc == SI_ERR_BOUNDS:
+            raise BoundsError(msg, rc)
+        raise SubspaceError(msg, rc)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.si_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        self._check(self.lib.si_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def set_stream(self, stream_handle):
+        self._check(self.lib.si_set_stream(self.h, c_void_p(stream_handle) if stream_handle else None))
+
+    def synchronize(self):
+        self._check(self.lib.si_synchronize(self.h))
+
+    def set_profiling(self, on):
+        self._check(self.lib.si_set_profiling(self.h, 1 if on else 0))
+
+    def reset_stats(self):
+        self._check(self.lib.si_reset_stats(self.h))
+
+    def stats(self):
+        st = SiStats()
+        self._check(self.lib.si_get_stats(self.h, byref(st)))
+        return {K_NAMES[i]: {"ms": st.ms[i], "launches": st.launches[i], "flops": st.flops[i], "bytes": st.bytes[i]}
+                for i in range(K_COUNT)}
+
+    # -- construction
+    def construct_begin(self, n, k_capacity, max_cols=0):
+        self._check(self.lib.si_construct_begin(self.h, int(n), int(k_capacity), int(max_cols)))
+        self._n = int(n)
+
+    def construct_push(self, w, n):
+        w = np.ascontiguousarray(w)
+        if w.dtype == np.float32:
+            dt = SI_F32
+        elif w.dtype == np.float64:
+            dt = SI_F64
+        else:
+            raise SubspaceError("weights must be Float32 or Float64, got %s" % w.dtype)
+        if w.size != self._n:
+            raise SubspaceError("DimensionMismatch: snapshot has %d elements, expected %d" % (w.size, self._n))
+        self._check(self.lib.si_construct_push(self.h, _ptr(w), dt, float(n)))
+
+    def construct_push_dev(self, dev_ptr, dtype, n):
+        self._check(self.lib.si_construct_push_dev(self.h, c_void_p(int(dev_ptr)), int(dtype), float(n)))
+
+    def construct_gram(self):
+        self._check(self.lib.si_construct_gram(self.h))
+
+    def construct_gram_get(self):
+        k = c_int64()
+        self._check(self.lib.si_construct_gram_get(self.h, None, byref(k)))
+        g = np.empty((k.value, k.value), dtype=np.float64, order="F")
+        self._check(self.lib.si_construct_gram_get(self.h, _ptr(g), byref(k)))
+        return g
+
+    def construct_gram_set(self, g):
+        g = _f64(g)
+        self._check(self.lib.si_construct_gram_set(self.h, _ptr(g)))
+
+    def construct_finish(self, m, want_swa=True, want_p=True):
+        k = c_int64()
+        w_swa = np.empty(self._n, dtype=np.float64) if want_swa else None
+        p = np.empty((self._n, int(m)), dtype=np.float64, order="F") if want_p else None
+        s = np.empty(int(m), dtype=np.float64)
+        self._check(self.lib.si_construct_finish(self.h, int(m), _ptr(w_swa), _ptr(p), _ptr(s), byref(k)))
+        return w_swa, p, s, k.value
+
+    def construct_get_A(self, k0, nk):
+        a = np.empty((self._n, int(nk)), dtype=np.float64, order="F")
+        self._check(self.lib.si_construct_get_A(self.h, int(k0), int(nk), _ptr(a)))
+        return a
+
+    # -- density + sampling
+    def infer_setup(self, table, n, m, w_swa, p, x, y, sigma_m):
+        """table: list of (in, out, act, w_off, b_off); w_swa/p None => reuse the finished construction."""
+        arr = (SiLayer * len(table))()
+        for i, (fin, fout, act, w_off, b_off) in enumerate(table):
+            arr[i] = SiLayer(0, int(fin), int(fout), int(act), int(w_off), int(b_off))
+        x = _f64(x)
+        y = _f64(y)
+        if x.ndim != 2 or y.ndim != 2 or x.shape[1] != y.shape[1]:
+            raise SubspaceError("DimensionMismatch: X is %s, Y is %s" % (x.shape, y.shape))
+        if w_swa is not None:
+            w_swa = _f64(w_swa)
+            p = _f64(p)
+            if w_swa.shape != (n,) or p.shape != (n, m):
+                raise SubspaceError("DimensionMismatch: W_swa %s, P %s, expected (%d,), (%d, %d)"
+                                    % (w_swa.shape, p.shape, n, n, m))
+        self._check(self.lib.si_infer_setup(self.h, arr, len(table), int(n), int(m), _ptr(w_swa), _ptr(p), _ptr(x),
+                                            _ptr(y), x.shape[0], y.shape[0], x.shape[1], float(sigma_m), SI_F64))
+        self._m, self._in, self._out, self._b, self._ni = int(m), x.shape[0], y.shape[0], x.shape[1], int(n)
+
+    def logdensity(self, z):
+        z = _f64(z)
+        if z.ndim == 1:
+            z = z.reshape(-1, 1, order="F")
+        if z.shape[0] != self._m:
+            raise SubspaceError("DimensionMismatch: z has %d rows, M = %d" % (z.shape[0], self._m))
+        lp = np.empty(z.shape[1], dtype=np.float64)
+        self._check(self.lib.si_logdensity(self.h, _ptr(z), z.shape[1], _ptr(lp)))
+        return lp
+
+    def forward(self, z):
+        z = _f64(z).reshape(-1)
+        yhat = np.empty((self._out, self._b), dtype=np.float64, order="F")
+        self._check(self.lib.si_forward(self.h, _ptr(z), _ptr(yhat)))
+        return yhat
+
+    def sample_rwmh(self, itr, sigma_z, seed, chain_id0=0, nchains=1, want_z=True):
+        z = np.empty((self._m, int(itr), int(nchains)), dtype=np.float64, order="F") if want_z else None
+        lp = np.empty((int(itr), int(nchains)), dtype=np.float64, order="F")
+        acc = np.empty(int(nchains), dtype=np.float64)
+        self._check(self.lib.si_sample_rwmh(self.h, int(itr), float(sigma_z), int(seed), int(chain_id0), int(nchains),
+                                            _ptr(z), _ptr(lp), _ptr(acc)))
+        return z, lp, acc
+
+    def reconstruct(self, z):
+        z = _f64(z)
+        if z.ndim == 1:
+            z = z.reshape(-1, 1, order="F")
+        w = np.empty((self._ni, z.shape[1]), dtype=np.float64, order="F")
+        self._check(self.lib.si_reconstruct(self.h, _ptr(z), z.shape[1], _ptr(w)))
+        return w
+
+
+def host_sym_eig(g):
+    """The host eigensolver of si_construct_finish (needs no GPU)."""
+    lib = load()
+    a = np.array(g, dtype=np.float64, order="F")
+    n = a.shape[0]
+    w = np.empty(n, dtype=np.float64)
+    rc = lib.si_host_sym_eig(n, _ptr(a), _ptr(w))
+    if rc != 0:
+        raise SubspaceError("eigensolver did not converge")
+    return w, a

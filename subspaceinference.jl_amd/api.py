@@ -1,0 +1,137 @@
+"""Host-side mirror of the reference's exported API for the hot path (src/SubspaceInference.jl:27-34):
+
+    subspace_construction(model, cost, data, opt; T=10, c=1, M=3, print_freq=1)        -> (W_swa, P)
+    subspace_inference(model, cost, data, opt; σ_z, σ_m, σ_p, itr, T, c, M, ...)        -> (chn, lp, W_swa)
+    sub_inference(in_model, data, W_swa, P; σ_z, σ_m, σ_p, itr, M, alg, backend)        -> (chn, lp)
+    inference(...)  README-only alias of sub_inference (README.md:153-154); alg=:mh == :rwmh
+
+Same names, argument meaning, defaults and error behaviour (`throw(String)` -> SubspaceError) as the
+reference.  Everything numerical goes through the C ABI (include/subspace_hip.h) to the HIP kernels; the
+only host arithmetic here is the caller-side training step (flux.py, see its header).  Extra keyword
+arguments (device, ctx, seed, max_cols, ...) are additions and default to the reference's behaviour.
+Python identifiers may be Greek, so `σ_z=` works as in Julia; `sigma_z=` is accepted too.
+"""
+import numpy as np
+
+from . import flux
+from ._capi import Context, SubspaceError
+
+_RWMH_ALGS = ("rwmh", "mh")
+
+
+def _get_ctx(ctx, device):
+    return (ctx, False) if ctx is not None else (Context(device), True)
+
+
+def _alg_name(alg):
+    return str(alg).lstrip(":")
+
+
+def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, *, device=0, ctx=None,
+                          max_cols=0, verbose=True, keep_on_device=False):
+    """src/subspace_construction.jl:26-67.
+
+    Per batch the host does `gradient` + `update!` (:39-43, caller side) and hands the flattened weights
+    (`extract_params`, src/libs.jl:19-22, Float32) plus `n = i/c` to the device, which applies the SWA update,
+    forms the deviation column and appends it (:45-52, kernel K1).  After the loop the device forms A'A
+    (K2), the host solves the K x K eigenproblem (H1) and the device projects P = A*V_M (K3) == :61-65.
+    """
+    ps = flux.params(model)
+    n_par = int(sum(p.size for p in ps))
+    nb = len(data)
+    n_push = sum(1 for i in range(1, T + 1) if i % c == 0) * nb
+    if n_push == 0:
+        # reference: reshape of an empty A, then psvd / U[:,1:M] fails
+        raise SubspaceError("BoundsError: no snapshot was collected (mod(i,c) never 0 for i in 1:T)")
+    ctx, own = _get_ctx(ctx, device)
+    try:
+        ctx.construct_begin(n_par, n_push, max_cols)
+        training_loss = 0.0
+        for i in range(1, T + 1):
+            for d in data:
+                training_loss, gs = flux.gradient(cost, model, *d)
+                flux.update(opt, ps, gs)
+                if i % c == 0:
+                    ctx.construct_push(flux.extract_params(ps), i / c)
+            if (i % print_freq == 0) or (i == T):
+                if verbose:
+                    print("Traing loss: ", training_loss, " Epoch: ", i)  # [sic] reference :57
+        w_swa, p, _, _ = ctx.construct_finish(M, want_swa=True, want_p=not keep_on_device)
+        return w_swa, p
+    finally:
+        if own and not keep_on_device:
+            ctx.close()
+
+
+def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=100, M=3, alg="rwmh",
+                  backend="forwarddiff", *, sigma_z=None, sigma_m=None, sigma_p=None, device=0, ctx=None,
+                  seed=0, chain_id=0, return_z=False):
+    """src/space_inference.jl:82-164 for a Chain model and alg = :rwmh.
+
+    `density(z)` (:90-95: W_swa + P*z -> model_re -> forward over the FULL data -> Gaussian log-likelihood,
+    prior term dead) and the RWMH loop (:111-116) run on the device; the output map (:125) materialises
+    `W_swa + P*z` for every sample like the reference unless `return_z=True` (then chn is the M x itr matrix
+    of subspace samples).  σ_p is accepted and unused, exactly as in the reference (quirk Q4).
+    """
+    σ_z = σ_z if sigma_z is None else sigma_z
+    σ_m = σ_m if sigma_m is None else sigma_m
+    a = _alg_name(alg)
+    if a in ("mala", "hmc", "nuts", "advi"):
+        raise SubspaceError("%s needs the gradient of the log-density (SURVEY 8(f2), not built yet)" % a)
+    if a not in _RWMH_ALGS:
+        raise SubspaceError("%s is not available" % a)  # reference :162
+    if not isinstance(in_model, flux.Chain):
+        raise SubspaceError("Error: density function is not avaliable for this model")  # [sic] reference :103
+    x, y = data.data[0], data.data[1]  # split_data, src/libs.jl:75-77 (full data, not the batches)
+    table, n_par = flux.layer_table(in_model)
+    ctx, own = _get_ctx(ctx, device)
+    try:
+        if W_swa is None:
+            ctx.infer_setup(table, n_par, M, None, None, x, y, σ_m)
+        else:
+            W_swa = np.asarray(W_swa, dtype=np.float64)
+            P = np.asarray(P, dtype=np.float64)
+            if P.shape[1] != M:
+                # reference: MvNormal(zeros(M), σ_z) proposal against an N x size(P,2) matrix -> DimensionMismatch in P*z
+                raise SubspaceError("DimensionMismatch: P has %d columns but M = %d" % (P.shape[1], M))
+            ctx.infer_setup(table, n_par, M, W_swa, P, x, y, σ_m)
+        z, lp, _ = ctx.sample_rwmh(itr, σ_z, seed, chain_id, 1)
+        z, lp = z[:, :, 0], lp[:, 0]
+        if return_z:
+            return z, lp
+        w = ctx.reconstruct(z)  # :125  map(z -> W_swa + P*z.params, chm)
+        return [w[:, t] for t in range(w.shape[1])], lp
+    finally:
+        if own:
+            ctx.close()
+
+
+def inference(*args, **kwargs):
+    """README.md:153-154 name for `sub_inference`."""
+    return sub_inference(*args, **kwargs)
+
+
+def subspace_inference(model, cost, data, opt, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=1000, T=25, c=1, M=20,
+                       print_freq=1, alg="rwmh", backend="forwarddiff", method="subspace", *, sigma_z=None,
+                       sigma_m=None, sigma_p=None, device=0, ctx=None, seed=0, verbose=True, return_z=False):
+    """src/space_inference.jl:33-54: construction, then sampling; returns (chn, lp, W_swa).
+    W_swa and P stay on the device between the two stages (no host round trip)."""
+    m = _alg_name(method)
+    if m == "diffusion":
+        raise SubspaceError("method :diffusion is outside the accelerated path (SURVEY section 2)")
+    if m != "subspace":
+        raise SubspaceError("Error: No method found")  # reference :42
+    a = _alg_name(alg)
+    if a in ("turing_mh", "turing_nuts"):
+        raise SubspaceError("Turing samplers are outside the accelerated path (SURVEY section 2)")
+    ctx, own = _get_ctx(ctx, device)
+    try:
+        w_swa, _ = subspace_construction(model, cost, data, opt, T=T, c=c, M=M, print_freq=print_freq, ctx=ctx,
+                                         verbose=verbose, keep_on_device=True)
+        chn, lp = sub_inference(model, data, None, None, σ_z=σ_z, σ_m=σ_m, σ_p=σ_p, itr=itr, M=M, alg=alg,
+                                backend=backend, sigma_z=sigma_z, sigma_m=sigma_m, ctx=ctx, seed=seed,
+                                return_z=return_z)
+        return chn, lp, w_swa
+    finally:
+        if own:
+            ctx.close()

@@ -1,0 +1,66 @@
+"""Build libsubspace_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build() and the tests.
+
+The library is plain HIP + C++ (no torch, no Triton, no hipify); it is built next to its sources so that it
+travels to the GPU box with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsubspace_hip.so")
+ARCH = "gfx950"
+
+# (source, extra flags).  kernels_stream.hip must not contract a*b+c: K1 is bit-exact against the reference's
+# three rounded operations.
+SOURCES = [
+    ("capi.hip", []),
+    ("kernels_stream.hip", ["-ffp-contract=off"]),
+    ("kernels_gemm.hip", []),
+    ("kernels_gram.hip", []),
+    ("eig.cpp", []),
+]
+HEADERS = ["si_internal.h", "philox.h", os.path.join("..", "..", "include", "subspace_hip.h")]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: cannot build libsubspace_hip.so")
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = _hipcc()
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    objs = []
+    for src, extra in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+                   "-c", s, "-o", o] + extra
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

@@ -1,0 +1,707 @@
+// C ABI of libsubspace_hip.so (see include/subspace_hip.h for the contract and the reference lines each
+// entry point replaces).  Host-side orchestration only: every arithmetic step of the hot path runs in the
+// HIP kernels of kernels_*.hip, except the K x K symmetric eigensolve (eig.cpp, host, K ~ 100).
+// There is no CPU fallback anywhere in this file.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "si_internal.h"
+
+namespace si {
+
+static thread_local std::string g_create_err;
+
+int32_t fail(Ctx* c, int32_t code, const std::string& msg) {
+  if (c)
+    c->err = msg;
+  else
+    g_create_err = msg;
+  return code;
+}
+
+// ---- profiling -------------------------------------------------------------------------------
+static hipEvent_t get_event(Ctx* c) {
+  if (!c->event_pool.empty()) {
+    hipEvent_t e = c->event_pool.back();
+    c->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+ProfScope::ProfScope(Ctx* c_, int cls_, double flops, double bytes) : c(c_), cls(cls_) {
+  if (!c) return;
+  c->stats.launches[cls] += 1;
+  c->stats.flops[cls] += flops;
+  c->stats.bytes[cls] += bytes;
+  if (!c->profiling || c->pending.size() >= (1u << 20)) return;
+  a = get_event(c);
+  b = get_event(c);
+  if (a && b) (void)hipEventRecord(a, c->stream);
+}
+ProfScope::~ProfScope() {
+  if (!c || !a || !b) return;
+  (void)hipEventRecord(b, c->stream);
+  c->pending.push_back({a, b, cls});
+}
+
+static void resolve_events(Ctx* c) {
+  for (auto& p : c->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) c->stats.ms[p.cls] += (double)ms;
+    c->event_pool.push_back(p.a);
+    c->event_pool.push_back(p.b);
+  }
+  c->pending.clear();
+}
+
+// ---- memory helpers ----------------------------------------------------------------------------
+template <typename T>
+static hipError_t dev_alloc(T** p, size_t count) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  return hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+}
+template <typename T>
+static void dev_free(T*& p) {
+  if (p) (void)hipFree((void*)p);
+  p = nullptr;
+}
+
+static void free_infer(Ctx* c);
+
+static void free_construct(Ctx* c) {
+  // an inference set up on the construction's own W_swa / P dies with it
+  if (c->i_ready && c->i_swa == c->d_swa && c->d_swa != nullptr) free_infer(c);
+  dev_free(c->d_swa);
+  dev_free(c->d_A);
+  dev_free(c->d_G);
+  dev_free(c->d_Gpart);
+  dev_free(c->d_V);
+  dev_free(c->d_P);
+  c->gpart_bytes = 0;
+  c->c_active = c->c_finished = c->gram_valid = false;
+  c->K = c->Kcap = c->N = c->ldA = 0;
+  c->npush = 0;
+  c->M_built = 0;
+}
+
+static void free_infer(Ctx* c) {
+  dev_free(c->d_iswa);
+  dev_free(c->d_iP);
+  dev_free(c->d_X);
+  dev_free(c->d_Y);
+  dev_free(c->d_w);
+  dev_free(c->d_act[0]);
+  dev_free(c->d_act[1]);
+  dev_free(c->d_ssepart);
+  dev_free(c->d_zcur);
+  dev_free(c->d_zprop);
+  dev_free(c->d_lpcur);
+  dev_free(c->d_sse);
+  dev_free(c->d_nacc);
+  c->chains_cap = 0;
+  c->i_ready = false;
+  c->i_swa = c->i_P = nullptr;
+}
+
+}  // namespace si
+
+using namespace si;
+
+#define CHECK_CTX(ctx) \
+  if (!(ctx)) return SI_ERR_INVALID
+#define BIND(ctx) SI_HIP(ctx, hipSetDevice((ctx)->device))
+
+extern "C" {
+
+int32_t si_version(void) { return 100; }
+
+const char* si_last_error(si_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int32_t si_create(si_ctx** out, int32_t device_id) {
+  if (!out) return fail(nullptr, SI_ERR_INVALID, "si_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, SI_ERR_NODEVICE,
+                std::string("si_create: no HIP device available (") +
+                    (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                    "); this library has no CPU backend");
+  if (device_id < 0 || device_id >= ndev)
+    return fail(nullptr, SI_ERR_INVALID, "si_create: device_id out of range");
+  si_ctx* c = new (std::nothrow) si_ctx();
+  if (!c) return fail(nullptr, SI_ERR_NOMEM, "si_create: host allocation failed");
+  c->device = device_id;
+  hipDeviceProp_t prop;
+  if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+    std::string m = std::string("si_create: ") + hipGetErrorString(e);
+    delete c;
+    return fail(nullptr, SI_ERR_HIP, m);
+  }
+  c->stream = c->own_stream;
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  snprintf(c->devname, sizeof(c->devname), "%s (%s)", prop.name, prop.gcnArchName);
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    std::string m = std::string("si_create: device is ") + prop.gcnArchName +
+                    ", but libsubspace_hip.so carries gfx950 code objects only";
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return fail(nullptr, SI_ERR_NODEVICE, m);
+  }
+  *out = c;
+  return SI_OK;
+}
+
+int32_t si_destroy(si_ctx* ctx) {
+  CHECK_CTX(ctx);
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  resolve_events(ctx);
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  free_construct(ctx);
+  free_infer(ctx);
+  dev_free(ctx->d_wstage);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return SI_OK;
+}
+
+int32_t si_set_stream(si_ctx* ctx, void* hip_stream) {
+  CHECK_CTX(ctx);
+  BIND(ctx);
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return SI_OK;
+}
+
+int32_t si_synchronize(si_ctx* ctx) {
+  CHECK_CTX(ctx);
+  BIND(ctx);
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+int32_t si_set_profiling(si_ctx* ctx, int32_t on) {
+  CHECK_CTX(ctx);
+  ctx->profiling = on != 0;
+  return SI_OK;
+}
+
+int32_t si_get_stats(si_ctx* ctx, si_stats* out) {
+  CHECK_CTX(ctx);
+  if (!out) return fail(ctx, SI_ERR_INVALID, "si_get_stats: out is NULL");
+  BIND(ctx);
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  resolve_events(ctx);
+  *out = ctx->stats;
+  return SI_OK;
+}
+
+int32_t si_reset_stats(si_ctx* ctx) {
+  CHECK_CTX(ctx);
+  BIND(ctx);
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  resolve_events(ctx);
+  std::memset(&ctx->stats, 0, sizeof(ctx->stats));
+  return SI_OK;
+}
+
+int32_t si_device_name(si_ctx* ctx, char* buf, int32_t buflen) {
+  CHECK_CTX(ctx);
+  if (!buf || buflen <= 0) return fail(ctx, SI_ERR_INVALID, "si_device_name: bad buffer");
+  std::strncpy(buf, ctx->devname, (size_t)buflen - 1);
+  buf[buflen - 1] = 0;
+  return SI_OK;
+}
+
+// =================================================================================================
+// construction
+// =================================================================================================
+int32_t si_construct_begin(si_ctx* ctx, int64_t N, int64_t K_capacity, int32_t max_cols) {
+  CHECK_CTX(ctx);
+  if (N <= 0 || K_capacity <= 0 || max_cols < 0)
+    return fail(ctx, SI_ERR_INVALID, "si_construct_begin: N and K_capacity must be positive, max_cols >= 0");
+  BIND(ctx);
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  free_construct(ctx);
+  ctx->N = N;
+  ctx->ldA = pad_ld(N);
+  ctx->max_cols = max_cols;
+  ctx->Kcap = max_cols > 0 ? std::min<int64_t>(max_cols, K_capacity) : K_capacity;
+  if (dev_alloc(&ctx->d_swa, (size_t)ctx->ldA) != hipSuccess ||
+      dev_alloc(&ctx->d_A, (size_t)ctx->ldA * (size_t)ctx->Kcap) != hipSuccess) {
+    free_construct(ctx);
+    return fail(ctx, SI_ERR_NOMEM, "si_construct_begin: device allocation of W_swa / A failed");
+  }
+  // W_swa = zeros(N)  (reference :31, quirk Q1: NOT the pretrained weights)
+  SI_HIP(ctx, hipMemsetAsync(ctx->d_swa, 0, (size_t)ctx->ldA * sizeof(double), ctx->stream));
+  SI_HIP(ctx, hipMemsetAsync(ctx->d_A, 0, (size_t)ctx->ldA * (size_t)ctx->Kcap * sizeof(double), ctx->stream));
+  ctx->c_active = true;
+  return SI_OK;
+}
+
+static int32_t push_common(si_ctx* ctx, const void* w_dev, int32_t w_dtype, double n) {
+  // column slot: keep-all appends; with max_cols the oldest column is overwritten (ring). The order of the
+  // columns does not change A*A' and hence neither the singular values nor P up to sign.
+  int64_t slot;
+  if (ctx->max_cols > 0) {
+    slot = ctx->npush % ctx->Kcap;
+  } else {
+    if (ctx->K >= ctx->Kcap) return fail(ctx, SI_ERR_STATE, "si_construct_push: more pushes than K_capacity");
+    slot = ctx->K;
+  }
+  const size_t wsz = w_dtype == SI_F32 ? 4 : 8;
+  {
+    ProfScope ps(ctx, SI_K_PUSH, 4.0 * (double)ctx->N, (double)ctx->N * (double)(wsz + 24));
+    launch_swa_dev_push(ctx->stream, w_dev, w_dtype, ctx->d_swa, ctx->d_A + slot * ctx->ldA, ctx->N, n,
+                        ctx->num_cu);
+  }
+  SI_HIP(ctx, hipGetLastError());
+  ctx->npush += 1;
+  ctx->K = std::min(ctx->npush, ctx->Kcap);
+  ctx->gram_valid = false;
+  ctx->c_finished = false;
+  return SI_OK;
+}
+
+int32_t si_construct_push_dev(si_ctx* ctx, const void* w_dev, int32_t w_dtype, double n) {
+  CHECK_CTX(ctx);
+  if (!ctx->c_active) return fail(ctx, SI_ERR_STATE, "si_construct_push_dev: call si_construct_begin first");
+  if (!w_dev || (w_dtype != SI_F32 && w_dtype != SI_F64))
+    return fail(ctx, SI_ERR_INVALID, "si_construct_push_dev: bad pointer or dtype");
+  BIND(ctx);
+  return push_common(ctx, w_dev, w_dtype, n);
+}
+
+int32_t si_construct_push(si_ctx* ctx, const void* w_host, int32_t w_dtype, double n) {
+  CHECK_CTX(ctx);
+  if (!ctx->c_active) return fail(ctx, SI_ERR_STATE, "si_construct_push: call si_construct_begin first");
+  if (!w_host || (w_dtype != SI_F32 && w_dtype != SI_F64))
+    return fail(ctx, SI_ERR_INVALID, "si_construct_push: bad pointer or dtype");
+  BIND(ctx);
+  const size_t bytes = (size_t)ctx->N * (w_dtype == SI_F32 ? 4 : 8);
+  if (ctx->wstage_bytes < bytes) {
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_wstage);
+    if (hipMalloc(&ctx->d_wstage, bytes) != hipSuccess) {
+      ctx->wstage_bytes = 0;
+      return fail(ctx, SI_ERR_NOMEM, "si_construct_push: staging allocation failed");
+    }
+    ctx->wstage_bytes = bytes;
+  }
+  // the host buffer is only valid during this call (Julia GC.@preserve), so the copy is synchronous
+  SI_HIP(ctx, hipMemcpyAsync(ctx->d_wstage, w_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return push_common(ctx, ctx->d_wstage, w_dtype, n);
+}
+
+int32_t si_construct_gram(si_ctx* ctx) {
+  CHECK_CTX(ctx);
+  if (!ctx->c_active || ctx->K <= 0) return fail(ctx, SI_ERR_STATE, "si_construct_gram: nothing pushed");
+  BIND(ctx);
+  const int64_t K = ctx->K;
+  const size_t need = launch_gram(ctx->stream, ctx->d_A, ctx->ldA, ctx->N, K, nullptr, nullptr, ctx->num_cu, nullptr);
+  if (ctx->gpart_bytes < need) {
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_Gpart);
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->d_Gpart), need) != hipSuccess) {
+      ctx->gpart_bytes = 0;
+      return fail(ctx, SI_ERR_NOMEM, "si_construct_gram: partial-slab allocation failed");
+    }
+    ctx->gpart_bytes = need;
+  }
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  dev_free(ctx->d_G);
+  if (dev_alloc(&ctx->d_G, (size_t)K * K) != hipSuccess)
+    return fail(ctx, SI_ERR_NOMEM, "si_construct_gram: G allocation failed");
+  launch_gram(ctx->stream, ctx->d_A, ctx->ldA, ctx->N, K, ctx->d_Gpart, ctx->d_G, ctx->num_cu, ctx);
+  SI_HIP(ctx, hipGetLastError());
+  ctx->gram_valid = true;
+  return SI_OK;
+}
+
+int32_t si_construct_gram_get(si_ctx* ctx, double* G_host, int64_t* K_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->gram_valid) return fail(ctx, SI_ERR_STATE, "si_construct_gram_get: call si_construct_gram first");
+  BIND(ctx);
+  if (K_out) *K_out = ctx->K;
+  if (G_host) {
+    SI_HIP(ctx, hipMemcpyAsync(G_host, ctx->d_G, (size_t)ctx->K * ctx->K * sizeof(double), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return SI_OK;
+}
+
+int32_t si_construct_gram_set(si_ctx* ctx, const double* G_host) {
+  CHECK_CTX(ctx);
+  if (!ctx->gram_valid || !G_host)
+    return fail(ctx, SI_ERR_STATE, "si_construct_gram_set: call si_construct_gram first / NULL input");
+  BIND(ctx);
+  SI_HIP(ctx, hipMemcpyAsync(ctx->d_G, G_host, (size_t)ctx->K * ctx->K * sizeof(double), hipMemcpyHostToDevice,
+                             ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P_out, double* s_out,
+                            int64_t* K_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->c_active || ctx->K <= 0) return fail(ctx, SI_ERR_STATE, "si_construct_finish: nothing pushed");
+  if (M <= 0) return fail(ctx, SI_ERR_INVALID, "si_construct_finish: M must be positive");
+  BIND(ctx);
+  const int64_t K = ctx->K, N = ctx->N;
+  if (K_out) *K_out = K;
+  // U[:,1:M] throws BoundsError in the reference when psvd returns fewer than M columns (:65)
+  if (M > K) return fail(ctx, SI_ERR_BOUNDS, "BoundsError: M exceeds the number of deviation columns K");
+  if (!ctx->gram_valid) {
+    int32_t rc = si_construct_gram(ctx);
+    if (rc != SI_OK) return rc;
+  }
+  // H1: eigen-decomposition of G on the host (K x K)
+  std::vector<double> G((size_t)K * K), lam((size_t)K);
+  SI_HIP(ctx, hipMemcpyAsync(G.data(), ctx->d_G, G.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (sym_eig((int)K, G.data(), lam.data()) != 0)
+    return fail(ctx, SI_ERR_INVALID, "si_construct_finish: eigensolver did not converge");
+  // descending singular values; V_M with a deterministic sign (largest-magnitude entry positive)
+  const int Mpad = project_mpad(M);
+  std::vector<double> V((size_t)K * Mpad, 0.0);
+  ctx->svals.assign((size_t)M, 0.0);
+  for (int m = 0; m < M; ++m) {
+    const int64_t col = K - 1 - m;
+    const double l = lam[(size_t)col];
+    ctx->svals[(size_t)m] = l > 0.0 ? std::sqrt(l) : 0.0;
+    const double* v = G.data() + (size_t)col * K;
+    int64_t imax = 0;
+    for (int64_t k = 1; k < K; ++k)
+      if (std::fabs(v[k]) > std::fabs(v[imax])) imax = k;
+    const double sgn = v[imax] < 0.0 ? -1.0 : 1.0;
+    for (int64_t k = 0; k < K; ++k) V[(size_t)k * Mpad + m] = sgn * v[k];
+  }
+  // numerical rank check.  psvd (rtol 5 eps) returns only rank(A) columns and U[:,1:M] then throws.  Through the
+  // Gram matrix, eigenvalues below ~K*eps*lambda_1 are rounding noise, i.e. singular values under ~1e-6*s_1 cannot
+  // be delivered to the path's rtol of 1e-4: report them as rank deficiency instead of returning noise.
+  const double lam1 = lam[(size_t)K - 1], lamM = lam[(size_t)(K - M)];
+  if (!(lam1 > 0.0) || lamM <= 64.0 * (double)K * 2.220446049250313e-16 * lam1 || M > std::min<int64_t>(N, K))
+    return fail(ctx, SI_ERR_BOUNDS,
+                "BoundsError: M exceeds the numerical rank of the deviation matrix (s_M < ~1e-6 s_1 is below what the "
+                "Gram-matrix route resolves)");
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  dev_free(ctx->d_V);
+  if (ctx->d_P == nullptr || ctx->M_built != M) {
+    // P is re-allocated: an inference bound to the old P of this construction must not outlive it
+    if (ctx->i_ready && ctx->i_P == ctx->d_P && ctx->d_P != nullptr) free_infer(ctx);
+    dev_free(ctx->d_P);
+    ctx->M_built = 0;
+    if (dev_alloc(&ctx->d_P, (size_t)ctx->ldA * M) != hipSuccess)
+      return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: allocation of P failed");
+  }
+  if (dev_alloc(&ctx->d_V, V.size()) != hipSuccess)
+    return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: allocation of V failed");
+  SI_HIP(ctx, hipMemcpyAsync(ctx->d_V, V.data(), V.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  SI_HIP(ctx, hipMemsetAsync(ctx->d_P, 0, (size_t)ctx->ldA * M * sizeof(double), ctx->stream));
+  {
+    ProfScope ps(ctx, SI_K_PROJECT, 2.0 * (double)N * (double)K * (double)M, (double)N * (double)(K + M) * 8.0);
+    launch_project(ctx->stream, ctx->d_A, ctx->ldA, N, K, ctx->d_V, M, Mpad, ctx->d_P, ctx->ldA, ctx->num_cu);
+  }
+  SI_HIP(ctx, hipGetLastError());
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));  // V (host vector) must outlive the async copy
+  ctx->M_built = M;
+  ctx->c_finished = true;
+  if (s_out) std::copy(ctx->svals.begin(), ctx->svals.end(), s_out);
+  if (W_swa_out)
+    SI_HIP(ctx, hipMemcpyAsync(W_swa_out, ctx->d_swa, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (P_out)
+    SI_HIP(ctx, hipMemcpy2DAsync(P_out, (size_t)N * sizeof(double), ctx->d_P, (size_t)ctx->ldA * sizeof(double),
+                                 (size_t)N * sizeof(double), (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+int32_t si_construct_get_A(si_ctx* ctx, int64_t k0, int64_t nk, double* A_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->c_active) return fail(ctx, SI_ERR_STATE, "si_construct_get_A: no construction in progress");
+  if (k0 < 0 || nk < 0 || k0 + nk > ctx->K || !A_out) return fail(ctx, SI_ERR_INVALID, "si_construct_get_A: bad range");
+  BIND(ctx);
+  if (nk == 0) return SI_OK;
+  SI_HIP(ctx, hipMemcpy2DAsync(A_out, (size_t)ctx->N * sizeof(double), ctx->d_A + k0 * ctx->ldA,
+                               (size_t)ctx->ldA * sizeof(double), (size_t)ctx->N * sizeof(double), (size_t)nk,
+                               hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+// =================================================================================================
+// density + sampling
+// =================================================================================================
+int32_t si_infer_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, int32_t M, const double* W_swa,
+                       const double* P, const double* X, const double* Y, int32_t in_dim, int32_t out_dim,
+                       int64_t B, double sigma_m, int32_t compute_dtype) {
+  CHECK_CTX(ctx);
+  if (!layers || L <= 0 || N <= 0 || M <= 0 || !X || !Y || in_dim <= 0 || out_dim <= 0 || B <= 0)
+    return fail(ctx, SI_ERR_INVALID, "si_infer_setup: bad argument");
+  if (!(sigma_m > 0.0)) return fail(ctx, SI_ERR_INVALID, "si_infer_setup: sigma_m must be positive");
+  if (compute_dtype != SI_F64)
+    return fail(ctx, SI_ERR_INVALID, "si_infer_setup: only compute_dtype = SI_F64 (the reference's arithmetic) is implemented");
+  if ((W_swa == nullptr) != (P == nullptr))
+    return fail(ctx, SI_ERR_INVALID, "si_infer_setup: W_swa and P must both be given or both be NULL");
+  // model must be a Chain of Dense layers (reference throws "model_re function is not available", libs.jl:59)
+  int32_t width = in_dim;
+  int64_t maxw = 0;
+  int main_layer = 0;
+  double main_flops = -1.0;
+  for (int l = 0; l < L; ++l) {
+    const si_layer& ly = layers[l];
+    if (ly.kind != SI_LAYER_DENSE)
+      return fail(ctx, SI_ERR_INVALID, "Error: model_re function is not available for this model (only Dense layers)");
+    if (ly.in != width || ly.out <= 0 || ly.act < 0 || ly.act > SI_ACT_SIGMOID)
+      return fail(ctx, SI_ERR_INVALID, "si_infer_setup: layer dimensions do not chain");
+    if (ly.w_off < 0 || ly.b_off < 0 || ly.w_off + (int64_t)ly.in * ly.out > N || ly.b_off + ly.out > N)
+      return fail(ctx, SI_ERR_INVALID, "si_infer_setup: layer offsets outside the flat weight vector");
+    width = ly.out;
+    maxw = std::max<int64_t>(maxw, ly.out);
+    const double fl = 2.0 * ly.in * (double)ly.out;
+    if (fl > main_flops) {
+      main_flops = fl;
+      main_layer = l;
+    }
+  }
+  if (width != out_dim) return fail(ctx, SI_ERR_INVALID, "si_infer_setup: last layer width != out_dim");
+  BIND(ctx);
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  free_infer(ctx);
+  if (!W_swa) {
+    if (!ctx->c_finished) return fail(ctx, SI_ERR_STATE, "si_infer_setup: no finished construction to take W_swa / P from");
+    if (ctx->N != N || ctx->M_built != M)
+      return fail(ctx, SI_ERR_INVALID, "si_infer_setup: N / M differ from the finished construction");
+    ctx->i_swa = ctx->d_swa;
+    ctx->i_P = ctx->d_P;
+    ctx->ldP = ctx->ldA;
+  } else {
+    ctx->ldP = pad_ld(N);
+    if (dev_alloc(&ctx->d_iswa, (size_t)ctx->ldP) != hipSuccess ||
+        dev_alloc(&ctx->d_iP, (size_t)ctx->ldP * M) != hipSuccess) {
+      free_infer(ctx);
+      return fail(ctx, SI_ERR_NOMEM, "si_infer_setup: allocation of W_swa / P failed");
+    }
+    SI_HIP(ctx, hipMemsetAsync(ctx->d_iswa, 0, (size_t)ctx->ldP * sizeof(double), ctx->stream));
+    SI_HIP(ctx, hipMemsetAsync(ctx->d_iP, 0, (size_t)ctx->ldP * M * sizeof(double), ctx->stream));
+    SI_HIP(ctx, hipMemcpyAsync(ctx->d_iswa, W_swa, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SI_HIP(ctx, hipMemcpy2DAsync(ctx->d_iP, (size_t)ctx->ldP * sizeof(double), P, (size_t)N * sizeof(double),
+                                 (size_t)N * sizeof(double), (size_t)M, hipMemcpyHostToDevice, ctx->stream));
+    ctx->i_swa = ctx->d_iswa;
+    ctx->i_P = ctx->d_iP;
+  }
+  ctx->layers.assign(layers, layers + L);
+  ctx->iN = N;
+  ctx->iM = M;
+  ctx->in_dim = in_dim;
+  ctx->out_dim = out_dim;
+  ctx->B = B;
+  ctx->sigma_m = sigma_m;
+  ctx->main_layer = main_layer;
+  ctx->act_elems = maxw * B;
+  ctx->sse_blocks = sse_num_blocks((int64_t)out_dim * B, ctx->num_cu);
+  if (dev_alloc(&ctx->d_X, (size_t)in_dim * B) != hipSuccess || dev_alloc(&ctx->d_Y, (size_t)out_dim * B) != hipSuccess ||
+      dev_alloc(&ctx->d_w, (size_t)pad_ld(N)) != hipSuccess || dev_alloc(&ctx->d_act[0], (size_t)ctx->act_elems) != hipSuccess ||
+      dev_alloc(&ctx->d_act[1], (size_t)ctx->act_elems) != hipSuccess ||
+      dev_alloc(&ctx->d_ssepart, (size_t)ctx->sse_blocks) != hipSuccess) {
+    free_infer(ctx);
+    return fail(ctx, SI_ERR_NOMEM, "si_infer_setup: device allocation failed");
+  }
+  SI_HIP(ctx, hipMemcpyAsync(ctx->d_X, X, (size_t)in_dim * B * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  SI_HIP(ctx, hipMemcpyAsync(ctx->d_Y, Y, (size_t)out_dim * B * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->i_ready = true;
+  return SI_OK;
+}
+
+static int32_t ensure_chains(si_ctx* ctx, int32_t C) {
+  if (ctx->chains_cap >= C) return SI_OK;
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  dev_free(ctx->d_zcur);
+  dev_free(ctx->d_zprop);
+  dev_free(ctx->d_lpcur);
+  dev_free(ctx->d_sse);
+  dev_free(ctx->d_nacc);
+  ctx->chains_cap = 0;
+  if (dev_alloc(&ctx->d_zcur, (size_t)ctx->iM * C) != hipSuccess || dev_alloc(&ctx->d_zprop, (size_t)ctx->iM * C) != hipSuccess ||
+      dev_alloc(&ctx->d_lpcur, (size_t)C) != hipSuccess || dev_alloc(&ctx->d_sse, (size_t)C) != hipSuccess ||
+      dev_alloc(&ctx->d_nacc, (size_t)C) != hipSuccess)
+    return fail(ctx, SI_ERR_NOMEM, "sampler state allocation failed");
+  ctx->chains_cap = C;
+  return SI_OK;
+}
+
+// one density evaluation for chain slot c: d_zprop[:, c] -> d_sse[c]; optionally leaves the model output in *yhat
+static int32_t eval_density(si_ctx* ctx, int c, const double** yhat_out) {
+  const int64_t N = ctx->iN, B = ctx->B;
+  const int32_t M = ctx->iM;
+  {
+    ProfScope ps(ctx, SI_K_RECON, 2.0 * (double)N * M, (double)N * (M + 2) * 8.0);
+    launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, ctx->d_zprop + (size_t)c * M, 1, ctx->d_w,
+                       pad_ld(N), ctx->num_cu);
+  }
+  const double* h = ctx->d_X;
+  for (size_t l = 0; l < ctx->layers.size(); ++l) {
+    const si_layer& ly = ctx->layers[l];
+    double* o = ctx->d_act[l & 1];
+    const double fl = 2.0 * (double)ly.in * (double)ly.out * (double)B;
+    const double by = ((double)ly.in * ly.out + ly.out + (double)(ly.in + ly.out) * (double)B) * 8.0;
+    {
+      ProfScope ps(ctx, SI_K_DENSE, fl, by);
+      ProfScope pm((int)l == ctx->main_layer ? ctx : nullptr, SI_K_DENSE_MAIN, fl, by);
+      launch_dense_f64(ctx->stream, ctx->d_w + ly.w_off, ctx->d_w + ly.b_off, h, o, ly.out, ly.in, B, ly.act);
+    }
+    h = o;
+  }
+  {
+    const int64_t d = (int64_t)ctx->out_dim * B;
+    ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d, 16.0 * (double)d);
+    launch_sse(ctx->stream, h, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c);
+  }
+  SI_HIP(ctx, hipGetLastError());
+  if (yhat_out) *yhat_out = h;
+  return SI_OK;
+}
+
+static double mvnormal_c0(double d, double sigma) {
+  // Distributions.mvnormal_c0: -(d*log(2pi) + logdet(Sigma))/2 with logdet = d*log(sigma^2)
+  return -(d * std::log(2.0 * 3.14159265358979323846) + d * std::log(sigma * sigma)) / 2.0;
+}
+
+int32_t si_logdensity(si_ctx* ctx, const double* Z, int32_t C, double* lp_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_logdensity: call si_infer_setup first");
+  if (!Z || C <= 0 || !lp_out) return fail(ctx, SI_ERR_INVALID, "si_logdensity: bad argument");
+  BIND(ctx);
+  int32_t rc = ensure_chains(ctx, C);
+  if (rc != SI_OK) return rc;
+  SI_HIP(ctx, hipMemcpyAsync(ctx->d_zprop, Z, (size_t)ctx->iM * C * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  for (int c = 0; c < C; ++c)
+    if ((rc = eval_density(ctx, c, nullptr)) != SI_OK) return rc;
+  std::vector<double> sse((size_t)C);
+  SI_HIP(ctx, hipMemcpyAsync(sse.data(), ctx->d_sse, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const double d = (double)ctx->out_dim * (double)ctx->B;
+  const double c0 = mvnormal_c0(d, ctx->sigma_m), s2 = ctx->sigma_m * ctx->sigma_m;
+  for (int c = 0; c < C; ++c) lp_out[c] = c0 - (sse[(size_t)c] / s2) / 2.0;
+  return SI_OK;
+}
+
+int32_t si_forward(si_ctx* ctx, const double* z, double* Yhat_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_forward: call si_infer_setup first");
+  if (!z || !Yhat_out) return fail(ctx, SI_ERR_INVALID, "si_forward: bad argument");
+  BIND(ctx);
+  int32_t rc = ensure_chains(ctx, 1);
+  if (rc != SI_OK) return rc;
+  SI_HIP(ctx, hipMemcpyAsync(ctx->d_zprop, z, (size_t)ctx->iM * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const double* yh = nullptr;
+  if ((rc = eval_density(ctx, 0, &yh)) != SI_OK) return rc;
+  SI_HIP(ctx, hipMemcpyAsync(Yhat_out, yh, (size_t)ctx->out_dim * ctx->B * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0, int32_t nchains,
+                       double* Z_out, double* lp_out, double* accept_rate_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_sample_rwmh: call si_infer_setup first");
+  if (itr <= 0 || nchains <= 0 || chain_id0 < 0 || !(sigma_z > 0.0))
+    return fail(ctx, SI_ERR_INVALID, "si_sample_rwmh: itr, nchains, sigma_z must be positive");
+  BIND(ctx);
+  const int32_t C = nchains, M = ctx->iM;
+  int32_t rc = ensure_chains(ctx, C);
+  if (rc != SI_OK) return rc;
+  double *dZ = nullptr, *dlp = nullptr;
+  if (dev_alloc(&dZ, (size_t)M * itr * C) != hipSuccess || dev_alloc(&dlp, (size_t)itr * C) != hipSuccess) {
+    dev_free(dZ);
+    dev_free(dlp);
+    return fail(ctx, SI_ERR_NOMEM, "si_sample_rwmh: output allocation failed");
+  }
+  const double d = (double)ctx->out_dim * (double)ctx->B;
+  const double c0 = mvnormal_c0(d, ctx->sigma_m), s2 = ctx->sigma_m * ctx->sigma_m;
+  {
+    ProfScope ps(ctx, SI_K_RWMH, 0, 0);
+    launch_rwmh_init(ctx->stream, ctx->d_zcur, ctx->d_lpcur, ctx->d_nacc, M, C);
+  }
+  for (int64_t t = 0; t < itr; ++t) {
+    {
+      ProfScope ps(ctx, SI_K_RWMH, 0, 0);
+      launch_rwmh_propose(ctx->stream, ctx->d_zcur, ctx->d_zprop, M, C, sigma_z, seed, chain_id0, (uint64_t)t);
+    }
+    for (int c = 0; c < C; ++c)
+      if ((rc = eval_density(ctx, c, nullptr)) != SI_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        dev_free(dZ);
+        dev_free(dlp);
+        return rc;
+      }
+    {
+      ProfScope ps(ctx, SI_K_RWMH, 0, 0);
+      launch_rwmh_accept(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->d_lpcur, ctx->d_sse, ctx->d_nacc, M, C, c0, s2,
+                         seed, chain_id0, (uint64_t)t, dZ, dlp, itr);
+    }
+  }
+  hipError_t e = hipGetLastError();
+  std::vector<int64_t> nacc((size_t)C);
+  if (e == hipSuccess && Z_out)
+    e = hipMemcpyAsync(Z_out, dZ, (size_t)M * itr * C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && lp_out)
+    e = hipMemcpyAsync(lp_out, dlp, (size_t)itr * C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(nacc.data(), ctx->d_nacc, (size_t)C * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  dev_free(dZ);
+  dev_free(dlp);
+  if (e != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string("si_sample_rwmh: ") + hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string("si_sample_rwmh: ") + hipGetErrorString(e2));
+  if (accept_rate_out)
+    for (int c = 0; c < C; ++c) accept_rate_out[c] = itr > 1 ? (double)nacc[(size_t)c] / (double)(itr - 1) : 0.0;
+  return SI_OK;
+}
+
+int32_t si_reconstruct(si_ctx* ctx, const double* Z, int64_t C, double* W_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_reconstruct: call si_infer_setup first");
+  if (!Z || C <= 0 || !W_out) return fail(ctx, SI_ERR_INVALID, "si_reconstruct: bad argument");
+  BIND(ctx);
+  const int64_t N = ctx->iN, ldw = pad_ld(N);
+  const int32_t M = ctx->iM;
+  const int64_t chunk = std::min<int64_t>(C, 64);
+  double *dZ = nullptr, *dW = nullptr;
+  if (dev_alloc(&dZ, (size_t)M * chunk) != hipSuccess || dev_alloc(&dW, (size_t)ldw * chunk) != hipSuccess) {
+    dev_free(dZ);
+    dev_free(dW);
+    return fail(ctx, SI_ERR_NOMEM, "si_reconstruct: allocation failed");
+  }
+  hipError_t e = hipSuccess;
+  for (int64_t c0 = 0; c0 < C && e == hipSuccess; c0 += chunk) {
+    const int64_t nc = std::min(chunk, C - c0);
+    e = hipMemcpyAsync(dZ, Z + c0 * M, (size_t)M * nc * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) break;
+    {
+      ProfScope ps(ctx, SI_K_RECON, 2.0 * (double)N * M * nc, (double)N * (M + 1 + nc) * 8.0);
+      launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, dZ, (int32_t)nc, dW, ldw, ctx->num_cu);
+    }
+    e = hipMemcpy2DAsync(W_out + c0 * N, (size_t)N * sizeof(double), dW, (size_t)ldw * sizeof(double),
+                         (size_t)N * sizeof(double), (size_t)nc, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  dev_free(dZ);
+  dev_free(dW);
+  if (e != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string("si_reconstruct: ") + hipGetErrorString(e));
+  return SI_OK;
+}
+
+}  // extern "C"

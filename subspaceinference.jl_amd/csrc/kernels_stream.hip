@@ -1,0 +1,298 @@
+// HBM-bound streaming kernels of the hot path (gfx950): K1 swa_dev_push, K4 reconstruct, the SSE
+// reduction of K5 and the tiny K6 propose/accept kernels.  This file is compiled with
+// -ffp-contract=off: K1 must round after every operation to match the reference bit for bit.
+#include "philox.h"
+#include "si_internal.h"
+
+namespace si {
+
+// ------------------------------------------------------------------------------------------------
+// K1  reference src/subspace_construction.jl:46-47,51-52
+//       W_swa = (n.*W_swa + W)./(n+1)      -> t = n*s (rounded); u = t + w (rounded); s' = u/(n+1)
+//       W_dev = W - W_swa ; append!(A, W_dev)
+// Algorithmic bytes per element: sizeof(w) + 8 (read s) + 8 (write s) + 8 (write A column).
+// Layout: s and the A column are 256-B aligned (padded leading dimension), so 16-B accesses are legal;
+// each thread handles 4 consecutive elements per iteration (16 B of f32 w / 2 x 16 B of f64).
+// ------------------------------------------------------------------------------------------------
+template <typename WT>
+__device__ __forceinline__ void push_one(const WT* __restrict__ w, double* __restrict__ s,
+                                         double* __restrict__ acol, int64_t i, double n, double np1) {
+#pragma clang fp contract(off)
+  const double wv = (double)w[i];
+  const double t = n * s[i];
+  const double u = t + wv;
+  const double sn = u / np1;
+  s[i] = sn;
+  acol[i] = wv - sn;
+}
+
+template <typename WT, bool W_ALIGNED>
+__global__ __launch_bounds__(256) void swa_dev_push_kernel(const WT* __restrict__ w,
+                                                           double* __restrict__ s,
+                                                           double* __restrict__ acol, int64_t N,
+                                                           double n, double np1) {
+#pragma clang fp contract(off)
+  const int64_t nquad = N >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += stride) {
+    const int64_t i = q << 2;
+    double wv[4];
+    if constexpr (W_ALIGNED) {
+      if constexpr (sizeof(WT) == 4) {
+        const float4 f = *reinterpret_cast<const float4*>(w + i);
+        wv[0] = (double)f.x; wv[1] = (double)f.y; wv[2] = (double)f.z; wv[3] = (double)f.w;
+      } else {
+        const double2 a = *reinterpret_cast<const double2*>(w + i);
+        const double2 b = *reinterpret_cast<const double2*>(w + i + 2);
+        wv[0] = a.x; wv[1] = a.y; wv[2] = b.x; wv[3] = b.y;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wv[j] = (double)w[i + j];
+    }
+    const double2 s0 = *reinterpret_cast<const double2*>(s + i);
+    const double2 s1 = *reinterpret_cast<const double2*>(s + i + 2);
+    const double sv[4] = {s0.x, s0.y, s1.x, s1.y};
+    double sn[4], dv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double t = n * sv[j];
+      const double u = t + wv[j];
+      sn[j] = u / np1;
+      dv[j] = wv[j] - sn[j];
+    }
+    *reinterpret_cast<double2*>(s + i) = make_double2(sn[0], sn[1]);
+    *reinterpret_cast<double2*>(s + i + 2) = make_double2(sn[2], sn[3]);
+    *reinterpret_cast<double2*>(acol + i) = make_double2(dv[0], dv[1]);
+    *reinterpret_cast<double2*>(acol + i + 2) = make_double2(dv[2], dv[3]);
+  }
+  // tail (N mod 4 elements) by the first threads of block 0
+  if (blockIdx.x == 0) {
+    const int64_t i = (nquad << 2) + threadIdx.x;
+    if (i < N) push_one<WT>(w, s, acol, i, n, np1);
+  }
+}
+
+static int stream_grid(int64_t work_items, int num_cu) {
+  int64_t blocks = (work_items + 255) / 256;
+  const int64_t cap = (int64_t)num_cu * 8;  // ~2048 blocks, grid-stride beyond (guide: Guideline 11)
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+void launch_swa_dev_push(hipStream_t st, const void* w, int32_t w_dtype, double* s, double* acol,
+                         int64_t N, double n, int num_cu) {
+  const int grid = stream_grid(N >> 2, num_cu);
+  const bool aligned = (reinterpret_cast<uintptr_t>(w) & 15u) == 0;
+  const double np1 = n + 1.0;
+  if (w_dtype == SI_F32) {
+    const float* wf = static_cast<const float*>(w);
+    if (aligned)
+      hipLaunchKernelGGL((swa_dev_push_kernel<float, true>), dim3(grid), dim3(256), 0, st, wf, s, acol, N, n, np1);
+    else
+      hipLaunchKernelGGL((swa_dev_push_kernel<float, false>), dim3(grid), dim3(256), 0, st, wf, s, acol, N, n, np1);
+  } else {
+    const double* wd = static_cast<const double*>(w);
+    if (aligned)
+      hipLaunchKernelGGL((swa_dev_push_kernel<double, true>), dim3(grid), dim3(256), 0, st, wd, s, acol, N, n, np1);
+    else
+      hipLaunchKernelGGL((swa_dev_push_kernel<double, false>), dim3(grid), dim3(256), 0, st, wd, s, acol, N, n, np1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4  reference src/space_inference.jl:91 and :125   new_W = W_swa + P*z
+// Algorithmic bytes per row: 8*(M+1) read + 8*C written; P is read ONCE for up to CB chains.
+// Each thread owns 2 consecutive rows (16-B loads down each column of P: lanes are consecutive rows, so
+// a wave reads 1 KiB contiguous per column); z is wave-uniform (scalar loads).
+// ------------------------------------------------------------------------------------------------
+template <int CB>
+__global__ __launch_bounds__(256) void reconstruct_kernel(const double* __restrict__ swa,
+                                                          const double* __restrict__ P, int64_t ldP,
+                                                          int64_t N, int32_t M,
+                                                          const double* __restrict__ Z,
+                                                          double* __restrict__ w, int64_t ldw) {
+  const int64_t npair = (N + 1) >> 1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npair; p += stride) {
+    const int64_t r = p << 1;
+    double2 acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[c] = make_double2(0.0, 0.0);
+    for (int m = 0; m < M; ++m) {
+      const double2 pv = *reinterpret_cast<const double2*>(P + r + (int64_t)m * ldP);
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const double z = Z[m + c * M];
+        acc[c].x += pv.x * z;
+        acc[c].y += pv.y * z;
+      }
+    }
+    const double2 sv = *reinterpret_cast<const double2*>(swa + r);
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      double* dst = w + (int64_t)c * ldw + r;
+      if (r + 1 < N) {
+        if ((ldw & 1) == 0)
+          *reinterpret_cast<double2*>(dst) = make_double2(sv.x + acc[c].x, sv.y + acc[c].y);
+        else {
+          dst[0] = sv.x + acc[c].x;
+          dst[1] = sv.y + acc[c].y;
+        }
+      } else {
+        dst[0] = sv.x + acc[c].x;
+      }
+    }
+  }
+}
+
+void launch_reconstruct(hipStream_t st, const double* swa, const double* P, int64_t ldP, int64_t N,
+                        int32_t M, const double* Z, int32_t C, double* w, int64_t ldw, int num_cu) {
+  const int grid = stream_grid((N + 1) >> 1, num_cu);
+  int c0 = 0;
+  while (c0 < C) {
+    const int rem = C - c0;
+    const double* Zc = Z + (int64_t)c0 * M;
+    double* wc = w + (int64_t)c0 * ldw;
+    if (rem >= 4) {
+      hipLaunchKernelGGL((reconstruct_kernel<4>), dim3(grid), dim3(256), 0, st, swa, P, ldP, N, M, Zc, wc, ldw);
+      c0 += 4;
+    } else if (rem >= 2) {
+      hipLaunchKernelGGL((reconstruct_kernel<2>), dim3(grid), dim3(256), 0, st, swa, P, ldP, N, M, Zc, wc, ldw);
+      c0 += 2;
+    } else {
+      hipLaunchKernelGGL((reconstruct_kernel<1>), dim3(grid), dim3(256), 0, st, swa, P, ldP, N, M, Zc, wc, ldw);
+      c0 += 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 tail  reference src/space_inference.jl:94   ||vec(Y) - vec(f(X))||^2
+// Deterministic: fixed block count, wave shuffle -> LDS -> per-block partial; block 0 of a second launch
+// sums the partials in index order.  Same inputs => same bits.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void sse_partial_kernel(const double* __restrict__ yhat,
+                                                          const double* __restrict__ y, int64_t d,
+                                                          double* __restrict__ part) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d; i += stride) {
+    const double r = y[i] - yhat[i];
+    acc += r * r;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sse_final_kernel(const double* __restrict__ part, int n,
+                                                        double* __restrict__ out) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+int sse_num_blocks(int64_t d, int num_cu) {
+  int64_t b = (d + 1023) / 1024;
+  if (b > (int64_t)num_cu * 4) b = (int64_t)num_cu * 4;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+void launch_sse(hipStream_t st, const double* yhat, const double* y, int64_t d, double* part,
+                int nblocks, double* sse_out) {
+  hipLaunchKernelGGL(sse_partial_kernel, dim3(nblocks), dim3(256), 0, st, yhat, y, d, part);
+  hipLaunchKernelGGL(sse_final_kernel, dim3(1), dim3(256), 0, st, part, nblocks, sse_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6  reference src/space_inference.jl:111-116 (AdvancedMH 0.6.2 RWMH + AbstractMCMC sample)
+//   step 0: z0 ~ N(0, sigma_z^2 I), always kept;  step t: z' = z + sigma_z*eps, accept iff -Exp(1) < lp'-lp
+// State stays on the device; one block per chain.
+// ------------------------------------------------------------------------------------------------
+__global__ void rwmh_init_kernel(double* zcur, double* lpcur, int64_t* nacc, int32_t M) {
+  const int c = blockIdx.x;
+  for (int m = threadIdx.x; m < M; m += blockDim.x) zcur[m + c * M] = 0.0;
+  if (threadIdx.x == 0) {
+    lpcur[c] = -__builtin_inf();
+    nacc[c] = 0;
+  }
+}
+
+__global__ void rwmh_propose_kernel(const double* __restrict__ zcur, double* __restrict__ zprop,
+                                    int32_t M, double sigma_z, uint64_t seed, int32_t chain_id0,
+                                    uint64_t step) {
+  const int c = blockIdx.x;
+  const uint32_t chain = (uint32_t)(chain_id0 + c);
+  const int nblk = (M + 1) >> 1;
+  for (int j = threadIdx.x; j < nblk; j += blockDim.x) {
+    double n0, n1;
+    philox_normal2(seed, chain, step, (uint32_t)j, n0, n1);
+    const int m0 = 2 * j;
+    zprop[m0 + c * M] = zcur[m0 + c * M] + sigma_z * n0;
+    if (m0 + 1 < M) zprop[m0 + 1 + c * M] = zcur[m0 + 1 + c * M] + sigma_z * n1;
+  }
+}
+
+__global__ void rwmh_accept_kernel(double* __restrict__ zcur, const double* __restrict__ zprop,
+                                   double* __restrict__ lpcur, const double* __restrict__ sse,
+                                   int64_t* __restrict__ nacc, int32_t M, double c0, double sigma2,
+                                   uint64_t seed, int32_t chain_id0, uint64_t step,
+                                   double* __restrict__ Z_out, double* __restrict__ lp_out,
+                                   int64_t itr) {
+  const int c = blockIdx.x;
+  const uint32_t chain = (uint32_t)(chain_id0 + c);
+  // Distributions.logpdf(MvNormal(mu, sigma), y) = c0 - (sse / sigma^2) / 2
+  const double lp_new = c0 - (sse[c] / sigma2) / 2.0;
+  const double lp_old = lpcur[c];
+  bool accept;
+  if (step == 0) {
+    accept = true;
+  } else {
+    const double e = philox_randexp(seed, chain, step);
+    accept = (-e < lp_new - lp_old);  // NaN compares false => reject, as in Julia
+  }
+  const double lp_keep = accept ? lp_new : lp_old;
+  for (int m = threadIdx.x; m < M; m += blockDim.x) {
+    const double zv = accept ? zprop[m + c * M] : zcur[m + c * M];
+    zcur[m + c * M] = zv;
+    Z_out[m + (int64_t)M * (step + (uint64_t)itr * c)] = zv;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lpcur[c] = lp_keep;
+    lp_out[step + (uint64_t)itr * c] = lp_keep;
+    if (accept && step > 0) nacc[c] += 1;
+  }
+}
+
+void launch_rwmh_init(hipStream_t st, double* zcur, double* lpcur, int64_t* nacc, int32_t M, int32_t C) {
+  hipLaunchKernelGGL(rwmh_init_kernel, dim3(C), dim3(64), 0, st, zcur, lpcur, nacc, M);
+}
+void launch_rwmh_propose(hipStream_t st, const double* zcur, double* zprop, int32_t M, int32_t C,
+                         double sigma_z, uint64_t seed, int32_t chain_id0, uint64_t step) {
+  hipLaunchKernelGGL(rwmh_propose_kernel, dim3(C), dim3(64), 0, st, zcur, zprop, M, sigma_z, seed, chain_id0, step);
+}
+void launch_rwmh_accept(hipStream_t st, double* zcur, const double* zprop, double* lpcur,
+                        const double* sse, int64_t* nacc, int32_t M, int32_t C, double c0,
+                        double sigma2, uint64_t seed, int32_t chain_id0, uint64_t step,
+                        double* Z_out, double* lp_out, int64_t itr) {
+  hipLaunchKernelGGL(rwmh_accept_kernel, dim3(C), dim3(64), 0, st, zcur, zprop, lpcur, sse, nacc, M, c0,
+                     sigma2, seed, chain_id0, step, Z_out, lp_out, itr);
+}
+
+}  // namespace si

@@ -1,0 +1,139 @@
+// Internal declarations shared by the C-ABI translation unit and the kernel launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/subspace_hip.h"
+
+namespace si {
+
+// leading dimensions of device matrices are padded to a multiple of this many elements (256 B) so that
+// every column starts 256-B aligned and 16-B vector accesses are legal whatever N is (N is odd at cfg2).
+constexpr int64_t LD_ALIGN = 32;
+inline int64_t pad_ld(int64_t n) { return (n + LD_ALIGN - 1) / LD_ALIGN * LD_ALIGN; }
+
+struct EventPair {
+  hipEvent_t a, b;
+  int cls;
+};
+
+struct Ctx {
+  int device = -1;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  char devname[256] = {0};
+  int num_cu = 256;
+
+  // profiling
+  bool profiling = false;
+  std::vector<EventPair> pending;
+  std::vector<hipEvent_t> event_pool;
+  si_stats stats{};
+
+  // ---- construction state (reference src/subspace_construction.jl:31-33,45-52,61-65)
+  bool c_active = false, c_finished = false, gram_valid = false;
+  int64_t N = 0, ldA = 0, Kcap = 0, K = 0;  // K = columns held
+  int32_t max_cols = 0;
+  int64_t npush = 0;
+  double* d_swa = nullptr;    // N (padded) fp64
+  double* d_A = nullptr;      // ldA x Kcap fp64, column-major; with max_cols>0 a ring of max_cols columns
+  void* d_wstage = nullptr;   // staging for host snapshots
+  size_t wstage_bytes = 0;
+  double* d_G = nullptr;      // K x K
+  double* d_Gpart = nullptr;  // partial slabs
+  size_t gpart_bytes = 0;
+  double* d_V = nullptr;      // K x Mpad (row k contiguous)
+  double* d_P = nullptr;      // ldA x M
+  int32_t M_built = 0;
+  std::vector<double> svals;
+
+  // ---- inference state (reference src/space_inference.jl:88-95,111-116,125)
+  bool i_ready = false;
+  bool i_owns_swaP = false;
+  std::vector<si_layer> layers;
+  int64_t iN = 0, ldP = 0;
+  int32_t iM = 0;
+  const double* i_swa = nullptr;  // device
+  const double* i_P = nullptr;    // device, ldP x M
+  double* d_iswa = nullptr;       // owned copies when set from host
+  double* d_iP = nullptr;
+  double* d_X = nullptr;
+  double* d_Y = nullptr;
+  int32_t in_dim = 0, out_dim = 0;
+  int64_t B = 0;
+  double sigma_m = 1.0;
+  double* d_w = nullptr;       // reconstructed weights, N
+  double* d_act[2] = {nullptr, nullptr};  // ping-pong activations, maxwidth x B
+  int64_t act_elems = 0;
+  double* d_ssepart = nullptr;  // per-block SSE partials
+  int sse_blocks = 0;
+  int main_layer = 0;
+  // sampler state (device)
+  double* d_zcur = nullptr;   // M x C
+  double* d_zprop = nullptr;  // M x C
+  double* d_lpcur = nullptr;  // C
+  double* d_sse = nullptr;    // C
+  int64_t* d_nacc = nullptr;  // C
+  int32_t chains_cap = 0;
+};
+
+// error helpers -------------------------------------------------------------------------------
+int32_t fail(Ctx* c, int32_t code, const std::string& msg);
+#define SI_HIP(c, expr)                                                                    \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return si::fail((c), SI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// profiling scope: records an event pair around kernel launches of one class
+struct ProfScope {
+  Ctx* c;
+  int cls;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(Ctx* c, int cls, double flops, double bytes);
+  ~ProfScope();
+};
+
+// ---- kernel launchers (kernels_*.hip) -------------------------------------------------------
+// K1: s <- (n*s + w)/(n+1); acol <- w - s   (three rounded ops, no FMA; reference :46-47,51)
+void launch_swa_dev_push(hipStream_t st, const void* w, int32_t w_dtype, double* s, double* acol,
+                         int64_t N, double n, int num_cu);
+// K2: G = A'A over columns [0,K) of A (ldA), rows [0,N); result K x K col-major symmetric in G
+// returns bytes of partial workspace required (if Gpart == nullptr nothing is launched)
+size_t launch_gram(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, double* Gpart,
+                   double* G, int num_cu, Ctx* prof);
+// K3: P[:, m] = sum_k A[:, k] * V[k*Mpad + m], m < M;  Mpad = project_mpad(M) (V rows zero-padded)
+int project_mpad(int M);
+void launch_project(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, const double* V,
+                    int32_t M, int32_t Mpad, double* P, int64_t ldP, int num_cu);
+// K4: w[c*ldw + r] = swa[r] + sum_m P[r + m*ldP] * Z[m + c*M]
+void launch_reconstruct(hipStream_t st, const double* swa, const double* P, int64_t ldP, int64_t N,
+                        int32_t M, const double* Z, int32_t C, double* w, int64_t ldw, int num_cu);
+// K5: Hout[i + out*b] = act(sum_k W[i + out*k] * Hin[k + in*b] + bias[i])
+void launch_dense_f64(hipStream_t st, const double* W, const double* bias, const double* Hin,
+                      double* Hout, int32_t out, int32_t in, int64_t B, int32_t act);
+// K5: sse = sum (y - yhat)^2 over d elements; deterministic two-stage
+int sse_num_blocks(int64_t d, int num_cu);
+void launch_sse(hipStream_t st, const double* yhat, const double* y, int64_t d, double* part,
+                int nblocks, double* sse_out);
+// K6
+void launch_rwmh_init(hipStream_t st, double* zcur, double* lpcur, int64_t* nacc, int32_t M, int32_t C);
+void launch_rwmh_propose(hipStream_t st, const double* zcur, double* zprop, int32_t M, int32_t C,
+                         double sigma_z, uint64_t seed, int32_t chain_id0, uint64_t step);
+void launch_rwmh_accept(hipStream_t st, double* zcur, const double* zprop, double* lpcur,
+                        const double* sse, int64_t* nacc, int32_t M, int32_t C, double c0,
+                        double sigma2, uint64_t seed, int32_t chain_id0, uint64_t step,
+                        double* Z_out, double* lp_out, int64_t itr);
+
+// host symmetric eigensolver (eig.cpp): a is n x n symmetric col-major, overwritten by eigenvectors
+// (columns), w gets eigenvalues ascending.  Returns 0 on success.
+int sym_eig(int n, double* a, double* w);
+
+}  // namespace si
+
+struct si_ctx : public si::Ctx {};

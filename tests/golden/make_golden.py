@@ -1,0 +1,62 @@
+"""Generates tests/golden/*.npz from the CPU oracle (oracle/subspace_oracle.py).
+
+The reference holds NO fixtures for this path (test/runtests.jl is empty) and cannot be run here (no Julia),
+so these vectors pin the ORACLE's outputs, not the reference's: PARITY UNPINNED.  They guard
+against silent drift of the oracle and give the GPU tests committed inputs/outputs at README-toy size.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import subspace_oracle as so  # noqa: E402
+
+TOY_DIMS, TOY_ACTS = [10, 20, 20, 2], [0, 0, 0]  # README.md:62 Chain(Dense(10,20),Dense(20,20),Dense(20,2))
+
+
+def glorot(rng, dims):
+    ws = []
+    for fin, fout in zip(dims[:-1], dims[1:]):
+        ws.append(((rng.random((fout, fin)) - 0.5) * np.sqrt(24.0 / (fin + fout))).astype(np.float32))
+        ws.append(np.zeros(fout, dtype=np.float32))
+    return ws
+
+
+def snapshot_stream(n, k, seed, dtype=np.float32):
+    """random-walk weights w_t = w_0 + 0.01*cumsum(randn): full-rank deviation matrix."""
+    rng = np.random.default_rng(seed)
+    w0 = so.extract_params(glorot(np.random.default_rng(1), TOY_DIMS)).astype(np.float64)
+    steps = 0.01 * rng.standard_normal((k, n))
+    return [(w0 + c).astype(dtype) for c in np.cumsum(steps, axis=0)]
+
+
+def main():
+    table, n = so.layer_table(TOY_DIMS, TOY_ACTS)
+    assert n == 682
+    # ---- construction, K = 12 (T=3 epochs x 4 batches, c=1 -> n = 1,1,1,1,2,2,2,2,3,3,3,3), M = 3
+    snaps = snapshot_stream(n, 12, seed=2)
+    ns = [float(i) for i in (1, 2, 3) for _ in range(4)]
+    w_swa, a = so.construct_stream(snaps, ns)
+    p, s = so.projection_from_A(a, 3)
+    np.savez_compressed(os.path.join(HERE, "toy_construct_k12.npz"), snapshots=np.stack(snaps), ns=np.array(ns),
+                        W_swa=w_swa, A=a, P=p, s=s[:3])
+    # ---- density + RWMH at README toy size: X = rand(10,100), Y = rand(2,100), M=3, itr=10, sigma = 1
+    rng = np.random.default_rng(0)
+    x = rng.random((10, 100))
+    y = rng.random((2, 100))
+    zs = np.asfortranarray(np.random.default_rng(3).standard_normal((3, 5)))
+    lps = np.array([so.logdensity(table, w_swa, p, x, y, 1.0, zs[:, j]) for j in range(5)])
+    yhat0 = so.forward(table, so.reconstruct(w_swa, p, zs[:, 0]), x)
+    z_chain, lp_chain, w_chain, nacc = so.sub_inference(table, x, y, w_swa, p, 1.0, 1.0, 10, seed=1234, chain=0)
+    np.savez_compressed(os.path.join(HERE, "toy_density_rwmh.npz"), X=x, Y=y, W_swa=w_swa, P=p, Z=zs, lp=lps,
+                        Yhat0=yhat0, Z_chain=z_chain, lp_chain=lp_chain, W_chain=w_chain, nacc=np.array(nacc),
+                        seed=np.array(1234), sigma_z=np.array(1.0), sigma_m=np.array(1.0))
+    print("wrote golden fixtures to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,241 @@
+"""GPU parity tests: every HIP kernel of the hot path, called through the C ABI, against the CPU oracle on the
+same seeded inputs and against the committed golden fixtures.  Tolerances are written next to each check:
+bit-exact for K1 (three rounded fp64 operations per element), stated rtol elsewhere (fp64 summation order
+differs from LAPACK/BLAS).  north_star's tolerance is rtol 1e-4 for W_swa, P (columns up to sign) and lp; the
+fp64 path is held to much tighter bounds here."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import subspace_oracle as so
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOY_TABLE, TOY_N = so.layer_table([10, 20, 20, 2], [0, 0, 0])
+
+
+def _align_signs(p, ref):
+    return p * np.sign(np.sum(p * ref, axis=0))[None, :]
+
+
+def _snap_stream(n, k, seed, dtype):
+    rng = np.random.default_rng(seed)
+    w0 = rng.standard_normal(n)
+    return [(w0 + c).astype(dtype) for c in np.cumsum(0.01 * rng.standard_normal((k, n)), axis=0)]
+
+
+# ----------------------------------------------------------------------------------------------- K1
+@pytest.mark.parametrize("n,dtype", [(1, np.float32), (3, np.float64), (682, np.float32), (4099, np.float32),
+                                     (100003, np.float64), (1047361, np.float32)])
+def test_swa_dev_push_bit_exact(gpu_ctx, n, dtype):
+    k = 5
+    snaps = _snap_stream(n, k, seed=n, dtype=dtype)
+    ns = [1.0, 1.0, 2.0, 2.0, 3.0]  # Q2: n is the epoch counter, repeated per batch
+    w_ref, a_ref = so.construct_stream(snaps, ns)
+    gpu_ctx.construct_begin(n, k)
+    for w, nn in zip(snaps, ns):
+        gpu_ctx.construct_push(w, nn)
+    a = gpu_ctx.construct_get_A(0, k)
+    assert np.array_equal(a, a_ref)  # bit-exact: same three rounded operations as reference :46-47,51
+    if k <= n:
+        w_swa, _, _, kk = gpu_ctx.construct_finish(1, want_p=False)
+        assert kk == k and np.array_equal(w_swa, w_ref)
+
+
+def test_push_state_errors(si, gpu_ctx):
+    gpu_ctx.construct_begin(10, 2)
+    gpu_ctx.construct_push(np.zeros(10, dtype=np.float32), 1.0)
+    gpu_ctx.construct_push(np.ones(10, dtype=np.float32), 1.0)
+    with pytest.raises(si.SubspaceError, match="more pushes than K_capacity"):
+        gpu_ctx.construct_push(np.ones(10, dtype=np.float32), 1.0)
+    with pytest.raises(si.SubspaceError, match="DimensionMismatch"):
+        gpu_ctx.construct_push(np.ones(9, dtype=np.float32), 1.0)
+    with pytest.raises(si.BoundsError):  # reference: BoundsError at U[:,1:M] when M > K
+        gpu_ctx.construct_finish(3)
+
+
+# ----------------------------------------------------------------------------------------------- K2 / H1 / K3
+@pytest.mark.parametrize("n,k,m", [(682, 12, 3), (5000, 64, 8), (4097, 65, 20), (100003, 100, 20), (682, 200, 5),
+                                   (50, 130, 4)])
+def test_gram_and_projection(gpu_ctx, n, k, m):
+    snaps = _snap_stream(n, k, seed=7 * n + k, dtype=np.float32)
+    ns = [float(1 + i // 4) for i in range(k)]
+    w_ref, a_ref = so.construct_stream(snaps, ns)
+    gpu_ctx.construct_begin(n, k)
+    for w, nn in zip(snaps, ns):
+        gpu_ctx.construct_push(w, nn)
+    gpu_ctx.construct_gram()
+    g = gpu_ctx.construct_gram_get()
+    g_ref = a_ref.T @ a_ref
+    assert np.array_equal(g, g.T)  # symmetric by construction
+    assert np.allclose(g, g_ref, rtol=1e-11, atol=1e-11 * np.abs(g_ref).max())
+    w_swa, p, s, kk = gpu_ctx.construct_finish(m)
+    p_ref, s_ref = so.projection_from_A(a_ref, m)
+    assert kk == k and np.array_equal(w_swa, w_ref)
+    assert np.allclose(s, s_ref[:m], rtol=1e-8)                     # singular values
+    scale = np.abs(p_ref).max()
+    assert np.allclose(_align_signs(p, p_ref), p_ref, rtol=1e-6, atol=1e-8 * scale)  # P columns up to sign
+    assert np.allclose(p.T @ p, np.diag(s ** 2), atol=1e-8 * s[0] ** 2)               # P'P = diag(s^2)
+
+
+def test_gram_deterministic(gpu_ctx):
+    n, k = 30011, 40
+    snaps = _snap_stream(n, k, seed=5, dtype=np.float32)
+    outs = []
+    for _ in range(2):
+        gpu_ctx.construct_begin(n, k)
+        for i, w in enumerate(snaps):
+            gpu_ctx.construct_push(w, float(1 + i))
+        gpu_ctx.construct_gram()
+        outs.append(gpu_ctx.construct_gram_get())
+    assert np.array_equal(outs[0], outs[1])  # fixed-order partial reduction: same inputs, same bits
+
+
+def test_rank_deficient_is_bounds_error(si, gpu_ctx):
+    # 6 pushes of the SAME weights with growing n: deviation columns are all multiples of one vector -> rank 1
+    n = 300
+    w = np.random.default_rng(0).standard_normal(n).astype(np.float32)
+    gpu_ctx.construct_begin(n, 6)
+    for i in range(6):
+        gpu_ctx.construct_push(w, float(i + 1))
+    with pytest.raises(si.BoundsError):
+        gpu_ctx.construct_finish(3)
+    w_swa, p, s, _ = gpu_ctx.construct_finish(1)
+    assert p.shape == (n, 1) and s[0] > 0
+
+
+def test_column_shift_option(gpu_ctx):
+    # max_cols = M keeps the newest M deviation columns (paper's shift, reference :48-50 commented out)
+    n, k, m = 1000, 10, 4
+    snaps = _snap_stream(n, k, seed=9, dtype=np.float32)
+    ns = [float(i + 1) for i in range(k)]
+    w_ref, a_ref = so.construct_stream(snaps, ns)
+    gpu_ctx.construct_begin(n, k, max_cols=m)
+    for w, nn in zip(snaps, ns):
+        gpu_ctx.construct_push(w, nn)
+    w_swa, p, s, kk = gpu_ctx.construct_finish(m)
+    p_ref, s_ref = so.projection_from_A(np.asfortranarray(a_ref[:, -m:]), m)
+    assert kk == m and np.array_equal(w_swa, w_ref)
+    assert np.allclose(s, s_ref[:m], rtol=1e-8)
+    assert np.allclose(_align_signs(p, p_ref), p_ref, rtol=1e-6, atol=1e-8 * np.abs(p_ref).max())
+
+
+def test_golden_construct(gpu_ctx):
+    g = np.load(os.path.join(GOLD, "toy_construct_k12.npz"))
+    gpu_ctx.construct_begin(682, 12)
+    for w, nn in zip(g["snapshots"], g["ns"]):
+        gpu_ctx.construct_push(w, float(nn))
+    assert np.array_equal(gpu_ctx.construct_get_A(0, 12), g["A"])
+    w_swa, p, s, _ = gpu_ctx.construct_finish(3)
+    assert np.array_equal(w_swa, g["W_swa"])
+    assert np.allclose(s, g["s"], rtol=1e-9)
+    assert np.allclose(_align_signs(p, g["P"]), g["P"], rtol=1e-7, atol=1e-10)
+
+
+# ----------------------------------------------------------------------------------------------- K4 / K5
+def _random_problem(dims, acts, b, m, seed):
+    rng = np.random.default_rng(seed)
+    table, n = so.layer_table(dims, acts)
+    w_swa = 0.3 * rng.standard_normal(n)
+    p = np.asfortranarray(0.05 * rng.standard_normal((n, m)))
+    x = np.asfortranarray(rng.standard_normal((dims[0], b)))
+    y = np.asfortranarray(rng.standard_normal((dims[-1], b)))
+    return table, n, w_swa, p, x, y
+
+
+@pytest.mark.parametrize("dims,acts,b,m", [
+    ([10, 20, 20, 2], [0, 0, 0], 100, 3),                 # README toy
+    ([2, 200, 50, 50, 50, 1], [1, 1, 1, 1, 0], 333, 5),   # docs/src/nn_example.md MLP
+    ([7, 33, 1], [2, 0], 1, 2),                           # single observation, tanh
+    ([5, 130, 65, 3], [3, 1, 0], 257, 4),                 # sigmoid, ragged tiles in every dimension
+    ([128, 960, 960, 1], [1, 1, 0], 1000, 20),            # cfg2 model, reduced batch
+])
+def test_forward_and_logdensity(gpu_ctx, dims, acts, b, m):
+    table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=sum(dims) + b)
+    gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=0.7)
+    zs = np.asfortranarray(np.random.default_rng(1).standard_normal((m, 3)))
+    yhat = gpu_ctx.forward(zs[:, 0])
+    yref = so.forward(table, so.reconstruct(w_swa, p, zs[:, 0]), x)
+    assert np.allclose(yhat, yref, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(yref).max()))
+    lp = gpu_ctx.logdensity(zs)
+    lp_ref = np.array([so.logdensity(table, w_swa, p, x, y, 0.7, zs[:, j]) for j in range(3)])
+    assert np.allclose(lp, lp_ref, rtol=1e-11)  # north_star: 1e-4
+    w = gpu_ctx.reconstruct(zs)
+    w_ref = w_swa[:, None] + p @ zs
+    assert np.allclose(w, w_ref, rtol=1e-13, atol=1e-14)
+
+
+def test_golden_density_and_chain(gpu_ctx):
+    d = np.load(os.path.join(GOLD, "toy_density_rwmh.npz"))
+    gpu_ctx.infer_setup(TOY_TABLE, TOY_N, 3, d["W_swa"], d["P"], d["X"], d["Y"], sigma_m=1.0)
+    assert np.allclose(gpu_ctx.logdensity(d["Z"]), d["lp"], rtol=1e-12)
+    assert np.allclose(gpu_ctx.forward(d["Z"][:, 0]), d["Yhat0"], rtol=1e-11, atol=1e-13)
+    z, lp, acc = gpu_ctx.sample_rwmh(10, 1.0, seed=1234)
+    # same Philox stream as the oracle: the chains agree step by step (device libm may differ by an ulp)
+    assert np.allclose(z[:, :, 0], d["Z_chain"], rtol=1e-12, atol=1e-14)
+    assert np.allclose(lp[:, 0], d["lp_chain"], rtol=1e-12)
+    assert abs(acc[0] - int(d["nacc"]) / 9.0) < 1e-15
+    w = gpu_ctx.reconstruct(z[:, :, 0])
+    assert np.allclose(w, d["W_chain"], rtol=1e-12, atol=1e-14)
+
+
+# ----------------------------------------------------------------------------------------------- K6
+def test_rwmh_matches_oracle_and_is_reproducible(gpu_ctx):
+    dims, acts, b, m = [6, 40, 3], [1, 0], 500, 6
+    table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=3)
+    gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=2.0)
+    itr = 60
+    z, lp, acc = gpu_ctx.sample_rwmh(itr, 0.05, seed=99, chain_id0=4, nchains=3)
+    for c in range(3):
+        zr, lpr, _, nacc = so.sub_inference(table, x, y, w_swa, p, 0.05, 2.0, itr, seed=99, chain=4 + c)
+        assert np.allclose(z[:, :, c], zr, rtol=1e-11, atol=1e-13)
+        assert np.allclose(lp[:, c], lpr, rtol=1e-11)
+        assert abs(acc[c] - nacc / (itr - 1)) < 1e-12
+    assert 0.05 < acc.mean() < 1.0
+    z2, lp2, _ = gpu_ctx.sample_rwmh(itr, 0.05, seed=99, chain_id0=4, nchains=3)
+    assert np.array_equal(z, z2) and np.array_equal(lp, lp2)  # same seed, same bits
+    z3, _, _ = gpu_ctx.sample_rwmh(itr, 0.05, seed=100, chain_id0=4, nchains=1)
+    assert not np.array_equal(z3[:, :, 0], z[:, :, 0])
+    # itr = 1: only the initial draw z0 ~ proposal
+    z1, lp1, acc1 = gpu_ctx.sample_rwmh(1, 0.05, seed=99, chain_id0=4)
+    assert np.array_equal(z1[:, 0, 0], z[:, 0, 0]) and acc1[0] == 0.0
+
+
+def test_rwmh_stationary_moments(gpu_ctx):
+    # identity "network" 2 -> 2 with W_swa = I-layer, P = basis of the bias: lp(z) = c - |y - z|^2 / (2 sigma^2)
+    table, n = so.layer_table([2, 2], [0])
+    w_swa = np.array([1.0, 0, 0, 1.0, 0, 0])       # W = I, b = 0
+    p = np.zeros((6, 2), order="F")
+    p[4, 0] = p[5, 1] = 1.0                          # z moves the bias
+    x = np.zeros((2, 1), order="F")
+    y = np.array([[0.5], [-1.0]])
+    gpu_ctx.infer_setup(table, n, 2, w_swa, p, x, y, sigma_m=1.0)
+    z, lp, acc = gpu_ctx.sample_rwmh(4000, 1.0, seed=5)
+    burn = z[:, 500:, 0]
+    assert np.all(np.abs(burn.mean(axis=1) - y[:, 0]) < 0.2)   # posterior N(y, I)
+    assert np.all(np.abs(burn.var(axis=1) - 1.0) < 0.3)
+    assert 0.2 < acc[0] < 0.8
+
+
+# ----------------------------------------------------------------------------------------------- API mirror
+def test_api_end_to_end_toy(si, gpu_ctx):
+    """README.md:52-79 through the reference's own function names."""
+    from subspaceinference_jl_amd import flux
+    rng = np.random.default_rng(0)
+    x, y = rng.random((10, 100)), rng.random((2, 100))
+    data = flux.DataLoader(x, y, shuffle=True, rng=np.random.default_rng(1))
+    wr = np.random.default_rng(2)
+    m = flux.Chain(flux.Dense(10, 20, rng=wr), flux.Dense(20, 20, rng=wr), flux.Dense(20, 2, rng=wr))
+    chn, lp, w_swa = si.subspace_inference(m, flux.mse, data, flux.ADAM(0.1), itr=10, T=10, c=1, M=3,
+                                           ctx=gpu_ctx, verbose=False, seed=1)
+    assert len(chn) == 10 and chn[0].shape == (682,) and lp.shape == (10,) and w_swa.shape == (682,)
+    assert np.all(np.isfinite(lp)) and np.all(np.isfinite(w_swa))
+    # K = 1000 > N = 682 (quirk Q3): every column kept
+    assert gpu_ctx.construct_get_A(999, 1).shape == (682, 1)
+    # lp of the first sample equals the oracle's density at the same weights' z (recovered by least squares)
+    w2, p2 = si.subspace_construction(m, flux.mse, data, flux.ADAM(0.1), T=2, c=1, M=3, ctx=gpu_ctx, verbose=False)
+    assert w2.shape == (682,) and p2.shape == (682, 3)
+    chn2, lp2 = si.inference(m, data, w2, p2, itr=5, M=3, alg=":mh", ctx=gpu_ctx, seed=3, σ_z=0.5)
+    z0 = np.linalg.lstsq(p2, chn2[0] - w2, rcond=None)[0]
+    assert np.isclose(lp2[0], so.logdensity(TOY_TABLE, w2, p2, x, y, 1.0, z0), rtol=1e-9)

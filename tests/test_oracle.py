@@ -1,0 +1,117 @@
+"""CPU tests of the oracle.  The reference has no tests or fixtures for this path (PARITY UNPINNED), so the
+oracle is cross-checked by identities that do not depend on it being right (SURVEY.md 8c i-v) and against the
+committed golden vectors (drift guard)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import scipy.stats
+
+from oracle import philox
+from oracle import subspace_oracle as so
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors for philox4x32-10
+    def h(c, k):
+        return [int(v) for v in philox.philox4x32(np.array(c, dtype=np.uint32), np.array(k, dtype=np.uint32))]
+    assert h([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert h([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert h([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_philox_moments():
+    z = np.concatenate([philox.normals(7, 0, t, 20) for t in range(2000)])
+    assert abs(z.mean()) < 0.02 and abs(z.var() - 1.0) < 0.03
+    e = np.array([philox.randexp(7, 1, t) for t in range(4000)])
+    assert abs(e.mean() - 1.0) < 0.05 and e.min() > 0
+
+
+def test_swa_closed_form_and_quirks():
+    # Q1: zero start, first n = 1 -> W/2.  Q2: same n repeated inside an epoch = EMA with factor n/(n+1)
+    w = np.array([2.0, -4.0, 8.0], dtype=np.float32)
+    s, dev = so.swa_dev_push(np.zeros(3), w, 1.0)
+    assert np.array_equal(s, w.astype(np.float64) / 2) and np.array_equal(dev, w / 2)
+    rng = np.random.default_rng(0)
+    ws = [rng.standard_normal(5).astype(np.float32) for _ in range(6)]
+    ns = [1.0, 1.0, 2.0, 2.0, 3.0, 3.0]
+    s_ref, a = so.construct_stream(ws, ns)
+    s = np.zeros(5)
+    for w_, n in zip(ws, ns):
+        s = (n / (n + 1.0)) * s + w_.astype(np.float64) / (n + 1.0)  # algebraically equal EMA form
+    assert np.allclose(s, s_ref, rtol=1e-14, atol=0)
+    assert a.shape == (5, 6)  # Q3: every column kept
+    assert np.array_equal(a[:, -1], ws[-1].astype(np.float64) - s_ref)  # deviation from the UPDATED mean
+
+
+def test_projection_identities():
+    rng = np.random.default_rng(1)
+    a = np.asfortranarray(rng.standard_normal((300, 12)) * np.logspace(0, -2, 12)[None, :])
+    p, s = so.projection_from_A(a, 4)
+    u, sv, vt = np.linalg.svd(a, full_matrices=False)
+    assert np.allclose(p.T @ p, np.diag(sv[:4] ** 2), atol=1e-10)          # P'P = diag(s^2)
+    assert np.allclose(np.abs(p), np.abs(u[:, :4] * sv[:4]), atol=1e-12)    # |P_j| = |U_j s_j|
+    assert np.allclose(np.abs(a @ vt[:4].T), np.abs(p), atol=1e-10)         # P = A V_M up to sign
+    with pytest.raises(IndexError):
+        so.projection_from_A(a, 13)
+
+
+def test_logpdf_against_scipy():
+    rng = np.random.default_rng(2)
+    y, mu = rng.standard_normal(50), rng.standard_normal(50)
+    for sigma in (0.3, 1.0, 2.5):
+        lp, sse = so.mvnormal_logpdf_iso(y, mu, sigma)
+        ref = scipy.stats.multivariate_normal(mean=mu, cov=sigma ** 2 * np.eye(50)).logpdf(y)
+        assert math.isclose(lp, ref, rel_tol=1e-12)
+        assert math.isclose(so.lp_from_sse(sse, 50, sigma), lp, rel_tol=0, abs_tol=0)
+
+
+def test_forward_hand_computed():
+    # 2 -> 2 (relu) -> 1 on 3 points, flat layout [vec(W1) col-major; b1; vec(W2); b2]
+    table, n = so.layer_table([2, 2, 1], [so.ACT_RELU, so.ACT_IDENTITY])
+    assert n == 9 and table[1][3] == 6 and table[1][4] == 8
+    w1 = np.array([[1.0, -2.0], [0.5, 3.0]])  # out x in
+    flat = np.concatenate([w1.reshape(-1, order="F"), [0.1, -0.2], [2.0, -1.0], [0.05]])
+    x = np.array([[1.0, 0.0, -1.0], [2.0, 1.0, 0.5]])
+    h = np.maximum(w1 @ x + np.array([[0.1], [-0.2]]), 0)
+    exp = np.array([[2.0, -1.0]]) @ h + 0.05
+    assert np.allclose(so.forward(table, flat, x), exp, atol=1e-15)
+    # prior term is dead code (Q4): lp is the likelihood alone
+    y = np.zeros((1, 3))
+    lp = so.logdensity(table, flat, np.zeros((9, 1)), x, y, 1.0, np.zeros(1))
+    assert math.isclose(lp, -(3 * math.log(2 * math.pi)) / 2 - float((exp ** 2).sum()) / 2, rel_tol=1e-14)
+
+
+def test_rwmh_gaussian_target():
+    # stationary moments of N(0,1) in 2-D; `itr` samples include the initial draw
+    dens = lambda z: -0.5 * float(z @ z)
+    zs, lps, nacc = so.rwmh(dens, 2, 6000, 1.0, seed=11)
+    assert zs.shape == (2, 6000) and lps.shape == (6000,)
+    assert np.array_equal(zs[:, 0], philox.normals(11, 0, 0, 2))
+    burn = zs[:, 500:]
+    assert np.all(np.abs(burn.mean(axis=1)) < 0.15) and np.all(np.abs(burn.var(axis=1) - 1.0) < 0.2)
+    assert 0.3 < nacc / 5999 < 0.8
+    # rejected steps repeat the previous sample
+    rep = np.all(zs[:, 1:] == zs[:, :-1], axis=0)
+    assert rep.sum() == 5999 - nacc
+
+
+def test_golden_vectors_match_oracle():
+    g = np.load(os.path.join(GOLD, "toy_construct_k12.npz"))
+    w_swa, a = so.construct_stream(list(g["snapshots"]), list(g["ns"]))
+    assert np.array_equal(w_swa, g["W_swa"]) and np.array_equal(a, g["A"])
+    p, s = so.projection_from_A(a, 3)
+    assert np.allclose(s[:3], g["s"], rtol=1e-12)
+    sign = np.sign(np.sum(p * g["P"], axis=0))
+    assert np.allclose(p * sign, g["P"], rtol=1e-9, atol=1e-12)
+    d = np.load(os.path.join(GOLD, "toy_density_rwmh.npz"))
+    table, _ = so.layer_table([10, 20, 20, 2], [0, 0, 0])
+    lps = [so.logdensity(table, d["W_swa"], d["P"], d["X"], d["Y"], 1.0, d["Z"][:, j]) for j in range(5)]
+    assert np.allclose(lps, d["lp"], rtol=1e-12)
+    z, lp, w, nacc = so.sub_inference(table, d["X"], d["Y"], d["W_swa"], d["P"], 1.0, 1.0, 10, seed=1234)
+    assert np.allclose(z, d["Z_chain"], rtol=1e-12) and np.allclose(lp, d["lp_chain"], rtol=1e-12)
+    assert nacc == int(d["nacc"])
