@@ -99,6 +99,9 @@ static void free_infer(Ctx* c) {
   dev_free(c->d_act[0]);
   dev_free(c->d_act[1]);
   dev_free(c->d_ssepart);
+  dev_free(c->d_part);
+  dev_free(c->d_yhat);
+  c->fuse_tail = false;
   dev_free(c->d_zcur);
   dev_free(c->d_zprop);
   dev_free(c->d_lpcur);
@@ -508,12 +511,19 @@ int32_t si_infer_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
   ctx->B = B;
   ctx->sigma_m = sigma_m;
   ctx->main_layer = main_layer;
-  ctx->act_elems = maxw * B;
+  // fused tail: a narrow last layer (regression heads: out = 1) is folded into the epilogue of the layer before it
+  ctx->fuse_tail = (L >= 2) && layers[L - 1].out <= SI_FUSE_MAX_OUT;
+  ctx->fuse_slots = ctx->fuse_tail ? dense_fused_slots(layers[L - 2].out) : 0;
+  int64_t maxstored = 1;
+  for (int l = 0; l < (ctx->fuse_tail ? L - 2 : L); ++l) maxstored = std::max<int64_t>(maxstored, layers[l].out);
+  ctx->act_elems = maxstored * B;
   ctx->sse_blocks = sse_num_blocks((int64_t)out_dim * B, ctx->num_cu);
   if (dev_alloc(&ctx->d_X, (size_t)in_dim * B) != hipSuccess || dev_alloc(&ctx->d_Y, (size_t)out_dim * B) != hipSuccess ||
       dev_alloc(&ctx->d_w, (size_t)pad_ld(N)) != hipSuccess || dev_alloc(&ctx->d_act[0], (size_t)ctx->act_elems) != hipSuccess ||
       dev_alloc(&ctx->d_act[1], (size_t)ctx->act_elems) != hipSuccess ||
-      dev_alloc(&ctx->d_ssepart, (size_t)ctx->sse_blocks) != hipSuccess) {
+      dev_alloc(&ctx->d_ssepart, (size_t)ctx->sse_blocks) != hipSuccess ||
+      (ctx->fuse_tail && (dev_alloc(&ctx->d_part, (size_t)ctx->fuse_slots * out_dim * B) != hipSuccess ||
+                          dev_alloc(&ctx->d_yhat, (size_t)out_dim * B) != hipSuccess))) {
     free_infer(ctx);
     return fail(ctx, SI_ERR_NOMEM, "si_infer_setup: device allocation failed");
   }
@@ -551,7 +561,9 @@ static int32_t eval_density(si_ctx* ctx, int c, const double** yhat_out) {
                        pad_ld(N), ctx->num_cu);
   }
   const double* h = ctx->d_X;
-  for (size_t l = 0; l < ctx->layers.size(); ++l) {
+  const size_t nl = ctx->layers.size();
+  const size_t nstored = ctx->fuse_tail ? nl - 2 : nl;
+  for (size_t l = 0; l < nstored; ++l) {
     const si_layer& ly = ctx->layers[l];
     double* o = ctx->d_act[l & 1];
     const double fl = 2.0 * (double)ly.in * (double)ly.out * (double)B;
@@ -563,8 +575,27 @@ static int32_t eval_density(si_ctx* ctx, int c, const double** yhat_out) {
     }
     h = o;
   }
-  {
-    const int64_t d = (int64_t)ctx->out_dim * B;
+  const int64_t d = (int64_t)ctx->out_dim * B;
+  if (ctx->fuse_tail) {
+    const si_layer& ly = ctx->layers[nl - 2];
+    const si_layer& ll = ctx->layers[nl - 1];
+    const double fl = 2.0 * (double)ly.in * (double)ly.out * (double)B + 2.0 * (double)ll.in * (double)ll.out * (double)B;
+    const double by = ((double)ly.in * ly.out + ly.out + (double)ly.in * (double)B + (double)ll.in * ll.out) * 8.0 +
+                      (double)ctx->fuse_slots * ll.out * (double)B * 8.0;
+    {
+      ProfScope ps(ctx, SI_K_DENSE, fl, by);
+      ProfScope pm(((int)nl - 2 == ctx->main_layer || (int)nl - 1 == ctx->main_layer) ? ctx : nullptr, SI_K_DENSE_MAIN, fl, by);
+      launch_dense_f64_fused(ctx->stream, ctx->d_w + ly.w_off, ctx->d_w + ly.b_off, h, ly.out, ly.in, B, ly.act,
+                             ctx->d_w + ll.w_off, ll.out, ctx->d_part);
+    }
+    {
+      ProfScope ps(ctx, SI_K_SSE, (3.0 + ctx->fuse_slots) * (double)d, (16.0 + 8.0 * ctx->fuse_slots) * (double)d);
+      launch_tail_sse(ctx->stream, ctx->d_part, ctx->fuse_slots, ll.out, B, ctx->d_w + ll.b_off, ll.act, ctx->d_Y,
+                      yhat_out ? ctx->d_yhat : nullptr, ctx->d_ssepart, ctx->sse_blocks);
+      launch_sse_final(ctx->stream, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c);
+    }
+    h = ctx->d_yhat;
+  } else {
     ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d, 16.0 * (double)d);
     launch_sse(ctx->stream, h, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c);
   }

@@ -41,10 +41,15 @@ __device__ __forceinline__ double apply_act(double v, int act) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int MINW, bool VEC, bool KEDGE>
+// FUSE: the layer's output is not stored.  The NEXT (last) layer of the chain, out_last <= 4 wide, is applied in the
+// epilogue: every wave reduces  sum_i Wlast[o][i] * act(H[i][b])  over its own features and writes one partial per
+// (feature slot, o, b) to `part`; tail_sse_kernel adds the slots in fixed order.  This removes the out x B store, the
+// whole GEMV-shaped last layer and its out x B re-read (cfg2: 768 MB written + 768 MB read per sample).
+template <int BM, int BN, int WM, int WN, int MINW, bool VEC, bool KEDGE, bool FUSE>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f64_kernel(
     const double* __restrict__ W, const double* __restrict__ bias, const double* __restrict__ Hin,
-    double* __restrict__ Hout, int out, int in, int64_t B, int act, int nMt, int64_t nNt) {
+    double* __restrict__ Hout, int out, int in, int64_t B, int act, int nMt, int64_t nNt,
+    const double* __restrict__ Wlast, int out_last, double* __restrict__ part) {
 #ifdef SI_GEMM_DEBUG_KNOB
   const int dbg = si_gemm_dbg;  // harness only, bit mask: 1 = every block loads tile (0,0) (L2-hot), 2 = no global loads in the k loop,
                                 // 4 = no barrier in the k loop, 8 = no LDS stores in the k loop (4 and 8 give wrong results: timing only)
@@ -285,7 +290,43 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f64_kernel(
     if (act == SI_ACT_IDENTITY) return v;
     return apply_act(v, act);
   };
-  if constexpr (WIDE) {
+  if constexpr (FUSE) {
+    int gi[TM];
+    double bv[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      gi[a] = iw0 + a * 16 + c;
+      bv[a] = gi[a] < out ? bias[gi[a]] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] = finish(acc[a][b][r] + bv[a]);
+    const int64_t slot = (int64_t)mt * WM + wm;
+    for (int o = 0; o < out_last; ++o) {
+      double wl[TM];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) wl[a] = gi[a] < out ? Wlast[o + (int64_t)out_last * gi[a]] : 0.0;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double p = 0.0;
+#pragma unroll
+          for (int a = 0; a < TM; ++a) p = fma(acc[a][b][r], wl[a], p);
+          // the 16 lanes of a 16-lane row hold the 16 features of one tile column: butterfly sum inside the row
+          p += __shfl_xor(p, 8, 16);
+          p += __shfl_xor(p, 4, 16);
+          p += __shfl_xor(p, 2, 16);
+          p += __shfl_xor(p, 1, 16);
+          const int64_t gb = bw0 + b * 16 + q + 4 * r;
+          if (c == 0 && gb < B) part[(slot * out_last + o) * B + gb] = p;
+        }
+      }
+    }
+  } else if constexpr (WIDE) {
     constexpr int CH_ROW = WI / 2;              // 16-B chunks per row of the wave's sub-tile
     constexpr int NCH = 16 * CH_ROW / 64;       // chunks per lane per 16-row block
     double* reg = smem + wave * (16 * WI);      // wave-private: no workgroup barrier needed (LDS is in-order per wave)
@@ -333,9 +374,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f64_kernel(
   SI_STAMP(3);
 }
 
-template <int BM, int BN, int WM, int WN, int MINW, bool VEC, bool KEDGE>
+struct FuseArgs {
+  const double* Wlast = nullptr;  // out_last x out, column-major (the last layer's weights inside the flat vector)
+  int out_last = 0;
+  double* part = nullptr;         // [slots][out_last][B]
+};
+
+template <int BM, int BN, int WM, int WN, int MINW, bool VEC, bool KEDGE, bool FUSE>
 static void launch_dense_inst(hipStream_t st, const double* W, const double* bias, const double* Hin, double* Hout,
-                              int32_t out, int32_t in, int64_t B, int32_t act) {
+                              int32_t out, int32_t in, int64_t B, int32_t act, const FuseArgs& fa) {
   size_t lds = 2 * (16 * (BM + 16) + BN * 18) * sizeof(double);
 #ifdef SI_GEMM_DEBUG_KNOB
   if (si_gemm_lds_floor > lds) lds = si_gemm_lds_floor;  // harness: force fewer workgroups per CU
@@ -345,33 +392,33 @@ static void launch_dense_inst(hipStream_t st, const double* W, const double* bia
   const int64_t nNt = (B + BN - 1) / BN;
   const int64_t groups = (nNt + 7) / 8;  // batch panels per XCD lane
   const int64_t grid = groups * nMt * 8;
-  auto kern = dense_f64_kernel<BM, BN, WM, WN, MINW, VEC, KEDGE>;
+  auto kern = dense_f64_kernel<BM, BN, WM, WN, MINW, VEC, KEDGE, FUSE>;
   static size_t attr_lds = 0;
   if (attr_lds < lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, W, bias, Hin, Hout, (int)out, (int)in, B,
-                     (int)act, nMt, nNt);
+                     (int)act, nMt, nNt, fa.Wlast, fa.out_last, fa.part);
 }
 
-template <int BM, int BN, int WM, int WN, int MINW>
+template <int BM, int BN, int WM, int WN, int MINW, bool FUSE = false>
 void launch_dense_cfg(hipStream_t st, const double* W, const double* bias, const double* Hin, double* Hout,
-                      int32_t out, int32_t in, int64_t B, int32_t act) {
+                      int32_t out, int32_t in, int64_t B, int32_t act, const FuseArgs& fa = FuseArgs()) {
   // 16-B staging accesses need even strides and 16-B aligned bases (W sits at an arbitrary offset of the flat
   // weight vector: layer 3 of cfg2 starts at an odd element); a ragged k edge (in % 16 != 0) needs zero-fill
   const bool vec = (out % 2 == 0) && (in % 2 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0) &&
-                   ((reinterpret_cast<uintptr_t>(Hin) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(Hout) & 15u) == 0) &&
-                   ((reinterpret_cast<uintptr_t>(bias) & 15u) == 0);
+                   ((reinterpret_cast<uintptr_t>(Hin) & 15u) == 0) &&
+                   (FUSE || (((reinterpret_cast<uintptr_t>(Hout) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(bias) & 15u) == 0)));
   const bool kedge = (in % 16) != 0;
   if (vec && !kedge)
-    launch_dense_inst<BM, BN, WM, WN, MINW, true, false>(st, W, bias, Hin, Hout, out, in, B, act);
+    launch_dense_inst<BM, BN, WM, WN, MINW, true, false, FUSE>(st, W, bias, Hin, Hout, out, in, B, act, fa);
   else if (vec)
-    launch_dense_inst<BM, BN, WM, WN, MINW, true, true>(st, W, bias, Hin, Hout, out, in, B, act);
+    launch_dense_inst<BM, BN, WM, WN, MINW, true, true, FUSE>(st, W, bias, Hin, Hout, out, in, B, act, fa);
   else if (!kedge)
-    launch_dense_inst<BM, BN, WM, WN, MINW, false, false>(st, W, bias, Hin, Hout, out, in, B, act);
+    launch_dense_inst<BM, BN, WM, WN, MINW, false, false, FUSE>(st, W, bias, Hin, Hout, out, in, B, act, fa);
   else
-    launch_dense_inst<BM, BN, WM, WN, MINW, false, true>(st, W, bias, Hin, Hout, out, in, B, act);
+    launch_dense_inst<BM, BN, WM, WN, MINW, false, true, FUSE>(st, W, bias, Hin, Hout, out, in, B, act, fa);
 }
 
 #ifndef SI_GEMM_NO_DISPATCH
@@ -379,20 +426,83 @@ void launch_dense_cfg(hipStream_t st, const double* W, const double* bias, const
 // (4 waves per SIMD) beat every 2-waves-per-SIMD shape -- 96x128: 68.2, 64x128: 67.2, 128x128: 65.1 TFLOP/s against
 // 56-60 for 4-wave 128x128 / 192x128 tiles -- because the prologue / epilogue of one workgroup hides under three other
 // waves' MFMAs.  The feature tile BM is the one that pads `out` least (960 = 10 x 96).
-void launch_dense_f64(hipStream_t st, const double* W, const double* bias, const double* Hin,
-                      double* Hout, int32_t out, int32_t in, int64_t B, int32_t act) {
-  if (out <= 32) {
-    launch_dense_cfg<32, 128, 1, 4, 2>(st, W, bias, Hin, Hout, out, in, B, act);
-    return;
-  }
+static int pick_bm(int32_t out) {
+  if (out <= 32) return 32;
   auto padded = [&](int bm) { return (out + bm - 1) / bm * bm; };
   const int p96 = padded(96), p128 = padded(128), p64 = padded(64);
-  if (p96 <= p128 && p96 <= p64)
-    launch_dense_cfg<96, 128, 2, 4, 4>(st, W, bias, Hin, Hout, out, in, B, act);
-  else if (p128 <= p64)
-    launch_dense_cfg<128, 128, 2, 4, 4>(st, W, bias, Hin, Hout, out, in, B, act);
-  else
-    launch_dense_cfg<64, 128, 2, 4, 4>(st, W, bias, Hin, Hout, out, in, B, act);
+  if (p96 <= p128 && p96 <= p64) return 96;
+  return p128 <= p64 ? 128 : 64;
+}
+
+void launch_dense_f64(hipStream_t st, const double* W, const double* bias, const double* Hin,
+                      double* Hout, int32_t out, int32_t in, int64_t B, int32_t act) {
+  switch (pick_bm(out)) {
+    case 32: launch_dense_cfg<32, 128, 1, 4, 2>(st, W, bias, Hin, Hout, out, in, B, act); break;
+    case 96: launch_dense_cfg<96, 128, 2, 4, 4>(st, W, bias, Hin, Hout, out, in, B, act); break;
+    case 128: launch_dense_cfg<128, 128, 2, 4, 4>(st, W, bias, Hin, Hout, out, in, B, act); break;
+    default: launch_dense_cfg<64, 128, 2, 4, 4>(st, W, bias, Hin, Hout, out, in, B, act); break;
+  }
+}
+
+// number of feature slots (partials per (o, b)) the fused kernel writes for a layer of width `out`
+int dense_fused_slots(int32_t out) {
+  const int bm = pick_bm(out);
+  const int wm = bm == 32 ? 1 : 2;
+  return (out + bm - 1) / bm * wm;
+}
+
+void launch_dense_f64_fused(hipStream_t st, const double* W, const double* bias, const double* Hin, int32_t out,
+                            int32_t in, int64_t B, int32_t act, const double* Wlast, int32_t out_last, double* part) {
+  FuseArgs fa;
+  fa.Wlast = Wlast;
+  fa.out_last = out_last;
+  fa.part = part;
+  switch (pick_bm(out)) {
+    case 32: launch_dense_cfg<32, 128, 1, 4, 2, true>(st, W, bias, Hin, nullptr, out, in, B, act, fa); break;
+    case 96: launch_dense_cfg<96, 128, 2, 4, 4, true>(st, W, bias, Hin, nullptr, out, in, B, act, fa); break;
+    case 128: launch_dense_cfg<128, 128, 2, 4, 4, true>(st, W, bias, Hin, nullptr, out, in, B, act, fa); break;
+    default: launch_dense_cfg<64, 128, 2, 4, 4, true>(st, W, bias, Hin, nullptr, out, in, B, act, fa); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tail of the fused path: yhat[o][b] = act_last(sum_slots part + b_last[o]);  block partials of (y - yhat)^2.
+// Fixed summation order => bit-reproducible.  Replaces the last Dense layer + the SSE pass of
+// reference src/space_inference.jl:94.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tail_sse_kernel(const double* __restrict__ part, int slots, int out_last,
+                                                       int64_t B, const double* __restrict__ bias_last, int act_last,
+                                                       const double* __restrict__ Y, double* __restrict__ yhat,
+                                                       double* __restrict__ blockpart) {
+  __shared__ double red[4];
+  double accv = 0.0;
+  const int64_t d = (int64_t)out_last * B;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < d; idx += stride) {
+    const int o = (int)(idx % out_last);
+    const int64_t b = idx / out_last;
+    double s = 0.0;
+    for (int sl = 0; sl < slots; ++sl) s += part[((int64_t)sl * out_last + o) * B + b];
+    double v = s + bias_last[o];
+    if (act_last == SI_ACT_RELU)
+      v = v > 0.0 ? v : 0.0;
+    else if (act_last != SI_ACT_IDENTITY)
+      v = apply_act(v, act_last);
+    if (yhat) yhat[idx] = v;
+    const double r = Y[idx] - v;
+    accv += r * r;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) accv += __shfl_down(accv, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = accv;
+  __syncthreads();
+  if (threadIdx.x == 0) blockpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+void launch_tail_sse(hipStream_t st, const double* part, int slots, int out_last, int64_t B, const double* bias_last,
+                     int act_last, const double* Y, double* yhat, double* blockpart, int nblocks) {
+  hipLaunchKernelGGL(tail_sse_kernel, dim3(nblocks), dim3(256), 0, st, part, slots, out_last, B, bias_last, act_last, Y,
+                     yhat, blockpart);
 }
 #endif
 

@@ -213,6 +213,10 @@ int sse_num_blocks(int64_t d, int num_cu) {
   return (int)b;
 }
 
+void launch_sse_final(hipStream_t st, const double* blockpart, int nblocks, double* sse_out) {
+  hipLaunchKernelGGL(sse_final_kernel, dim3(1), dim3(256), 0, st, blockpart, nblocks, sse_out);
+}
+
 void launch_sse(hipStream_t st, const double* yhat, const double* y, int64_t d, double* part,
                 int nblocks, double* sse_out) {
   hipLaunchKernelGGL(sse_partial_kernel, dim3(nblocks), dim3(256), 0, st, yhat, y, d, part);

@@ -70,6 +70,10 @@ struct Ctx {
   double* d_act[2] = {nullptr, nullptr};  // ping-pong activations, maxwidth x B
   int64_t act_elems = 0;
   double* d_ssepart = nullptr;  // per-block SSE partials
+  bool fuse_tail = false;       // last layer folded into the epilogue of the layer in front of it
+  int fuse_slots = 0;
+  double* d_part = nullptr;     // [slots][out_last][B] partial last-layer products
+  double* d_yhat = nullptr;     // out_dim x B, only filled on request (si_forward)
   int sse_blocks = 0;
   int main_layer = 0;
   // sampler state (device)
@@ -117,6 +121,16 @@ void launch_reconstruct(hipStream_t st, const double* swa, const double* P, int6
 // K5: Hout[i + out*b] = act(sum_k W[i + out*k] * Hin[k + in*b] + bias[i])
 void launch_dense_f64(hipStream_t st, const double* W, const double* bias, const double* Hin,
                       double* Hout, int32_t out, int32_t in, int64_t B, int32_t act);
+// K5 fused tail: the layer in front of a narrow (out_last <= SI_FUSE_MAX_OUT) last layer does not store its output;
+// it writes per-slot partial products with the last layer's weights, summed by launch_tail_sse (block partials of
+// (y - yhat)^2 to `blockpart`, to be finished by sse_final via launch_sse_final)
+constexpr int SI_FUSE_MAX_OUT = 4;
+int dense_fused_slots(int32_t out);
+void launch_dense_f64_fused(hipStream_t st, const double* W, const double* bias, const double* Hin, int32_t out,
+                            int32_t in, int64_t B, int32_t act, const double* Wlast, int32_t out_last, double* part);
+void launch_tail_sse(hipStream_t st, const double* part, int slots, int out_last, int64_t B, const double* bias_last,
+                     int act_last, const double* Y, double* yhat, double* blockpart, int nblocks);
+void launch_sse_final(hipStream_t st, const double* blockpart, int nblocks, double* sse_out);
 // K5: sse = sum (y - yhat)^2 over d elements; deterministic two-stage
 int sse_num_blocks(int64_t d, int num_cu);
 void launch_sse(hipStream_t st, const double* yhat, const double* y, int64_t d, double* part,

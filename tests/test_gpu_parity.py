@@ -150,6 +150,9 @@ def _random_problem(dims, acts, b, m, seed):
     ([7, 33, 1], [2, 0], 1, 2),                           # single observation, tanh
     ([5, 130, 65, 3], [3, 1, 0], 257, 4),                 # sigmoid, ragged tiles in every dimension
     ([128, 960, 960, 1], [1, 1, 0], 1000, 20),            # cfg2 model, reduced batch
+    ([6, 40, 8], [1, 0], 300, 3),                         # wide head (out > 4): unfused tail
+    ([10, 5], [2], 77, 2),                                # single Dense layer
+    ([3, 100, 97, 2], [1, 2, 3], 130, 4),                 # odd widths: scalar staging path, activated head
 ])
 def test_forward_and_logdensity(gpu_ctx, dims, acts, b, m):
     table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=sum(dims) + b)

@@ -38,26 +38,26 @@ int main(int argc, char** argv) {
   hipMemcpy(db, hb.data(), hb.size() * 8, hipMemcpyHostToDevice);
   hipMemcpy(dX, hX.data(), hX.size() * 8, hipMemcpyHostToDevice);
   std::vector<Variant> vs = {
-    {"128x128 2x2 w2 (baseline)", launch_dense_cfg<128, 128, 2, 2, 2>},
-    {"160x128 2x2 w2", launch_dense_cfg<160, 128, 2, 2, 2>},
-    {"192x128 2x2 w1", launch_dense_cfg<192, 128, 2, 2, 1>},
-    {"192x128 4x2 w2 (8 waves)", launch_dense_cfg<192, 128, 4, 2, 2>},
-    {"192x128 2x4 w2 (8 waves)", launch_dense_cfg<192, 128, 2, 4, 2>},
-    {"160x128 2x4 w4 (8 waves)", launch_dense_cfg<160, 128, 2, 4, 4>},
-    {"192x256 2x4 w2 (8 waves)", launch_dense_cfg<192, 256, 2, 4, 2>},
-    {"160x256 2x4 w2 (8 waves)", launch_dense_cfg<160, 256, 2, 4, 2>},
-    {"192x192 2x4 w2 (8 waves)", launch_dense_cfg<192, 192, 2, 4, 2>},
-    {"128x256 2x4 w2 (8 waves)", launch_dense_cfg<128, 256, 2, 4, 2>},
-    {"96x128 2x2 w2", launch_dense_cfg<96, 128, 2, 2, 2>},
-    {"64x128 2x2 w2", launch_dense_cfg<64, 128, 2, 2, 2>},
-    {"32x128 1x4 w2", launch_dense_cfg<32, 128, 1, 4, 2>},
-    {"96x128 2x4 w4 (8 waves)", launch_dense_cfg<96, 128, 2, 4, 4>},
-    {"128x128 2x4 w4 (8 waves)", launch_dense_cfg<128, 128, 2, 4, 4>},
-    {"128x128 4x2 w4 (8 waves)", launch_dense_cfg<128, 128, 4, 2, 4>},
-    {"64x128 2x4 w4 (8 waves)", launch_dense_cfg<64, 128, 2, 4, 4>},
-    {"96x256 2x4 w2 (8 waves)", launch_dense_cfg<96, 256, 2, 4, 2>},
-    {"192x128 4x2 w3 (8 waves)", launch_dense_cfg<192, 128, 4, 2, 3>},
-    {"64x64 2x2 w4", launch_dense_cfg<64, 64, 2, 2, 4>},
+    {"128x128 2x2 w2 (baseline)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<128, 128, 2, 2, 2>(st, W, b, X, Y, o, i, B, a); }},
+    {"160x128 2x2 w2", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<160, 128, 2, 2, 2>(st, W, b, X, Y, o, i, B, a); }},
+    {"192x128 2x2 w1", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<192, 128, 2, 2, 1>(st, W, b, X, Y, o, i, B, a); }},
+    {"192x128 4x2 w2 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<192, 128, 4, 2, 2>(st, W, b, X, Y, o, i, B, a); }},
+    {"192x128 2x4 w2 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<192, 128, 2, 4, 2>(st, W, b, X, Y, o, i, B, a); }},
+    {"160x128 2x4 w4 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<160, 128, 2, 4, 4>(st, W, b, X, Y, o, i, B, a); }},
+    {"192x256 2x4 w2 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<192, 256, 2, 4, 2>(st, W, b, X, Y, o, i, B, a); }},
+    {"160x256 2x4 w2 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<160, 256, 2, 4, 2>(st, W, b, X, Y, o, i, B, a); }},
+    {"192x192 2x4 w2 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<192, 192, 2, 4, 2>(st, W, b, X, Y, o, i, B, a); }},
+    {"128x256 2x4 w2 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<128, 256, 2, 4, 2>(st, W, b, X, Y, o, i, B, a); }},
+    {"96x128 2x2 w2", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<96, 128, 2, 2, 2>(st, W, b, X, Y, o, i, B, a); }},
+    {"64x128 2x2 w2", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<64, 128, 2, 2, 2>(st, W, b, X, Y, o, i, B, a); }},
+    {"32x128 1x4 w2", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<32, 128, 1, 4, 2>(st, W, b, X, Y, o, i, B, a); }},
+    {"96x128 2x4 w4 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<96, 128, 2, 4, 4>(st, W, b, X, Y, o, i, B, a); }},
+    {"128x128 2x4 w4 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<128, 128, 2, 4, 4>(st, W, b, X, Y, o, i, B, a); }},
+    {"128x128 4x2 w4 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<128, 128, 4, 2, 4>(st, W, b, X, Y, o, i, B, a); }},
+    {"64x128 2x4 w4 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<64, 128, 2, 4, 4>(st, W, b, X, Y, o, i, B, a); }},
+    {"96x256 2x4 w2 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<96, 256, 2, 4, 2>(st, W, b, X, Y, o, i, B, a); }},
+    {"192x128 4x2 w3 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<192, 128, 4, 2, 3>(st, W, b, X, Y, o, i, B, a); }},
+    {"64x64 2x2 w4", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<64, 64, 2, 2, 4>(st, W, b, X, Y, o, i, B, a); }},
   };
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   std::vector<double> ref((size_t)out * 4096), got((size_t)out * 4096);
