@@ -1,0 +1,112 @@
+"""world_size-2 `gloo` tests (CPU) of the multi-GPU host path: chain partitioning, the Gram all-reduce of the
+row-sharded construction and the final gathers.  The GPU context is replaced by a test double that computes the
+rank-local pieces with the ORACLE (tests may use it as the checker); the collective plumbing under test is the
+product's own (subspaceinference.jl_amd/dist.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeCtx:
+    """Rank-local stand-in for _capi.Context: same method names, NumPy arithmetic on this rank's row block."""
+
+    def __init__(self, a_local, w_local, eig):
+        self.a, self.w, self.eig, self.g = a_local, w_local, eig, None
+
+    def construct_gram(self):
+        self.g = self.a.T @ self.a
+
+    def construct_gram_get(self):
+        return self.g
+
+    def construct_gram_set(self, g):
+        self.g = np.array(g)
+
+    def construct_finish(self, m):
+        lam, v = self.eig(self.g)
+        v = v[:, ::-1][:, :m]
+        v = v * np.sign(v[np.argmax(np.abs(v), axis=0), np.arange(m)])[None, :]
+        return self.w, self.a @ v, np.sqrt(lam[::-1][:m]), self.a.shape[1]
+
+    def sample_rwmh(self, itr, sigma_z, seed, chain_id0=0, nchains=1):
+        from oracle import philox
+        z = np.stack([np.stack([sigma_z * philox.normals(seed, chain_id0 + c, t, 3) for t in range(itr)], axis=1)
+                      for c in range(nchains)], axis=2)
+        lp = -0.5 * (z ** 2).sum(axis=0)
+        return z, lp, np.full(nchains, 0.5)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import subspaceinference_jl_amd as si
+    from subspaceinference_jl_amd import dist as sd
+    from oracle import subspace_oracle as so
+    try:
+        r, w = sd.init(backend="gloo")
+        assert (r, w) == (rank, world)
+        n, k, m = 1000 + 37, 12, 3
+        rng = np.random.default_rng(0)  # same data on every rank
+        snaps = [rng.standard_normal(n).astype(np.float32) for _ in range(k)]
+        ns = [float(1 + i // 3) for i in range(k)]
+        w_swa, a = so.construct_stream(snaps, ns)
+        p_ref, s_ref = so.projection_from_A(a, m)
+        r0, r1 = sd.row_shard(n, rank, world)
+        ctx = FakeCtx(a[r0:r1], w_swa[r0:r1], si.host_sym_eig)
+        w_full, p_full, s, kk = sd.sharded_construct_finish(ctx, m, n_total=n, gather=True)
+        ok = kk == k and np.array_equal(w_full, w_swa) and np.allclose(s, s_ref[:m], rtol=1e-9)
+        sign = np.sign(np.sum(p_full * p_ref, axis=0))
+        ok = ok and np.allclose(p_full * sign, p_ref, rtol=1e-7, atol=1e-10)
+        # the all-reduced Gram is the full one on every rank
+        ok = ok and np.allclose(ctx.g, a.T @ a, rtol=1e-12)
+        # chains: 5 chains over 2 ranks, gathered == one rank running all five
+        z, lp, acc = sd.sample_chains(ctx, 5, 7, 0.3, seed=9)
+        zr, lpr, _ = FakeCtx(None, None, None).sample_rwmh(7, 0.3, 9, 0, 5)
+        ok = ok and z.shape == (3, 7, 5) and np.array_equal(z, zr) and np.array_equal(lp, lpr) and acc.shape == (5,)
+        q.put((rank, bool(ok), ""))
+    except Exception as e:  # surface the failure in the parent
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+    finally:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_partitions():
+    sys.path.insert(0, ROOT)
+    from subspaceinference_jl_amd import dist as sd
+    for n in (1, 31, 32, 33, 1047361, 51138049):
+        for ws in (1, 2, 3, 8):
+            blocks = [sd.row_shard(n, r, ws) for r in range(ws)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(ws - 1))
+            assert all(b[0] % 32 == 0 or b[0] == b[1] for b in blocks)  # non-empty shards start 256-B aligned
+    assert [sd.chain_ids(8, r, 8) for r in range(8)] == [[i] for i in range(8)]
+    assert sd.chain_ids(5, 0, 2) == [0, 1, 2] and sd.chain_ids(5, 1, 2) == [3, 4]
+    assert sd.chain_ids(1, 1, 2) == []
+    assert sd.world() == (0, 1)
+    assert np.array_equal(sd.allreduce_sum(np.eye(3)), np.eye(3))  # no process group: identity
+
+
+@pytest.mark.timeout(300)
+def test_gloo_world2_sharded_construct_and_chains():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, ok, tb in res:
+        assert ok, "rank %d failed\n%s" % (rank, tb)
