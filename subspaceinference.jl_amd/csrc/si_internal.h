@@ -10,9 +10,10 @@
 
 namespace si {
 
-// leading dimensions of device matrices are padded to a multiple of this many elements (256 B) so that
-// every column starts 256-B aligned and 16-B vector accesses are legal whatever N is (N is odd at cfg2).
-constexpr int64_t LD_ALIGN = 32;
+// leading dimensions of device matrices are padded to a multiple of this many elements (512 B) so that every
+// column starts 512-B aligned, 16-B vector accesses are legal whatever N is (N is odd at cfg2), and the 64-row slabs
+// of the Gram kernel never run past a column (the padding rows of A are kept at zero).
+constexpr int64_t LD_ALIGN = 64;
 inline int64_t pad_ld(int64_t n) { return (n + LD_ALIGN - 1) / LD_ALIGN * LD_ALIGN; }
 
 struct EventPair {

@@ -1,0 +1,46 @@
+// Development harness for K2 (Gram) and K3 (projection) at construct shapes.  Not shipped.
+#include "../subspaceinference.jl_amd/csrc/kernels_gram.hip"
+#include <cstdio>
+#include <vector>
+namespace si {
+int32_t fail(Ctx*, int32_t c, const std::string&) { return c; }
+ProfScope::ProfScope(Ctx*, int, double, double) {}
+ProfScope::~ProfScope() {}
+}
+using namespace si;
+__global__ void fill(double* a, size_t n, unsigned long long seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long s = (i + 1) * 6364136223846793005ull + seed; s ^= s >> 29; s *= 0xBF58476D1CE4E5B9ull; s ^= s >> 32;
+    a[i] = (double)(s >> 11) / 9007199254740992.0 - 0.5;
+  }
+}
+int main(int argc, char** argv) {
+  const int64_t N = argc > 1 ? atoll(argv[1]) : 1047361;
+  const int K = argc > 2 ? atoi(argv[2]) : 100, M = argc > 3 ? atoi(argv[3]) : 20;
+  const int64_t ldA = pad_ld(N);
+  double *A, *G, *Gp, *V, *P;
+  hipMalloc(&A, (size_t)ldA * K * 8); hipMemset(A, 0, (size_t)ldA * K * 8);
+  for (int k = 0; k < K; ++k) hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, A + (size_t)k * ldA, (size_t)N, 1000ull + k);
+  hipMalloc(&G, (size_t)K * K * 8);
+  const size_t need = launch_gram(0, A, ldA, N, K, nullptr, nullptr, 256, nullptr);
+  hipMalloc(&Gp, need);
+  const int Mpad = project_mpad(M);
+  hipMalloc(&V, (size_t)K * Mpad * 8); hipLaunchKernelGGL(fill, dim3(64), dim3(256), 0, 0, V, (size_t)K * Mpad, 7ull);
+  hipMalloc(&P, (size_t)ldA * M * 8);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 4; ++rep) {
+    hipEventRecord(e0, 0);
+    launch_gram(0, A, ldA, N, K, Gp, G, 256, nullptr);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    hipEventRecord(e0, 0);
+    launch_project(0, A, ldA, N, K, V, M, Mpad, P, ldA, 256);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms2; hipEventElapsedTime(&ms2, e0, e1);
+    printf("N=%lld K=%d M=%d: gram+reduce %.3f ms (%.2f TFLOP/s useful, %.2f TB/s of A), project %.3f ms (%.2f TB/s)\n", (long long)N, K, M, ms,
+           (double)N * K * (K + 1) / (ms * 1e-3) / 1e12, (double)N * K * 8 / (ms * 1e-3) / 1e12, ms2, (double)N * (K + M) * 8 / (ms2 * 1e-3) / 1e12);
+  }
+  std::vector<double> g((size_t)K * K); hipMemcpy(g.data(), G, g.size() * 8, hipMemcpyDeviceToHost);
+  printf("G[0,0]=%.6f G[1,0]=%.6f G[K-1,K-1]=%.6f (expect ~N/12=%.1f on the diagonal)\n", g[0], g[1], g[(size_t)K * K - 1], N / 12.0);
+  return 0;
+}
