@@ -176,7 +176,7 @@ def main():
             "construct_device_ms": {k: round(cst[k]["ms"], 4) for k in ("push", "gram", "gram_reduce", "project")},
             "sample_device_ms_per_step": {k: round(st[k]["ms"] / args.steps, 4) for k in ("reconstruct", "dense", "sse", "rwmh")},
             "accept_rate": float(acc[0]), "lp_last": float(lp[-1, 0]),
-            "roofline": {"kernel": "dense_f64_kernel<128,128> layer 960x960 (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+            "roofline": {"kernel": "dense_f64_kernel<96,128> layer 960x960 + fused 960->1 tail (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F64_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "flops_per_launch": fl, "launches": dm["launches"]},
