@@ -86,6 +86,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # Only the JSON line may reach stdout: RCCL prints a version banner to fd 1 when the communicator is created.
+    # Keep the real stdout aside and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -96,9 +102,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SI_BENCH_FORCE_DIST") == "1":  # the env knob rehearses the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import subspaceinference_jl_amd as si
@@ -190,7 +199,7 @@ def main():
             out["parity_lp_rel_err_vs_oracle"] = abs(lp_cpu - float(lp[0, 0])) / abs(lp_cpu)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ctx.close()
     if dist is not None:
         dist.barrier()
