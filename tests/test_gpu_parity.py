@@ -242,3 +242,76 @@ def test_api_end_to_end_toy(si, gpu_ctx):
     chn2, lp2 = si.inference(m, data, w2, p2, itr=5, M=3, alg=":mh", ctx=gpu_ctx, seed=3, σ_z=0.5)
     z0 = np.linalg.lstsq(p2, chn2[0] - w2, rcond=None)[0]
     assert np.isclose(lp2[0], so.logdensity(TOY_TABLE, w2, p2, x, y, 1.0, z0), rtol=1e-9)
+
+
+# ----------------------------------------------------------------------------------------------- full BASELINE sizes
+def _device_snapshots(n, k, seed):
+    import torch
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    w0 = torch.randn(n, generator=gen, device="cuda", dtype=torch.float64)
+    out = torch.empty((k, n), device="cuda", dtype=torch.float32)
+    cur = w0
+    for i in range(k):  # random-walk stream, built row by row to bound memory
+        cur = cur + 0.01 * torch.randn(n, generator=gen, device="cuda", dtype=torch.float64)
+        out[i] = cur.to(torch.float32)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("n,k,m", [(1047361, 100, 20),      # cfg2
+                                   (5200266, 200, 20),      # cfg4: flattened conv-net weight vector, K > 128 path
+                                   (51138049, 16, 8)])      # cfg5 length (reduced K: bounded test time)
+def test_construct_full_size_properties(gpu_ctx, n, k, m):
+    """At BASELINE.json's sizes the oracle's dense SVD is too slow / too large for a test, so the construction is
+    checked through size-independent properties plus spot checks against fp64 host arithmetic on a few columns."""
+    import torch
+    snaps = _device_snapshots(n, k, seed=n % 1000 + k)
+    gpu_ctx.construct_begin(n, k)
+    for i in range(k):
+        gpu_ctx.construct_push_dev(snaps[i].data_ptr(), 0, float(1 + i // 2))
+    gpu_ctx.construct_gram()
+    g = gpu_ctx.construct_gram_get()
+    assert np.array_equal(g, g.T)
+    # spot check: three deviation columns pulled back, their Gram entries recomputed on the host in fp64
+    cols = [0, k // 2, k - 1]
+    a_cols = [gpu_ctx.construct_get_A(c, 1)[:, 0] for c in cols]
+    for i, ci in enumerate(cols):
+        for j, cj in enumerate(cols):
+            ref = float(np.dot(a_cols[i], a_cols[j]))
+            assert abs(g[ci, cj] - ref) <= 1e-10 * np.sqrt(g[ci, ci] * g[cj, cj])
+    # K1 at full size: the last column equals w_k - W_swa recomputed on the host from the same snapshots
+    w_swa, p, s, kk = gpu_ctx.construct_finish(m)
+    assert kk == k and np.array_equal(a_cols[2], snaps[k - 1].cpu().numpy().astype(np.float64) - w_swa)
+    # P'P = diag(s^2), s descending, energy bounded by trace(G)
+    ptp = p.T @ p
+    assert np.allclose(ptp, np.diag(s ** 2), atol=1e-8 * s[0] ** 2)
+    assert np.all(np.diff(s) <= 0) and (s ** 2).sum() <= np.trace(g) * (1 + 1e-12)
+    # eigen-relation G v = s^2 v for v = A' p / s^2 (uses only device outputs + the pulled columns' rows of G)
+    lam = np.linalg.eigvalsh(g)[::-1][:m]
+    assert np.allclose(s ** 2, lam, rtol=1e-9)
+    del snaps
+    torch.cuda.empty_cache()
+
+
+def test_density_full_size_cfg2(gpu_ctx):
+    """cfg2 at full size (N = 1,047,361, B = 100,000): one oracle evaluation plus exact invariances."""
+    dims, acts, b, m = [128, 960, 960, 1], [1, 1, 0], 100000, 20
+    table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=11)
+    w_swa *= 0.1
+    gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=1.0)
+    z = np.asfortranarray(0.1 * np.random.default_rng(2).standard_normal((m, 2)))
+    lp = gpu_ctx.logdensity(z)
+    assert np.isclose(lp[0], so.logdensity(table, w_swa, p, x, y, 1.0, z[:, 0]), rtol=1e-11)
+    # same inputs, same bits (fixed-order reductions everywhere)
+    assert np.array_equal(lp, gpu_ctx.logdensity(z))
+    # reconstruct is affine in z: W(z1 + z2) - W(z1) - W(z2) + W(0) = 0
+    zz = np.asfortranarray(np.stack([z[:, 0], z[:, 1], z[:, 0] + z[:, 1], np.zeros(m)], axis=1))
+    w = gpu_ctx.reconstruct(zz)
+    assert np.abs(w[:, 2] - w[:, 0] - w[:, 1] + w[:, 3]).max() <= 1e-13 * np.abs(w).max()
+    assert np.array_equal(w[:, 3], w_swa)
+    # permuting the observations permutes yhat and leaves the SSE unchanged up to summation order
+    perm = np.random.default_rng(3).permutation(b)
+    yh = gpu_ctx.forward(z[:, 0])
+    gpu_ctx.infer_setup(table, n, m, w_swa, p, np.asfortranarray(x[:, perm]), np.asfortranarray(y[:, perm]), 1.0)
+    assert np.allclose(gpu_ctx.forward(z[:, 0]), yh[:, perm], rtol=1e-12, atol=1e-13)
+    assert np.isclose(gpu_ctx.logdensity(z[:, :1])[0], lp[0], rtol=1e-12)
