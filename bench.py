@@ -121,7 +121,9 @@ def main():
     w0 = torch.from_numpy(glorot_flat(1).astype(np.float64)).cuda()
     gen = torch.Generator(device="cuda").manual_seed(2)
     steps = torch.randn(K_SNAP, n_par, generator=gen, device="cuda", dtype=torch.float64) * 0.01
-    snaps = (w0[None, :] + torch.cumsum(steps, dim=0)).to(torch.float32).contiguous()  # K x N fp32, random walk
+    ldw = n_par + (n_par & 1)  # rows padded to an even length: 8-B aligned fp32 pairs for the batched push
+    snaps = torch.zeros(K_SNAP, ldw, device="cuda", dtype=torch.float32)
+    snaps[:, :n_par] = (w0[None, :] + torch.cumsum(steps, dim=0)).to(torch.float32)  # K x N fp32, random walk
     del steps
     torch.cuda.synchronize()
 
@@ -137,8 +139,9 @@ def main():
     # ---- subspace construction (K pushes + Gram + eig + project), results stay on the device
     def construct():
         ctx.construct_begin(n_par, K_SNAP)
-        for k in range(K_SNAP):
-            ctx.construct_push_dev(snaps[k].data_ptr(), 0, float(k + 1))  # T=100 epochs, full batch, c=1: n = i
+        # T=100 epochs, full batch, c=1: n = i.  The snapshots are device-resident, so they are pushed in one pass
+        # (bit-identical to K_SNAP single pushes, tests/test_gpu_parity.py::test_push_batch_equals_sequential)
+        ctx.construct_push_batch_dev(snaps.data_ptr(), 0, ldw, np.arange(1, K_SNAP + 1, dtype=np.float64))
         return ctx.construct_finish(M, want_swa=False, want_p=False)
     construct()  # warm-up (allocations, code-object load)
     barrier()
@@ -183,6 +186,7 @@ def main():
                        "chains_per_gpu": 1, "parallelism": "independent chains x%d (one per GPU), no data-path collective" % world},
             "construct_wall_ms": construct_ms,
             "construct_device_ms": {k: round(cst[k]["ms"], 4) for k in ("push", "gram", "gram_reduce", "project")},
+            "construct_host_eig_ms": round(cst["eig_host"]["ms"], 4),
             "sample_device_ms_per_step": {k: round(st[k]["ms"] / args.steps, 4) for k in ("reconstruct", "dense", "sse", "rwmh")},
             "accept_rate": float(acc[0]), "lp_last": float(lp[-1, 0]),
             "roofline": {"kernel": "dense_f64_kernel<96,128> layer 960x960 + fused 960->1 tail (v_mfma_f64_16x16x4_f64)", "bound": "mfma",

@@ -67,7 +67,8 @@ enum {
   SI_K_SSE = 6,      /* K5 sum of squared errors              */
   SI_K_RWMH = 7,     /* K6 propose / accept kernels           */
   SI_K_DENSE_MAIN = 8, /* K5 the largest layer only (dominant kernel) */
-  SI_K_COUNT = 9
+  SI_K_EIG_HOST = 9,   /* H1 K x K symmetric eigensolve: HOST wall time, not a device kernel */
+  SI_K_COUNT = 10
 };
 
 typedef struct {
@@ -101,6 +102,11 @@ int32_t si_construct_begin(si_ctx* ctx, int64_t N, int64_t K_capacity, int32_t m
  * batch of the epoch).  w has N elements of w_dtype.                                                */
 int32_t si_construct_push(si_ctx* ctx, const void* w_host, int32_t w_dtype, double n);
 int32_t si_construct_push_dev(si_ctx* ctx, const void* w_dev, int32_t w_dtype, double n);
+/* `count` pushes in one pass over snapshots already on the device: snapshot j starts at w_dev + j*ld elements and is
+ * pushed with n_host[j].  Bit-identical to `count` calls of si_construct_push_dev, with W_swa held in registers
+ * (count*(s_w+8)+16 bytes per element instead of count*(s_w+24)) and one launch instead of `count`.               */
+int32_t si_construct_push_batch_dev(si_ctx* ctx, const void* w_dev, int32_t w_dtype, int64_t ld, int32_t count,
+                                    const double* n_host);
 /* Gram matrix G = A'A (K x K, fp64) of the columns pushed so far, computed on the device.
  * get/set exist so that a row-sharded construction (each rank holds a row block of w, W_swa, A, P) can
  * all-reduce G across ranks (RCCL via the host wrapper) before si_construct_finish.                  */

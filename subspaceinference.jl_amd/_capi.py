@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "libsubspace_hip.so")
 SI_OK, SI_ERR_INVALID, SI_ERR_STATE, SI_ERR_HIP, SI_ERR_NOMEM, SI_ERR_BOUNDS, SI_ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 SI_F32, SI_F64 = 0, 1
 ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
-K_NAMES = ["push", "gram", "gram_reduce", "project", "reconstruct", "dense", "sse", "rwmh", "dense_main"]
+K_NAMES = ["push", "gram", "gram_reduce", "project", "reconstruct", "dense", "sse", "rwmh", "dense_main", "eig_host"]
 K_COUNT = len(K_NAMES)
 
 
@@ -58,6 +58,7 @@ SIGNATURES = {
     "si_construct_begin": (c_int32, [c_void_p, c_int64, c_int64, c_int32]),
     "si_construct_push": (c_int32, [c_void_p, c_void_p, c_int32, c_double]),
     "si_construct_push_dev": (c_int32, [c_void_p, c_void_p, c_int32, c_double]),
+    "si_construct_push_batch_dev": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
     "si_construct_gram": (c_int32, [c_void_p]),
     "si_construct_gram_get": (c_int32, [c_void_p, c_void_p, POINTER(c_int64)]),
     "si_construct_gram_set": (c_int32, [c_void_p, c_void_p]),
@@ -190,6 +191,11 @@ class Context:
 
     def construct_push_dev(self, dev_ptr, dtype, n):
         self._check(self.lib.si_construct_push_dev(self.h, c_void_p(int(dev_ptr)), int(dtype), float(n)))
+
+    def construct_push_batch_dev(self, dev_ptr, dtype, ld, ns):
+        ns = np.ascontiguousarray(ns, dtype=np.float64)
+        self._check(self.lib.si_construct_push_batch_dev(self.h, c_void_p(int(dev_ptr)), int(dtype), int(ld), ns.size,
+                                                         _ptr(ns)))
 
     def construct_gram(self):
         self._check(self.lib.si_construct_gram(self.h))

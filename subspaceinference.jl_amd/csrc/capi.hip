@@ -4,6 +4,7 @@
 // There is no CPU fallback anywhere in this file.
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <new>
 
@@ -80,12 +81,15 @@ static void free_construct(Ctx* c) {
   dev_free(c->d_swa);
   dev_free(c->d_A);
   dev_free(c->d_G);
+  c->g_cap = 0;
+  c->v_cap = 0;
   dev_free(c->d_Gpart);
   dev_free(c->d_V);
   dev_free(c->d_P);
   c->gpart_bytes = 0;
   c->c_active = c->c_finished = c->gram_valid = false;
   c->K = c->Kcap = c->N = c->ldA = 0;
+  c->a_cols_alloc = 0;
   c->npush = 0;
   c->M_built = 0;
 }
@@ -171,6 +175,7 @@ int32_t si_destroy(si_ctx* ctx) {
   free_construct(ctx);
   free_infer(ctx);
   dev_free(ctx->d_wstage);
+  dev_free(ctx->d_nvals);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return SI_OK;
@@ -233,19 +238,30 @@ int32_t si_construct_begin(si_ctx* ctx, int64_t N, int64_t K_capacity, int32_t m
     return fail(ctx, SI_ERR_INVALID, "si_construct_begin: N and K_capacity must be positive, max_cols >= 0");
   BIND(ctx);
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  free_construct(ctx);
-  ctx->N = N;
-  ctx->ldA = pad_ld(N);
-  ctx->max_cols = max_cols;
-  ctx->Kcap = max_cols > 0 ? std::min<int64_t>(max_cols, K_capacity) : K_capacity;
-  if (dev_alloc(&ctx->d_swa, (size_t)ctx->ldA) != hipSuccess ||
-      dev_alloc(&ctx->d_A, (size_t)ctx->ldA * (size_t)ctx->Kcap) != hipSuccess) {
+  const int64_t kcap = max_cols > 0 ? std::min<int64_t>(max_cols, K_capacity) : K_capacity;
+  if (ctx->d_A != nullptr && ctx->N == N && ctx->a_cols_alloc >= kcap) {
+    // same problem size as the previous construction: keep the buffers (the padding rows of A are still zero --
+    // pushes only ever write rows < N -- and stale columns beyond K are never read)
+    if (ctx->i_ready && ctx->i_swa == ctx->d_swa) free_infer(ctx);  // an inference bound to the old W_swa / P
+    ctx->c_finished = ctx->gram_valid = false;
+    ctx->K = 0;
+    ctx->npush = 0;
+  } else {
     free_construct(ctx);
-    return fail(ctx, SI_ERR_NOMEM, "si_construct_begin: device allocation of W_swa / A failed");
+    ctx->N = N;
+    ctx->ldA = pad_ld(N);
+    if (dev_alloc(&ctx->d_swa, (size_t)ctx->ldA) != hipSuccess ||
+        dev_alloc(&ctx->d_A, (size_t)ctx->ldA * (size_t)kcap) != hipSuccess) {
+      free_construct(ctx);
+      return fail(ctx, SI_ERR_NOMEM, "si_construct_begin: device allocation of W_swa / A failed");
+    }
+    ctx->a_cols_alloc = kcap;
+    SI_HIP(ctx, hipMemsetAsync(ctx->d_A, 0, (size_t)ctx->ldA * (size_t)kcap * sizeof(double), ctx->stream));
   }
+  ctx->max_cols = max_cols;
+  ctx->Kcap = kcap;
   // W_swa = zeros(N)  (reference :31, quirk Q1: NOT the pretrained weights)
   SI_HIP(ctx, hipMemsetAsync(ctx->d_swa, 0, (size_t)ctx->ldA * sizeof(double), ctx->stream));
-  SI_HIP(ctx, hipMemsetAsync(ctx->d_A, 0, (size_t)ctx->ldA * (size_t)ctx->Kcap * sizeof(double), ctx->stream));
   ctx->c_active = true;
   return SI_OK;
 }
@@ -281,6 +297,40 @@ int32_t si_construct_push_dev(si_ctx* ctx, const void* w_dev, int32_t w_dtype, d
     return fail(ctx, SI_ERR_INVALID, "si_construct_push_dev: bad pointer or dtype");
   BIND(ctx);
   return push_common(ctx, w_dev, w_dtype, n);
+}
+
+int32_t si_construct_push_batch_dev(si_ctx* ctx, const void* w_dev, int32_t w_dtype, int64_t ld, int32_t count,
+                                    const double* n_host) {
+  CHECK_CTX(ctx);
+  if (!ctx->c_active) return fail(ctx, SI_ERR_STATE, "si_construct_push_batch_dev: call si_construct_begin first");
+  if (!w_dev || !n_host || count <= 0 || ld < ctx->N || (w_dtype != SI_F32 && w_dtype != SI_F64))
+    return fail(ctx, SI_ERR_INVALID, "si_construct_push_batch_dev: bad pointer, count, ld or dtype");
+  if (ctx->max_cols == 0 && ctx->K + count > ctx->Kcap)
+    return fail(ctx, SI_ERR_STATE, "si_construct_push: more pushes than K_capacity");
+  BIND(ctx);
+  if (ctx->nvals_cap < count) {
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_nvals);
+    if (dev_alloc(&ctx->d_nvals, (size_t)count) != hipSuccess) {
+      ctx->nvals_cap = 0;
+      return fail(ctx, SI_ERR_NOMEM, "si_construct_push_batch_dev: allocation failed");
+    }
+    ctx->nvals_cap = count;
+  }
+  SI_HIP(ctx, hipMemcpyAsync(ctx->d_nvals, n_host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));  // n_host is caller-owned and only valid during the call
+  const size_t wsz = w_dtype == SI_F32 ? 4 : 8;
+  {
+    ProfScope ps(ctx, SI_K_PUSH, 4.0 * (double)ctx->N * count, (double)ctx->N * ((double)count * (wsz + 8) + 16.0));
+    launch_swa_dev_push_batch(ctx->stream, w_dev, w_dtype, ld, ctx->d_swa, ctx->d_A, ctx->ldA, ctx->N, count,
+                              ctx->d_nvals, ctx->max_cols > 0 ? ctx->npush % ctx->Kcap : ctx->K, ctx->Kcap, ctx->num_cu);
+  }
+  SI_HIP(ctx, hipGetLastError());
+  ctx->npush += count;
+  ctx->K = std::min(ctx->npush, ctx->Kcap);
+  ctx->gram_valid = false;
+  ctx->c_finished = false;
+  return SI_OK;
 }
 
 int32_t si_construct_push(si_ctx* ctx, const void* w_host, int32_t w_dtype, double n) {
@@ -320,10 +370,14 @@ int32_t si_construct_gram(si_ctx* ctx) {
     }
     ctx->gpart_bytes = need;
   }
-  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  dev_free(ctx->d_G);
-  if (dev_alloc(&ctx->d_G, (size_t)K * K) != hipSuccess)
-    return fail(ctx, SI_ERR_NOMEM, "si_construct_gram: G allocation failed");
+  if (ctx->g_cap < K * K) {
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_G);
+    ctx->g_cap = 0;
+    if (dev_alloc(&ctx->d_G, (size_t)K * K) != hipSuccess)
+      return fail(ctx, SI_ERR_NOMEM, "si_construct_gram: G allocation failed");
+    ctx->g_cap = K * K;
+  }
   launch_gram(ctx->stream, ctx->d_A, ctx->ldA, ctx->N, K, ctx->d_Gpart, ctx->d_G, ctx->num_cu, ctx);
   SI_HIP(ctx, hipGetLastError());
   ctx->gram_valid = true;
@@ -372,8 +426,13 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
   std::vector<double> G((size_t)K * K), lam((size_t)K);
   SI_HIP(ctx, hipMemcpyAsync(G.data(), ctx->d_G, G.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (sym_eig((int)K, G.data(), lam.data()) != 0)
-    return fail(ctx, SI_ERR_INVALID, "si_construct_finish: eigensolver did not converge");
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int erc = sym_eig((int)K, G.data(), lam.data());
+    ctx->stats.ms[SI_K_EIG_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ctx->stats.launches[SI_K_EIG_HOST] += 1;
+    if (erc != 0) return fail(ctx, SI_ERR_INVALID, "si_construct_finish: eigensolver did not converge");
+  }
   // descending singular values; V_M with a deterministic sign (largest-magnitude entry positive)
   const int Mpad = project_mpad(M);
   std::vector<double> V((size_t)K * Mpad, 0.0);
@@ -397,9 +456,8 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
     return fail(ctx, SI_ERR_BOUNDS,
                 "BoundsError: M exceeds the numerical rank of the deviation matrix (s_M < ~1e-6 s_1 is below what the "
                 "Gram-matrix route resolves)");
-  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  dev_free(ctx->d_V);
   if (ctx->d_P == nullptr || ctx->M_built != M) {
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // P is re-allocated: an inference bound to the old P of this construction must not outlive it
     if (ctx->i_ready && ctx->i_P == ctx->d_P && ctx->d_P != nullptr) free_infer(ctx);
     dev_free(ctx->d_P);
@@ -407,8 +465,14 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
     if (dev_alloc(&ctx->d_P, (size_t)ctx->ldA * M) != hipSuccess)
       return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: allocation of P failed");
   }
-  if (dev_alloc(&ctx->d_V, V.size()) != hipSuccess)
-    return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: allocation of V failed");
+  if (ctx->v_cap < (int64_t)V.size()) {
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_V);
+    ctx->v_cap = 0;
+    if (dev_alloc(&ctx->d_V, V.size()) != hipSuccess)
+      return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: allocation of V failed");
+    ctx->v_cap = (int64_t)V.size();
+  }
   SI_HIP(ctx, hipMemcpyAsync(ctx->d_V, V.data(), V.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   SI_HIP(ctx, hipMemsetAsync(ctx->d_P, 0, (size_t)ctx->ldA * M * sizeof(double), ctx->stream));
   {

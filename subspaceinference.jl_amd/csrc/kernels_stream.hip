@@ -73,6 +73,56 @@ __global__ __launch_bounds__(256) void swa_dev_push_kernel(const WT* __restrict_
   }
 }
 
+// K1, batched: `count` snapshots that are already device-resident (w_j = w + j*ld) are pushed in ONE pass.  W_swa
+// stays in registers across the pushes, so the traffic per element drops from count*(s_w+24) to count*(s_w+8)+16 bytes
+// and `count` launches become one.  Same three rounded operations per push, in the same order: bit-identical to
+// `count` calls of swa_dev_push_kernel.  slot_j = (slot0 + j) mod kcap (ring only when max_cols is used).
+template <typename WT, bool VEC>
+__global__ __launch_bounds__(256) void swa_dev_push_batch_kernel(const WT* __restrict__ w, int64_t ld,
+                                                                 double* __restrict__ s, double* __restrict__ A,
+                                                                 int64_t ldA, int64_t N, int count,
+                                                                 const double* __restrict__ nvals, int64_t slot0,
+                                                                 int64_t kcap) {
+#pragma clang fp contract(off)
+  const int64_t npair = (N + 1) >> 1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npair; p += stride) {
+    const int64_t i = p << 1;
+    const bool two = i + 1 < N;
+    double2 sv = *reinterpret_cast<const double2*>(s + i);  // s is padded: reading s[N] is legal
+    for (int j = 0; j < count; ++j) {
+      const WT* wj = w + (int64_t)j * ld + i;
+      double w0, w1;
+      if constexpr (VEC) {
+        if constexpr (sizeof(WT) == 4) {
+          const float2 f = *reinterpret_cast<const float2*>(wj);
+          w0 = (double)f.x; w1 = (double)f.y;
+        } else {
+          const double2 f = *reinterpret_cast<const double2*>(wj);
+          w0 = f.x; w1 = f.y;
+        }
+      } else {
+        w0 = (double)wj[0];
+        w1 = two ? (double)wj[1] : 0.0;
+      }
+      const double n = nvals[j], np1 = n + 1.0;
+      const double t0 = n * sv.x, t1 = n * sv.y;
+      const double u0 = t0 + w0, u1 = t1 + w1;
+      sv.x = u0 / np1;
+      sv.y = u1 / np1;
+      double* col = A + ((slot0 + j) % kcap) * ldA + i;
+      if (two)
+        *reinterpret_cast<double2*>(col) = make_double2(w0 - sv.x, w1 - sv.y);
+      else
+        col[0] = w0 - sv.x;
+    }
+    if (two)
+      *reinterpret_cast<double2*>(s + i) = sv;
+    else
+      s[i] = sv.x;
+  }
+}
+
 static int stream_grid(int64_t work_items, int num_cu) {
   int64_t blocks = (work_items + 255) / 256;
   const int64_t cap = (int64_t)num_cu * 8;  // ~2048 blocks, grid-stride beyond (guide: Guideline 11)
@@ -98,6 +148,28 @@ void launch_swa_dev_push(hipStream_t st, const void* w, int32_t w_dtype, double*
       hipLaunchKernelGGL((swa_dev_push_kernel<double, true>), dim3(grid), dim3(256), 0, st, wd, s, acol, N, n, np1);
     else
       hipLaunchKernelGGL((swa_dev_push_kernel<double, false>), dim3(grid), dim3(256), 0, st, wd, s, acol, N, n, np1);
+  }
+}
+
+void launch_swa_dev_push_batch(hipStream_t st, const void* w, int32_t w_dtype, int64_t ld, double* s, double* A,
+                               int64_t ldA, int64_t N, int count, const double* nvals_dev, int64_t slot0, int64_t kcap,
+                               int num_cu) {
+  const int grid = stream_grid((N + 1) >> 1, num_cu);
+  const size_t esz = w_dtype == SI_F32 ? 4 : 8;
+  // vector loads need every snapshot row 2-element aligned and the last pair of an odd N inside the padded row
+  const bool vec = (ld % 2 == 0) && (ld >= N + (N & 1)) && ((reinterpret_cast<uintptr_t>(w) & (2 * esz - 1)) == 0);
+  if (w_dtype == SI_F32) {
+    const float* wf = static_cast<const float*>(w);
+    if (vec)
+      hipLaunchKernelGGL((swa_dev_push_batch_kernel<float, true>), dim3(grid), dim3(256), 0, st, wf, ld, s, A, ldA, N, count, nvals_dev, slot0, kcap);
+    else
+      hipLaunchKernelGGL((swa_dev_push_batch_kernel<float, false>), dim3(grid), dim3(256), 0, st, wf, ld, s, A, ldA, N, count, nvals_dev, slot0, kcap);
+  } else {
+    const double* wd = static_cast<const double*>(w);
+    if (vec)
+      hipLaunchKernelGGL((swa_dev_push_batch_kernel<double, true>), dim3(grid), dim3(256), 0, st, wd, ld, s, A, ldA, N, count, nvals_dev, slot0, kcap);
+    else
+      hipLaunchKernelGGL((swa_dev_push_batch_kernel<double, false>), dim3(grid), dim3(256), 0, st, wd, ld, s, A, ldA, N, count, nvals_dev, slot0, kcap);
   }
 }
 

@@ -43,8 +43,11 @@ struct Ctx {
   double* d_swa = nullptr;    // N (padded) fp64
   double* d_A = nullptr;      // ldA x Kcap fp64, column-major; with max_cols>0 a ring of max_cols columns
   void* d_wstage = nullptr;   // staging for host snapshots
+  double* d_nvals = nullptr;  // per-push n values of a batched push
+  int64_t nvals_cap = 0;
   size_t wstage_bytes = 0;
   double* d_G = nullptr;      // K x K
+  int64_t g_cap = 0, v_cap = 0, a_cols_alloc = 0;
   double* d_Gpart = nullptr;  // partial slabs
   size_t gpart_bytes = 0;
   double* d_V = nullptr;      // K x Mpad (row k contiguous)
@@ -108,6 +111,9 @@ struct ProfScope {
 // K1: s <- (n*s + w)/(n+1); acol <- w - s   (three rounded ops, no FMA; reference :46-47,51)
 void launch_swa_dev_push(hipStream_t st, const void* w, int32_t w_dtype, double* s, double* acol,
                          int64_t N, double n, int num_cu);
+void launch_swa_dev_push_batch(hipStream_t st, const void* w, int32_t w_dtype, int64_t ld, double* s, double* A,
+                               int64_t ldA, int64_t N, int count, const double* nvals_dev, int64_t slot0, int64_t kcap,
+                               int num_cu);
 // K2: G = A'A over columns [0,K) of A (ldA), rows [0,N); result K x K col-major symmetric in G
 // returns bytes of partial workspace required (if Gpart == nullptr nothing is launched)
 size_t launch_gram(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, double* Gpart,

@@ -43,6 +43,33 @@ def test_swa_dev_push_bit_exact(gpu_ctx, n, dtype):
         assert kk == k and np.array_equal(w_swa, w_ref)
 
 
+@pytest.mark.parametrize("n,ld,dtype,max_cols", [(682, 682, np.float32, 0), (1001, 1002, np.float32, 0),
+                                                  (4099, 4100, np.float64, 0), (5000, 5000, np.float32, 3)])
+def test_push_batch_equals_sequential(gpu_ctx, n, ld, dtype, max_cols):
+    import torch
+    k = 7
+    snaps = _snap_stream(n, k, seed=n + 1, dtype=dtype)
+    ns = np.array([1.0, 1.0, 2.0, 2.0, 3.0, 3.0, 4.0])
+    gpu_ctx.construct_begin(n, k, max_cols)
+    for w, nn in zip(snaps, ns):
+        gpu_ctx.construct_push(w, nn)
+    kk = min(k, max_cols) if max_cols else k
+    a_seq = gpu_ctx.construct_get_A(0, kk)
+    w_seq = gpu_ctx.construct_finish(1, want_p=False)[0]
+    buf = np.zeros((k, ld), dtype=dtype)
+    buf[:, :n] = np.stack(snaps)
+    dev = torch.from_numpy(buf).cuda()
+    gpu_ctx.construct_begin(n, k, max_cols)
+    gpu_ctx.construct_push_batch_dev(dev.data_ptr(), 0 if dtype == np.float32 else 1, ld, ns[:4])
+    gpu_ctx.construct_push_batch_dev(dev[4:].data_ptr(), 0 if dtype == np.float32 else 1, ld, ns[4:])
+    assert np.array_equal(gpu_ctx.construct_get_A(0, kk), a_seq)
+    assert np.array_equal(gpu_ctx.construct_finish(1, want_p=False)[0], w_seq)
+    w_ref, a_ref = so.construct_stream(snaps, list(ns))
+    assert np.array_equal(w_seq, w_ref)
+    if not max_cols:
+        assert np.array_equal(a_seq, a_ref)
+
+
 def test_push_state_errors(si, gpu_ctx):
     gpu_ctx.construct_begin(10, 2)
     gpu_ctx.construct_push(np.zeros(10, dtype=np.float32), 1.0)
