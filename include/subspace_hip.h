@@ -68,7 +68,8 @@ enum {
   SI_K_RWMH = 7,     /* K6 propose / accept kernels           */
   SI_K_DENSE_MAIN = 8, /* K5 the largest layer only (dominant kernel) */
   SI_K_EIG_HOST = 9,   /* H1 K x K symmetric eigensolve: HOST wall time, not a device kernel */
-  SI_K_COUNT = 10
+  SI_K_BACKWARD = 10,  /* reverse sweep of si_logdensity_grad: delta, dW (split-K MFMA), W'delta, P'g */
+  SI_K_COUNT = 11
 };
 
 typedef struct {
@@ -134,8 +135,17 @@ int32_t si_infer_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
                        int32_t compute_dtype);
 /* :90-95  lp[c] = logpdf(MvNormal(vec(f_{W_swa+P z_c}(X)), sigma_m), vec(Y)),  Z is M x C          */
 int32_t si_logdensity(si_ctx* ctx, const double* Z, int32_t C, double* lp_out /* C */);
+/* lp and its gradient with respect to z: grad_out[m] = d lp / d z_m = (P' * d lp / d w)[m].
+ * Replaces `l_pi_grad(theta) = (density(theta), getbackend(backend).gradient(density, theta))`
+ * (src/space_inference.jl:107): one reverse sweep through the chain instead of M-wide forward duals.         */
+int32_t si_logdensity_grad(si_ctx* ctx, const double* z /* M */, double* lp_out, double* grad_out /* M */);
 /* same, additionally returning the model output (out_dim x B) of the LAST z -- forward-pass parity  */
 int32_t si_forward(si_ctx* ctx, const double* z /* M */, double* Yhat_out /* out_dim x B */);
+/* posterior predictive on NEW inputs: Yhat_out[:, :, c] = f_{W_swa + P*Z[:, c]}(Xnew), out_dim x Bn x C column-major.
+ * What the reference's users compute on the host from every returned weight sample (docs/src/nn_example.md:207-217,
+ * `re(chn[i])(x)`), without materialising the N-long weight vectors.                                  */
+int32_t si_predict(si_ctx* ctx, const double* Z /* M x C */, int32_t C, const double* Xnew /* in_dim x Bn */,
+                   int64_t Bn, double* Yhat_out);
 /* :111-116  DensityModel + RWMH(MvNormal(zeros(M), sigma_z)) + sample(model, spl, itr): `itr` samples
  * per chain INCLUDING the initial draw z0 ~ proposal; accept iff -randexp() < lp' - lp.  Chains
  * chain_id0 .. chain_id0+nchains-1 use the library's Philox4x32-10 streams (seed, chain, step).

@@ -141,6 +141,42 @@ def logdensity(table, w_swa, p, x, y, sigma_m, z):
     return lp
 
 
+def _dact(h, kind):
+    """derivative of the activation expressed through its OUTPUT h (relu' = [h > 0], tanh' = 1 - h^2, ...)"""
+    if kind == ACT_IDENTITY:
+        return np.ones_like(h)
+    if kind == ACT_RELU:
+        return (h > 0.0).astype(h.dtype)
+    if kind == ACT_TANH:
+        return 1.0 - h * h
+    if kind == ACT_SIGMOID:
+        return h * (1.0 - h)
+    raise ValueError(kind)
+
+
+def logdensity_grad(table, w_swa, p, x, y, sigma_m, z):
+    """src/space_inference.jl:107  `l_pi_grad(theta) = (density(theta), gradient(density, theta))`.
+
+    The reference differentiates `density` with ForwardDiff (M duals through the chain); the value is the gradient of
+    the same scalar, restated here as one reverse sweep in NumPy.  Returns (lp, d lp / d z, d lp / d w)."""
+    new_w = w_swa + p @ z
+    hs = [x]
+    for (fin, fout, act, w_off, b_off) in table:
+        w = new_w[w_off:w_off + fin * fout].reshape((fout, fin), order="F")
+        hs.append(_act(w @ hs[-1] + new_w[b_off:b_off + fout][:, None], act))
+    lp, _ = mvnormal_logpdf_iso(y.reshape(-1, order="F"), hs[-1].reshape(-1, order="F"), sigma_m)
+    gw = np.zeros_like(new_w)
+    delta = (y - hs[-1]) / (sigma_m * sigma_m) * _dact(hs[-1], table[-1][2])
+    for l in range(len(table) - 1, -1, -1):
+        fin, fout, act, w_off, b_off = table[l]
+        gw[w_off:w_off + fin * fout] = (delta @ hs[l].T).reshape(-1, order="F")
+        gw[b_off:b_off + fout] = delta.sum(axis=1)
+        if l > 0:
+            w = new_w[w_off:w_off + fin * fout].reshape((fout, fin), order="F")
+            delta = (w.T @ delta) * _dact(hs[l], table[l - 1][2])
+    return lp, p.T @ gw, gw
+
+
 def reconstruct(w_swa, p, z):
     """src/space_inference.jl:91 and :125  `W_swa + P*z`."""
     return w_swa + p @ z

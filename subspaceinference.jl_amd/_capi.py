@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "libsubspace_hip.so")
 SI_OK, SI_ERR_INVALID, SI_ERR_STATE, SI_ERR_HIP, SI_ERR_NOMEM, SI_ERR_BOUNDS, SI_ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 SI_F32, SI_F64 = 0, 1
 ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
-K_NAMES = ["push", "gram", "gram_reduce", "project", "reconstruct", "dense", "sse", "rwmh", "dense_main", "eig_host"]
+K_NAMES = ["push", "gram", "gram_reduce", "project", "reconstruct", "dense", "sse", "rwmh", "dense_main", "eig_host", "backward"]
 K_COUNT = len(K_NAMES)
 
 
@@ -67,7 +67,9 @@ SIGNATURES = {
     "si_infer_setup": (c_int32, [c_void_p, POINTER(SiLayer), c_int32, c_int64, c_int32, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_int32, c_int32, c_int64, c_double, c_int32]),
     "si_logdensity": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
+    "si_logdensity_grad": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "si_forward": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "si_predict": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "si_sample_rwmh": (c_int32, [c_void_p, c_int64, c_double, c_uint64, c_int32, c_int32, c_void_p, c_void_p,
                                  c_void_p]),
     "si_reconstruct": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
@@ -254,11 +256,31 @@ class Context:
         self._check(self.lib.si_logdensity(self.h, _ptr(z), z.shape[1], _ptr(lp)))
         return lp
 
+    def logdensity_grad(self, z):
+        z = _f64(z).reshape(-1)
+        if z.size != self._m:
+            raise SubspaceError("DimensionMismatch: z has %d elements, M = %d" % (z.size, self._m))
+        lp = np.empty(1, dtype=np.float64)
+        g = np.empty(self._m, dtype=np.float64)
+        self._check(self.lib.si_logdensity_grad(self.h, _ptr(z), _ptr(lp), _ptr(g)))
+        return float(lp[0]), g
+
     def forward(self, z):
         z = _f64(z).reshape(-1)
         yhat = np.empty((self._out, self._b), dtype=np.float64, order="F")
         self._check(self.lib.si_forward(self.h, _ptr(z), _ptr(yhat)))
         return yhat
+
+    def predict(self, z, xnew):
+        z = _f64(z)
+        if z.ndim == 1:
+            z = z.reshape(-1, 1, order="F")
+        xnew = _f64(xnew)
+        if z.shape[0] != self._m or xnew.ndim != 2 or xnew.shape[0] != self._in:
+            raise SubspaceError("DimensionMismatch: Z %s, Xnew %s" % (z.shape, xnew.shape))
+        out = np.empty((self._out, xnew.shape[1], z.shape[1]), dtype=np.float64, order="F")
+        self._check(self.lib.si_predict(self.h, _ptr(z), z.shape[1], _ptr(xnew), xnew.shape[1], _ptr(out)))
+        return out
 
     def sample_rwmh(self, itr, sigma_z, seed, chain_id0=0, nchains=1, want_z=True):
         z = np.empty((self._m, int(itr), int(nchains)), dtype=np.float64, order="F") if want_z else None

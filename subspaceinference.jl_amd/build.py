@@ -19,9 +19,10 @@ SOURCES = [
     ("kernels_stream.hip", ["-ffp-contract=off"]),
     ("kernels_gemm.hip", []),
     ("kernels_gram.hip", []),
+    ("kernels_bwd.hip", []),
     ("eig.cpp", []),
 ]
-HEADERS = ["si_internal.h", "philox.h", os.path.join("..", "..", "include", "subspace_hip.h")]
+HEADERS = ["si_internal.h", "philox.h", "kernels_gemm.h", os.path.join("..", "..", "include", "subspace_hip.h")]
 
 
 def _hipcc():

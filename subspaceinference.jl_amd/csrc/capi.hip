@@ -105,6 +105,16 @@ static void free_infer(Ctx* c) {
   dev_free(c->d_ssepart);
   dev_free(c->d_part);
   dev_free(c->d_yhat);
+  for (auto& h : c->d_hs) dev_free(h);
+  c->d_hs.clear();
+  dev_free(c->d_delta[0]);
+  dev_free(c->d_delta[1]);
+  dev_free(c->d_gw);
+  dev_free(c->d_bwpart);
+  dev_free(c->d_rspart);
+  dev_free(c->d_ptgpart);
+  dev_free(c->d_gz);
+  c->g_ready = false;
   c->fuse_tail = false;
   dev_free(c->d_zcur);
   dev_free(c->d_zprop);
@@ -692,6 +702,101 @@ int32_t si_logdensity(si_ctx* ctx, const double* Z, int32_t C, double* lp_out) {
   return SI_OK;
 }
 
+static int32_t ensure_grad(si_ctx* ctx) {
+  if (ctx->g_ready) return SI_OK;
+  const int64_t B = ctx->B;
+  int64_t maxw = 1;
+  size_t maxpart = 1;
+  ctx->d_hs.assign(ctx->layers.size(), nullptr);
+  bool ok = true;
+  for (size_t l = 0; l < ctx->layers.size() && ok; ++l) {
+    const si_layer& ly = ctx->layers[l];
+    maxw = std::max<int64_t>(maxw, ly.out);
+    int64_t ks;
+    const int ns = backward_weight_splits(ly.out, ly.in, B, ctx->num_cu, &ks);
+    maxpart = std::max(maxpart, (size_t)ns * ly.out * ly.in);
+    ok = dev_alloc(&ctx->d_hs[l], (size_t)ly.out * B) == hipSuccess;
+  }
+  ok = ok && dev_alloc(&ctx->d_delta[0], (size_t)maxw * B) == hipSuccess &&
+       dev_alloc(&ctx->d_delta[1], (size_t)maxw * B) == hipSuccess &&
+       dev_alloc(&ctx->d_gw, (size_t)pad_ld(ctx->iN)) == hipSuccess && dev_alloc(&ctx->d_bwpart, maxpart) == hipSuccess &&
+       dev_alloc(&ctx->d_rspart, (size_t)rowsum_chunks() * maxw) == hipSuccess &&
+       dev_alloc(&ctx->d_ptgpart, (size_t)ptg_blocks() * ctx->iM) == hipSuccess && dev_alloc(&ctx->d_gz, (size_t)ctx->iM) == hipSuccess;
+  if (!ok) {
+    for (auto& h : ctx->d_hs) dev_free(h);
+    ctx->d_hs.clear();
+    dev_free(ctx->d_delta[0]); dev_free(ctx->d_delta[1]); dev_free(ctx->d_gw); dev_free(ctx->d_bwpart);
+    dev_free(ctx->d_rspart); dev_free(ctx->d_ptgpart); dev_free(ctx->d_gz);
+    return fail(ctx, SI_ERR_NOMEM, "si_logdensity_grad: workspace allocation failed");
+  }
+  ctx->g_ready = true;
+  return SI_OK;
+}
+
+int32_t si_logdensity_grad(si_ctx* ctx, const double* z, double* lp_out, double* grad_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_logdensity_grad: call si_infer_setup first");
+  if (!z || !lp_out || !grad_out) return fail(ctx, SI_ERR_INVALID, "si_logdensity_grad: bad argument");
+  BIND(ctx);
+  int32_t rc = ensure_chains(ctx, 1);
+  if (rc != SI_OK) return rc;
+  if ((rc = ensure_grad(ctx)) != SI_OK) return rc;
+  const int64_t N = ctx->iN, B = ctx->B;
+  const int32_t M = ctx->iM;
+  const size_t nl = ctx->layers.size();
+  const double s2 = ctx->sigma_m * ctx->sigma_m;
+  SI_HIP(ctx, hipMemcpyAsync(ctx->d_zprop, z, (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  {
+    ProfScope ps(ctx, SI_K_RECON, 2.0 * (double)N * M, (double)N * (M + 2) * 8.0);
+    launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, ctx->d_zprop, 1, ctx->d_w, pad_ld(N), ctx->num_cu);
+  }
+  // forward with every layer's output kept (the fused tail is not used here: the backward sweep needs them all)
+  const double* h = ctx->d_X;
+  for (size_t l = 0; l < nl; ++l) {
+    const si_layer& ly = ctx->layers[l];
+    ProfScope ps(ctx, SI_K_DENSE, 2.0 * (double)ly.in * ly.out * (double)B,
+                 ((double)ly.in * ly.out + ly.out + (double)(ly.in + ly.out) * (double)B) * 8.0);
+    launch_dense_f64(ctx->stream, ctx->d_w + ly.w_off, ctx->d_w + ly.b_off, h, ctx->d_hs[l], ly.out, ly.in, B, ly.act);
+    h = ctx->d_hs[l];
+  }
+  const int64_t d = (int64_t)ctx->out_dim * B;
+  {
+    ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d, 16.0 * (double)d);
+    launch_sse(ctx->stream, h, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse);
+  }
+  {
+    double bflops = 0.0;
+    for (const auto& ly : ctx->layers) bflops += 4.0 * (double)ly.in * ly.out * (double)B;
+    ProfScope ps(ctx, SI_K_BACKWARD, bflops, 0.0);
+    SI_HIP(ctx, hipMemsetAsync(ctx->d_gw, 0, (size_t)pad_ld(N) * sizeof(double), ctx->stream));
+    int cur = 0;
+    // d lp / d yhat = (y - yhat) / sigma^2
+    launch_delta_out(ctx->stream, ctx->d_Y, h, d, 1.0 / s2, ctx->layers[nl - 1].act, ctx->d_delta[cur]);
+    for (size_t li = nl; li-- > 0;) {
+      const si_layer& ly = ctx->layers[li];
+      const double* hprev = li > 0 ? ctx->d_hs[li - 1] : ctx->d_X;
+      launch_rowsum(ctx->stream, ctx->d_delta[cur], ly.out, B, ctx->d_rspart, ctx->d_gw + ly.b_off);
+      int64_t ks;
+      const int ns = backward_weight_splits(ly.out, ly.in, B, ctx->num_cu, &ks);
+      launch_backward_weight(ctx->stream, ctx->d_delta[cur], hprev, ctx->d_bwpart, ly.out, ly.in, B, ns, ks);
+      launch_split_reduce(ctx->stream, ctx->d_bwpart, ns, (int64_t)ly.out * ly.in, ctx->d_gw + ly.w_off);
+      if (li > 0) {
+        launch_backward_data(ctx->stream, ctx->d_w + ly.w_off, ctx->d_delta[cur], hprev, ctx->d_delta[cur ^ 1], ly.out,
+                             ly.in, B, ctx->layers[li - 1].act);
+        cur ^= 1;
+      }
+    }
+    launch_ptg(ctx->stream, ctx->i_P, ctx->ldP, N, M, ctx->d_gw, ctx->d_ptgpart, ctx->d_gz);
+  }
+  SI_HIP(ctx, hipGetLastError());
+  double sse = 0.0;
+  SI_HIP(ctx, hipMemcpyAsync(&sse, ctx->d_sse, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipMemcpyAsync(grad_out, ctx->d_gz, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *lp_out = mvnormal_c0((double)d, ctx->sigma_m) - (sse / s2) / 2.0;
+  return SI_OK;
+}
+
 int32_t si_forward(si_ctx* ctx, const double* z, double* Yhat_out) {
   CHECK_CTX(ctx);
   if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_forward: call si_infer_setup first");
@@ -704,6 +809,56 @@ int32_t si_forward(si_ctx* ctx, const double* z, double* Yhat_out) {
   if ((rc = eval_density(ctx, 0, &yh)) != SI_OK) return rc;
   SI_HIP(ctx, hipMemcpyAsync(Yhat_out, yh, (size_t)ctx->out_dim * ctx->B * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+int32_t si_predict(si_ctx* ctx, const double* Z, int32_t C, const double* Xnew, int64_t Bn, double* Yhat_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_predict: call si_infer_setup first");
+  if (!Z || C <= 0 || !Xnew || Bn <= 0 || !Yhat_out) return fail(ctx, SI_ERR_INVALID, "si_predict: bad argument");
+  BIND(ctx);
+  int32_t rc = ensure_chains(ctx, C);
+  if (rc != SI_OK) return rc;
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // run the ordinary forward path on temporary data buffers sized for Bn (the density's own X, Y stay untouched)
+  struct Saved {
+    double *X, *Y, *act0, *act1, *ssepart, *part, *yhat;
+    int64_t B, act_elems;
+    int sse_blocks;
+  } sv{ctx->d_X, ctx->d_Y, ctx->d_act[0], ctx->d_act[1], ctx->d_ssepart, ctx->d_part, ctx->d_yhat,
+       ctx->B, ctx->act_elems, ctx->sse_blocks};
+  const int64_t act_elems = sv.act_elems / sv.B * Bn;
+  const int sse_blocks = sse_num_blocks((int64_t)ctx->out_dim * Bn, ctx->num_cu);
+  double *tX = nullptr, *tY = nullptr, *tA0 = nullptr, *tA1 = nullptr, *tS = nullptr, *tP = nullptr, *tYh = nullptr;
+  bool ok = dev_alloc(&tX, (size_t)ctx->in_dim * Bn) == hipSuccess && dev_alloc(&tY, (size_t)ctx->out_dim * Bn) == hipSuccess &&
+            dev_alloc(&tA0, (size_t)act_elems) == hipSuccess && dev_alloc(&tA1, (size_t)act_elems) == hipSuccess &&
+            dev_alloc(&tS, (size_t)sse_blocks) == hipSuccess &&
+            (!ctx->fuse_tail || (dev_alloc(&tP, (size_t)ctx->fuse_slots * ctx->out_dim * Bn) == hipSuccess &&
+                                 dev_alloc(&tYh, (size_t)ctx->out_dim * Bn) == hipSuccess));
+  hipError_t e = hipSuccess;
+  if (ok) {
+    e = hipMemcpyAsync(tX, Xnew, (size_t)ctx->in_dim * Bn * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(tY, 0, (size_t)ctx->out_dim * Bn * sizeof(double), ctx->stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(ctx->d_zprop, Z, (size_t)ctx->iM * C * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    ctx->d_X = tX; ctx->d_Y = tY; ctx->d_act[0] = tA0; ctx->d_act[1] = tA1; ctx->d_ssepart = tS; ctx->d_part = tP;
+    ctx->d_yhat = tYh; ctx->B = Bn; ctx->act_elems = act_elems; ctx->sse_blocks = sse_blocks;
+    for (int c = 0; c < C && e == hipSuccess && rc == SI_OK; ++c) {
+      const double* yh = nullptr;
+      rc = eval_density(ctx, c, &yh);
+      if (rc == SI_OK)
+        e = hipMemcpyAsync(Yhat_out + (size_t)c * ctx->out_dim * Bn, yh, (size_t)ctx->out_dim * Bn * sizeof(double),
+                           hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // yh is overwritten by the next sample
+    }
+    ctx->d_X = sv.X; ctx->d_Y = sv.Y; ctx->d_act[0] = sv.act0; ctx->d_act[1] = sv.act1; ctx->d_ssepart = sv.ssepart;
+    ctx->d_part = sv.part; ctx->d_yhat = sv.yhat; ctx->B = sv.B; ctx->act_elems = sv.act_elems; ctx->sse_blocks = sv.sse_blocks;
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  dev_free(tX); dev_free(tY); dev_free(tA0); dev_free(tA1); dev_free(tS); dev_free(tP); dev_free(tYh);
+  if (!ok) return fail(ctx, SI_ERR_NOMEM, "si_predict: device allocation failed");
+  if (rc != SI_OK) return rc;
+  if (e != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string("si_predict: ") + hipGetErrorString(e));
   return SI_OK;
 }
 

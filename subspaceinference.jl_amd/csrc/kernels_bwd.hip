@@ -1,0 +1,451 @@
+// Backward pass of the Dense chain in fp64: the gradient of the log-density (or of the mse
+// training loss) with respect to the flat weight vector, and its pull-back to the subspace, grad_z = P' grad_w.
+// The reference obtains d lp / d z by pushing M-wide ForwardDiff duals through the whole network
+// (src/space_inference.jl:107 `getbackend(backend).gradient(density, theta)`); one reverse sweep gives the same
+// numbers with 2x the forward flops instead of Mx.
+//
+//   Delta_L     = g .* act_L'(H_L)                              delta_out_kernel
+//   dW_l        = Delta_l * H_{l-1}'      (out x in, K = B)     gemm_f64_kernel<A m-fast, B n-fast, split-K> + reduce
+//   db_l        = rowsum(Delta_l)                               rowsum kernels
+//   Delta_{l-1} = (W_l' * Delta_l) .* act_{l-1}'(H_{l-1})       gemm_f64_kernel<A k-fast, B k-fast, EPI_DACT>
+//   grad_z      = P' * grad_w                                   pt_g kernels
+//
+// gemm_f64_kernel is the forward kernel's pipeline (kernels_gemm.hip: 8 waves, 16-deep k tiles, two LDS buffers, one
+// barrier per tile, MFMAs split around the LDS/global traffic, v_mfma_f64_16x16x4_f64) with the operand staging made
+// generic over the two storage orders an operand can have:
+//   layout 0 "row-fast": X[r + ld*k]  -> LDS [k][R+16]      layout 1 "k-fast": X[k + ld*r] -> LDS [r][18]
+// Both LDS images give conflict-free ds_read_b64 operand reads (same bank arithmetic as the forward kernel).
+#include <type_traits>
+
+#include "kernels_gemm.h"
+
+namespace si {
+
+enum { EPI_DACT = 1, EPI_RAW = 2 };
+
+__device__ __forceinline__ double dact_from_output(double h, int act) {
+  switch (act) {
+    case SI_ACT_RELU: return h > 0.0 ? 1.0 : 0.0;       // relu'(z) = [z > 0] = [relu(z) > 0]
+    case SI_ACT_TANH: return 1.0 - h * h;
+    case SI_ACT_SIGMOID: return h * (1.0 - h);
+    default: return 1.0;
+  }
+}
+
+// one operand tile: R rows (feature / batch index) x 16 k values
+template <int R, int LAY, int NT, bool VEC>
+struct Stager {
+  static constexpr int E = VEC ? 2 : 1;
+  static constexpr int NREG = (16 * R + NT * E - 1) / (NT * E);
+  static constexpr int RP = R + 16, KP = 18;
+  static constexpr int LDS_ELEMS = LAY == 0 ? 16 * RP : R * KP;
+  int go[NREG], lds[NREG], kk[NREG];
+  bool live[NREG];
+  double reg[NREG][E];
+  const double* base;
+  int64_t ld;
+
+  __device__ __forceinline__ void init(const double* X, int64_t ld_, int64_t r0, int64_t rmax, int64_t k0, int tid) {
+    ld = ld_;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      const int idx = (tid + NT * r) * E;
+      if constexpr (LAY == 0) {
+        const int rr = idx % R, k = idx / R;
+        int64_t g = r0 + rr;
+        if (g > rmax - E) g = rmax - E;  // clamped rows only feed outputs that are never stored
+        if (g < 0) g = 0;
+        kk[r] = k;
+        live[r] = k < 16;
+        go[r] = (int)(g - r0) + (int)ld * (k < 16 ? k : 0);
+        lds[r] = k * RP + rr;
+      } else {
+        const int k = idx & 15, rr = idx >> 4;
+        int64_t g = r0 + (rr < R ? rr : 0);
+        if (g > rmax - 1) g = rmax - 1;
+        kk[r] = k;
+        live[r] = rr < R;
+        go[r] = (int)(g - r0) * (int)ld + k;
+        lds[r] = rr * KP + k;
+      }
+    }
+    base = LAY == 0 ? X + r0 + ld * k0 : X + ld * r0 + k0;
+  }
+  // klen = k values that remain from this tile's first k (>= 1)
+  __device__ __forceinline__ void load(int kt, int64_t klen_total) {
+    const double* p = base + (LAY == 0 ? ld * 16 : (int64_t)16) * kt;
+    const int64_t kmax = klen_total - (LAY == 1 ? E : 1) - (int64_t)kt * 16;  // last legal k (pair start) in this tile
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      int o = go[r];
+      if (kk[r] > kmax) o -= (int)(LAY == 0 ? ld : 1) * (int)(kk[r] - (kmax > 0 ? kmax : 0));
+      if constexpr (VEC) {
+        const double2 v = *reinterpret_cast<const double2*>(p + o);
+        reg[r][0] = v.x;
+        reg[r][1] = v.y;
+      } else {
+        reg[r][0] = p[o];
+      }
+    }
+  }
+  __device__ __forceinline__ void store(double* dst, int kt, int64_t klen_total) const {
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      if (!live[r]) continue;
+      const bool ok = (int64_t)kt * 16 + kk[r] < klen_total;  // zero-fill a ragged k edge (it would add into outputs)
+      if constexpr (VEC)
+        *reinterpret_cast<double2*>(dst + lds[r]) = make_double2(ok ? reg[r][0] : 0.0, ok ? reg[r][1] : 0.0);
+      else
+        dst[lds[r]] = ok ? reg[r][0] : 0.0;
+    }
+  }
+};
+
+// C[m + ldc*n] (+ epilogue) = sum_k A(m,k) * B(k,n) over k in [k0, k0+klen) of split blockIdx.y
+template <int BM, int BN, int WM, int WN, int MINW, int ALAY, int BLAY, bool VEC, int EPI>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_f64_kernel(
+    const double* __restrict__ A, int64_t lda, const double* __restrict__ Bm, int64_t ldb, double* __restrict__ C,
+    int64_t ldc, int Mrows, int64_t Ncols, int64_t Kdim, int64_t ksplit, const double* __restrict__ aux, int act, int nMt,
+    int64_t nNt) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  using SA = Stager<BM, ALAY, NT, VEC>;
+  using SB = Stager<BN, BLAY, NT, VEC>;
+  extern __shared__ double smem[];
+  double* sAbuf = smem;                           // [2][SA::LDS_ELEMS]
+  double* sBbuf = smem + 2 * SA::LDS_ELEMS;       // [2][SB::LDS_ELEMS]
+
+  const int64_t bid = blockIdx.x;
+  const int xcd = (int)(bid & 7);
+  const int64_t j = bid >> 3;
+  const int mt = (int)(j % nMt);
+  const int64_t nt = (j / nMt) * 8 + xcd;
+  if (nt >= nNt) return;
+  const int64_t k0 = (int64_t)blockIdx.y * ksplit;
+  int64_t klen = Kdim - k0;
+  if (klen > ksplit) klen = ksplit;
+  if (klen <= 0) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int m0 = mt * BM;
+  const int64_t n0 = nt * BN;
+  const int q = lane >> 4, c = lane & 15;
+
+  d4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  SA sa;
+  SB sb;
+  sa.init(A, lda, m0, Mrows, k0, tid);
+  sb.init(Bm, ldb, n0, Ncols, k0, tid);
+  const int nk = (int)((klen + 15) / 16);
+
+  double fa[2][TM], fb[2][TN];
+  const int aw = wm * (BM / WM) + c, bw = wn * (BN / WN) + c;
+  auto read_frags = [&](int buf, int s, auto SET) {
+    constexpr int set = decltype(SET)::value;
+    const double* pa = sAbuf + buf * SA::LDS_ELEMS;
+    const double* pb = sBbuf + buf * SB::LDS_ELEMS;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+      fa[set][a] = ALAY == 0 ? pa[(4 * s + q) * SA::RP + aw + a * 16] : pa[(aw + a * 16) * SA::KP + 4 * s + q];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+      fb[set][b] = BLAY == 0 ? pb[(4 * s + q) * SB::RP + bw + b * 16] : pb[(bw + b * 16) * SB::KP + 4 * s + q];
+  };
+  auto mfma_half = [&](auto SET, auto HALF) {
+    constexpr int set = decltype(SET)::value, half = decltype(HALF)::value;
+    constexpr int lo = half == 0 ? 0 : (TM * TN) / 2, hi = half == 0 ? (TM * TN) / 2 : TM * TN;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int t = lo; t < hi; ++t) {
+      const int a = t / TN, b = t % TN;
+      acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[set][b], fa[set][a], acc[a][b], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  sa.load(0, klen);
+  sb.load(0, klen);
+  sa.store(sAbuf, 0, klen);
+  sb.store(sBbuf, 0, klen);
+  if (nk > 1) {
+    sa.load(1, klen);
+    sb.load(1, klen);
+  }
+  __syncthreads();
+  read_frags(0, 0, I0{});
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    mfma_half(I0{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(buf, 1, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(I0{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+
+    mfma_half(I1{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(buf, 2, I0{});
+    if (kt + 1 < nk) {
+      sa.store(sAbuf + (buf ^ 1) * SA::LDS_ELEMS, kt + 1, klen);
+      sb.store(sBbuf + (buf ^ 1) * SB::LDS_ELEMS, kt + 1, klen);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(I1{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+
+    mfma_half(I0{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(buf, 3, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(I0{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+
+    mfma_half(I1{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (kt + 1 < nk) read_frags(buf ^ 1, 0, I0{});
+    if (kt + 2 < nk) {
+      sa.load(kt + 2, klen);
+      sb.load(kt + 2, klen);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(I1{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // epilogue: D[n = q + 4r][m = c] per tile; transposed through LDS for 16-B stores when the shape allows
+  constexpr int WI = BM / WM;
+  constexpr bool WIDE = VEC && (64 % (WI / 2) == 0) && (WM * WN * 16 * WI <= 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS));
+  const int mw0 = m0 + wm * WI;
+  const int64_t nw0 = n0 + wn * (BN / WN);
+  double* Cout = C + (EPI == EPI_RAW ? (int64_t)blockIdx.y * ldc * Ncols : 0);
+  if constexpr (WIDE) {
+    constexpr int CH_ROW = WI / 2, NCH = 16 * CH_ROW / 64;
+    double* reg = smem + wave * (16 * WI);
+    __syncthreads();  // all waves are done with the staging buffers (the loop's last barrier precedes the last reads)
+#pragma unroll
+    for (int bt = 0; bt < TN; ++bt) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) reg[(q + 4 * r) * WI + a * 16 + c] = acc[a][bt][r];
+#pragma unroll
+      for (int p = 0; p < NCH; ++p) {
+        const int chunk = p * 64 + lane;
+        const int row = chunk / CH_ROW, col2 = chunk % CH_ROW;
+        double2 v = *reinterpret_cast<const double2*>(reg + 2 * chunk);
+        const int gm = mw0 + 2 * col2;
+        const int64_t gn = nw0 + bt * 16 + row;
+        if (gm + 1 < Mrows && gn < Ncols) {
+          const int64_t off = gm + ldc * gn;
+          if constexpr (EPI == EPI_DACT) {
+            const double2 h = *reinterpret_cast<const double2*>(aux + off);
+            v.x *= dact_from_output(h.x, act);
+            v.y *= dact_from_output(h.y, act);
+          }
+          *reinterpret_cast<double2*>(Cout + off) = v;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int gm = mw0 + a * 16 + c;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t gn = nw0 + b * 16 + q + 4 * r;
+          if (gm < Mrows && gn < Ncols) {
+            const int64_t off = gm + ldc * gn;
+            double v = acc[a][b][r];
+            if constexpr (EPI == EPI_DACT) v *= dact_from_output(aux[off], act);
+            Cout[off] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int ALAY, int BLAY, int EPI>
+static void launch_gemm(hipStream_t st, const double* A, int64_t lda, const double* Bm, int64_t ldb, double* C, int64_t ldc,
+                        int Mrows, int64_t Ncols, int64_t Kdim, int nsplit, int64_t ksplit, const double* aux, int act) {
+  constexpr int WM = 2, WN = 4, NT = 512;
+  using SA = Stager<BM, ALAY, NT, false>;
+  using SB = Stager<BN, BLAY, NT, false>;
+  constexpr size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(double);
+  const int nMt = (Mrows + BM - 1) / BM;
+  const int64_t nNt = (Ncols + BN - 1) / BN;
+  const int64_t grid = (nNt + 7) / 8 * nMt * 8;
+  // 16-B staging: pairs run along the fast index of each operand, so that extent and the leading dimensions must be
+  // even and the bases 16-B aligned; the k-fast pairs also need every split to start at an even k
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  const bool vec = al(A) && al(Bm) && al(C) && (aux == nullptr || al(aux)) && lda % 2 == 0 && ldb % 2 == 0 &&
+                   ldc % 2 == 0 && Mrows % 2 == 0 && (ALAY == 0 || Kdim % 2 == 0) &&
+                   (BLAY == 0 ? Ncols % 2 == 0 : Kdim % 2 == 0) && ksplit % 2 == 0;
+  if (vec) {
+    auto kern = gemm_f64_kernel<BM, BN, WM, WN, 4, ALAY, BLAY, true, EPI>;
+    static bool set = false;
+    if (!set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)nsplit), dim3(NT), lds, st, A, lda, Bm, ldb, C, ldc, Mrows,
+                       Ncols, Kdim, ksplit, aux, act, nMt, nNt);
+  } else {
+    auto kern = gemm_f64_kernel<BM, BN, WM, WN, 4, ALAY, BLAY, false, EPI>;
+    static bool set = false;
+    if (!set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)nsplit), dim3(NT), lds, st, A, lda, Bm, ldb, C, ldc, Mrows,
+                       Ncols, Kdim, ksplit, aux, act, nMt, nNt);
+  }
+}
+
+// Delta_prev[in x B] = (W' * Delta) .* act_prev'(Hprev);  W is out x in (column-major) inside the flat vector
+void launch_backward_data(hipStream_t st, const double* W, const double* Delta, const double* Hprev, double* DeltaPrev,
+                          int32_t out, int32_t in, int64_t B, int32_t act_prev) {
+  // A(m = in idx, k = out idx) = W[k + out*m]: k-fast;  B(k, n = b) = Delta[k + out*n]: k-fast
+  if (in > 64)
+    launch_gemm<128, 128, 1, 1, EPI_DACT>(st, W, out, Delta, out, DeltaPrev, in, in, B, out, 1, ((int64_t)out + 15) / 16 * 16, Hprev, act_prev);
+  else
+    launch_gemm<64, 128, 1, 1, EPI_DACT>(st, W, out, Delta, out, DeltaPrev, in, in, B, out, 1, ((int64_t)out + 15) / 16 * 16, Hprev, act_prev);
+}
+
+// partial dW[split][out x in] = Delta[:, split's columns] * Hprev[:, split's columns]';  returns nsplit
+int backward_weight_splits(int32_t out, int32_t in, int64_t B, int num_cu, int64_t* ksplit_out) {
+  const int bm = out > 64 ? 128 : 64;
+  const int64_t tiles = (int64_t)((out + bm - 1) / bm) * ((in + 127) / 128);
+  int64_t nsplit = ((int64_t)num_cu * 3 + tiles - 1) / tiles;
+  const int64_t maxsplit = (B + 255) / 256;
+  if (nsplit > maxsplit) nsplit = maxsplit;
+  if (nsplit < 1) nsplit = 1;
+  int64_t ks = ((B + nsplit - 1) / nsplit + 15) / 16 * 16;
+  nsplit = (B + ks - 1) / ks;
+  *ksplit_out = ks;
+  return (int)nsplit;
+}
+
+void launch_backward_weight(hipStream_t st, const double* Delta, const double* Hprev, double* part, int32_t out,
+                            int32_t in, int64_t B, int nsplit, int64_t ksplit) {
+  // A(m = out idx, k = b) = Delta[m + out*k]: row-fast;  B(k = b, n = in idx) = Hprev[n + in*k]: row-fast
+  if (out > 64)
+    launch_gemm<128, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0);
+  else
+    launch_gemm<64, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ small kernels
+// dst[e] = sum_split part[split][e], fixed order (bit-reproducible)
+__global__ __launch_bounds__(256) void split_reduce_kernel(const double* __restrict__ part, int nsplit, int64_t elems,
+                                                           double* __restrict__ dst) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < elems; e += stride) {
+    double s = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[(int64_t)sp * elems + e];
+    dst[e] = s;
+  }
+}
+void launch_split_reduce(hipStream_t st, const double* part, int nsplit, int64_t elems, double* dst) {
+  int64_t blocks = (elems + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, nsplit, elems, dst);
+}
+
+// Delta_L[e] = scale * (Y[e] - Yhat[e]) * act_L'(Yhat[e])      (scale = 1/sigma^2 for lp, -2/d for the mse loss)
+__global__ __launch_bounds__(256) void delta_out_kernel(const double* __restrict__ Y, const double* __restrict__ Yhat,
+                                                        int64_t d, double scale, int act, double* __restrict__ delta) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < d; e += stride) {
+    const double yh = Yhat[e];
+    delta[e] = scale * (Y[e] - yh) * dact_from_output(yh, act);
+  }
+}
+void launch_delta_out(hipStream_t st, const double* Y, const double* Yhat, int64_t d, double scale, int act, double* delta) {
+  int64_t blocks = (d + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(delta_out_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Y, Yhat, d, scale, act, delta);
+}
+
+// db[i] = sum_b Delta[i + out*b]: stage 1 gives one partial per (column chunk, i); stage 2 sums chunks in order
+constexpr int RS_CHUNKS = 64;
+__global__ __launch_bounds__(256) void rowsum_partial_kernel(const double* __restrict__ D, int out, int64_t B,
+                                                             double* __restrict__ part) {
+  // block = (32 rows) x (8 column lanes); grid.x = row groups, grid.y = column chunk
+  __shared__ double red[8][33];
+  const int il = threadIdx.x & 31, bl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + il;
+  const int64_t per = (B + RS_CHUNKS - 1) / RS_CHUNKS;
+  const int64_t b0 = (int64_t)blockIdx.y * per;
+  int64_t b1 = b0 + per;
+  if (b1 > B) b1 = B;
+  double s = 0.0;
+  if (i < out)
+    for (int64_t b = b0 + bl; b < b1; b += 8) s += D[i + (int64_t)out * b];
+  red[bl][il] = s;
+  __syncthreads();
+  if (bl == 0 && i < out) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][il];
+    part[(int64_t)blockIdx.y * out + i] = t;
+  }
+}
+__global__ __launch_bounds__(256) void rowsum_final_kernel(const double* __restrict__ part, int out, double* __restrict__ db) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= out) return;
+  double s = 0.0;
+  for (int ch = 0; ch < RS_CHUNKS; ++ch) s += part[(int64_t)ch * out + i];
+  db[i] = s;
+}
+void launch_rowsum(hipStream_t st, const double* D, int32_t out, int64_t B, double* part /* RS_CHUNKS*out */, double* db) {
+  hipLaunchKernelGGL(rowsum_partial_kernel, dim3((out + 31) / 32, RS_CHUNKS), dim3(256), 0, st, D, (int)out, B, part);
+  hipLaunchKernelGGL(rowsum_final_kernel, dim3((out + 255) / 256), dim3(256), 0, st, part, (int)out, db);
+}
+int rowsum_chunks() { return RS_CHUNKS; }
+
+// grad_z[m] = sum_r P[r + ldP*m] * g[r]   (HBM-bound: P is read once, N*M*8 bytes)
+constexpr int PTG_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void ptg_partial_kernel(const double* __restrict__ P, int64_t ldP, int64_t N, int M,
+                                                          const double* __restrict__ g, double* __restrict__ part) {
+  __shared__ double red[4];
+  const int64_t per = ((N + PTG_BLOCKS - 1) / PTG_BLOCKS + 1) / 2 * 2;
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  int64_t r1 = r0 + per;
+  if (r1 > N) r1 = N;
+  for (int m = 0; m < M; ++m) {
+    double s = 0.0;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) s += P[r + ldP * m] * g[r];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.x * M + m] = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+  }
+}
+__global__ void ptg_final_kernel(const double* __restrict__ part, int M, double* __restrict__ gz) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double s = 0.0;
+  for (int b = 0; b < PTG_BLOCKS; ++b) s += part[(int64_t)b * M + m];
+  gz[m] = s;
+}
+void launch_ptg(hipStream_t st, const double* P, int64_t ldP, int64_t N, int M, const double* g, double* part, double* gz) {
+  hipLaunchKernelGGL(ptg_partial_kernel, dim3(PTG_BLOCKS), dim3(256), 0, st, P, ldP, N, M, g, part);
+  hipLaunchKernelGGL(ptg_final_kernel, dim3((M + 63) / 64), dim3(64), 0, st, part, M, gz);
+}
+int ptg_blocks() { return PTG_BLOCKS; }
+
+}  // namespace si

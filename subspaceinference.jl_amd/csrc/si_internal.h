@@ -80,6 +80,15 @@ struct Ctx {
   double* d_yhat = nullptr;     // out_dim x B, only filled on request (si_forward)
   int sse_blocks = 0;
   int main_layer = 0;
+  // gradient workspace (allocated on the first si_logdensity_grad)
+  bool g_ready = false;
+  std::vector<double*> d_hs;   // post-activation output of every layer, out_l x B
+  double* d_delta[2] = {nullptr, nullptr};
+  double* d_gw = nullptr;      // gradient w.r.t. the flat weight vector
+  double* d_bwpart = nullptr;  // split-K partials of dW
+  double* d_rspart = nullptr;  // row-sum partials
+  double* d_ptgpart = nullptr;
+  double* d_gz = nullptr;
   // sampler state (device)
   double* d_zcur = nullptr;   // M x C
   double* d_zprop = nullptr;  // M x C
@@ -142,6 +151,18 @@ void launch_sse_final(hipStream_t st, const double* blockpart, int nblocks, doub
 int sse_num_blocks(int64_t d, int num_cu);
 void launch_sse(hipStream_t st, const double* yhat, const double* y, int64_t d, double* part,
                 int nblocks, double* sse_out);
+// backward pass (kernels_bwd.hip): gradient of the log-density w.r.t. the flat weights and its pull-back P' g
+void launch_backward_data(hipStream_t st, const double* W, const double* Delta, const double* Hprev, double* DeltaPrev,
+                          int32_t out, int32_t in, int64_t B, int32_t act_prev);
+int backward_weight_splits(int32_t out, int32_t in, int64_t B, int num_cu, int64_t* ksplit_out);
+void launch_backward_weight(hipStream_t st, const double* Delta, const double* Hprev, double* part, int32_t out,
+                            int32_t in, int64_t B, int nsplit, int64_t ksplit);
+void launch_split_reduce(hipStream_t st, const double* part, int nsplit, int64_t elems, double* dst);
+void launch_delta_out(hipStream_t st, const double* Y, const double* Yhat, int64_t d, double scale, int act, double* delta);
+void launch_rowsum(hipStream_t st, const double* D, int32_t out, int64_t B, double* part, double* db);
+int rowsum_chunks();
+void launch_ptg(hipStream_t st, const double* P, int64_t ldP, int64_t N, int M, const double* g, double* part, double* gz);
+int ptg_blocks();
 // K6
 void launch_rwmh_init(hipStream_t st, double* zcur, double* lpcur, int64_t* nacc, int32_t M, int32_t C);
 void launch_rwmh_propose(hipStream_t st, const double* zcur, double* zprop, int32_t M, int32_t C,

@@ -196,6 +196,42 @@ def test_forward_and_logdensity(gpu_ctx, dims, acts, b, m):
     assert np.allclose(w, w_ref, rtol=1e-13, atol=1e-14)
 
 
+@pytest.mark.parametrize("dims,acts", [([10, 20, 20, 2], [0, 0, 0]), ([6, 40, 8], [1, 0]), ([4, 50, 1], [2, 0])])
+def test_predict_new_inputs(gpu_ctx, dims, acts):
+    table, n, w_swa, p, x, y = _random_problem(dims, acts, 64, 3, seed=21)
+    gpu_ctx.infer_setup(table, n, 3, w_swa, p, x, y, sigma_m=1.0)
+    z = np.asfortranarray(np.random.default_rng(4).standard_normal((3, 4)))
+    lp_before = gpu_ctx.logdensity(z)
+    xnew = np.asfortranarray(np.random.default_rng(5).standard_normal((dims[0], 301)))
+    yh = gpu_ctx.predict(z, xnew)
+    assert yh.shape == (dims[-1], 301, 4)
+    for c in range(4):
+        ref = so.forward(table, so.reconstruct(w_swa, p, z[:, c]), xnew)
+        assert np.allclose(yh[:, :, c], ref, rtol=1e-10, atol=1e-12)
+    assert np.array_equal(gpu_ctx.logdensity(z), lp_before)  # the density's own data is untouched
+
+
+@pytest.mark.parametrize("dims,acts,b,m", [
+    ([10, 20, 20, 2], [0, 0, 0], 100, 3),                 # README toy
+    ([2, 200, 50, 50, 50, 1], [1, 1, 1, 1, 0], 333, 5),   # docs/src/nn_example.md MLP (relu)
+    ([5, 130, 65, 3], [3, 2, 0], 257, 4),                 # sigmoid / tanh, ragged everywhere
+    ([3, 100, 97, 2], [1, 2, 3], 130, 4),                 # odd widths (scalar staging), activated head
+    ([10, 5], [2], 77, 2),                                # single layer
+    ([128, 960, 960, 1], [1, 1, 0], 3000, 20),            # cfg2 model, reduced batch
+])
+def test_logdensity_gradient(gpu_ctx, dims, acts, b, m):
+    table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=sum(dims) + b + 1)
+    gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=0.9)
+    z = np.random.default_rng(6).standard_normal(m)
+    lp, g = gpu_ctx.logdensity_grad(z)
+    lp_ref, g_ref, _ = so.logdensity_grad(table, w_swa, p, x, y, 0.9, z)
+    assert np.isclose(lp, lp_ref, rtol=1e-11)
+    assert np.allclose(g, g_ref, rtol=1e-8, atol=1e-9 * np.abs(g_ref).max())
+    assert np.isclose(gpu_ctx.logdensity(z)[0], lp, rtol=1e-12)   # fused-tail density == unfused forward of the sweep
+    lp2, g2 = gpu_ctx.logdensity_grad(z)
+    assert lp2 == lp and np.array_equal(g, g2)                    # fixed-order reductions: same bits
+
+
 def test_golden_density_and_chain(gpu_ctx):
     d = np.load(os.path.join(GOLD, "toy_density_rwmh.npz"))
     gpu_ctx.infer_setup(TOY_TABLE, TOY_N, 3, d["W_swa"], d["P"], d["X"], d["Y"], sigma_m=1.0)

@@ -86,6 +86,23 @@ def test_forward_hand_computed():
     assert math.isclose(lp, -(3 * math.log(2 * math.pi)) / 2 - float((exp ** 2).sum()) / 2, rel_tol=1e-14)
 
 
+def test_gradient_against_finite_differences():
+    rng = np.random.default_rng(5)
+    for dims, acts in (([4, 9, 3], [so.ACT_TANH, so.ACT_IDENTITY]), ([3, 8, 6, 1], [so.ACT_SIGMOID, so.ACT_TANH, so.ACT_SIGMOID])):
+        table, n = so.layer_table(dims, acts)
+        w_swa, p = 0.4 * rng.standard_normal(n), 0.3 * rng.standard_normal((n, 4))
+        x, y = rng.standard_normal((dims[0], 17)), rng.standard_normal((dims[-1], 17))
+        z = rng.standard_normal(4)
+        lp, gz, gw = so.logdensity_grad(table, w_swa, p, x, y, 0.8, z)
+        assert math.isclose(lp, so.logdensity(table, w_swa, p, x, y, 0.8, z), rel_tol=1e-14)
+        for m in range(4):
+            e = np.zeros(4)
+            e[m] = 1e-6
+            fd = (so.logdensity(table, w_swa, p, x, y, 0.8, z + e) - so.logdensity(table, w_swa, p, x, y, 0.8, z - e)) / 2e-6
+            assert math.isclose(gz[m], fd, rel_tol=1e-6, abs_tol=1e-7)
+        assert np.allclose(gz, p.T @ gw)
+
+
 def test_rwmh_gaussian_target():
     # stationary moments of N(0,1) in 2-D; `itr` samples include the initial draw
     dens = lambda z: -0.5 * float(z @ z)
