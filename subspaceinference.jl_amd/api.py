@@ -13,7 +13,7 @@ Python identifiers may be Greek, so `σ_z=` works as in Julia; `sigma_z=` is acc
 """
 import numpy as np
 
-from . import flux
+from . import flux, samplers
 from ._capi import Context, SubspaceError
 
 _RWMH_ALGS = ("rwmh", "mh")
@@ -76,9 +76,9 @@ def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=10
     σ_z = σ_z if sigma_z is None else sigma_z
     σ_m = σ_m if sigma_m is None else sigma_m
     a = _alg_name(alg)
-    if a in ("mala", "hmc", "nuts", "advi"):
-        raise SubspaceError("%s needs the gradient of the log-density (SURVEY 8(f2), not built yet)" % a)
-    if a not in _RWMH_ALGS:
+    if a in ("nuts", "advi"):
+        raise SubspaceError("%s is outside what this build accelerates (SURVEY section 2 / 8f)" % a)
+    if a not in _RWMH_ALGS and a not in ("mala", "hmc"):
         raise SubspaceError("%s is not available" % a)  # reference :162
     if not isinstance(in_model, flux.Chain):
         raise SubspaceError("Error: density function is not avaliable for this model")  # [sic] reference :103
@@ -95,8 +95,15 @@ def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=10
                 # reference: MvNormal(zeros(M), σ_z) proposal against an N x size(P,2) matrix -> DimensionMismatch in P*z
                 raise SubspaceError("DimensionMismatch: P has %d columns but M = %d" % (P.shape[1], M))
             ctx.infer_setup(table, n_par, M, W_swa, P, x, y, σ_m)
-        z, lp, _ = ctx.sample_rwmh(itr, σ_z, seed, chain_id, 1)
-        z, lp = z[:, :, 0], lp[:, 0]
+        if a in _RWMH_ALGS:
+            z, lp, _ = ctx.sample_rwmh(itr, σ_z, seed, chain_id, 1)
+            z, lp = z[:, :, 0], lp[:, 0]
+        else:
+            # :mala (:117-120) / :hmc (:139-160): the sampler logic is host control flow, every density + gradient
+            # evaluation is the device reverse sweep (si_logdensity_grad) instead of M-wide ForwardDiff duals (:107)
+            rng = np.random.default_rng([int(seed), int(chain_id)])
+            fn = samplers.mala if a == "mala" else samplers.hmc
+            z, lp, _ = fn(ctx.logdensity_grad, M, itr, σ_z, rng)
         if return_z:
             return z, lp
         w = ctx.reconstruct(z)  # :125  map(z -> W_swa + P*z.params, chm)

@@ -111,3 +111,16 @@ def test_api_error_behaviour(si):
     with pytest.raises(si.SubspaceError, match="not avaliable"):
         si.sub_inference(object(), data, w, p, M=1)                               # space_inference.jl:103
     assert si.inference.__doc__ and "sub_inference" in si.inference.__doc__
+
+
+def test_gradient_samplers_on_gaussian_target():
+    """Host sampler logic (MALA / one-step HMC with dual averaging) on N(mu, I): stationary moments."""
+    from subspaceinference_jl_amd import samplers
+    mu = np.array([0.5, -1.0, 2.0])
+    fn = lambda z: (-0.5 * float((z - mu) @ (z - mu)), -(z - mu))
+    for sampler, s in ((samplers.mala, 0.9), (samplers.hmc, 1.0)):
+        z, lp, acc = sampler(fn, 3, 6000, s, np.random.default_rng(1))
+        burn = z[:, 1000:]
+        assert np.all(np.abs(burn.mean(axis=1) - mu) < 0.2), sampler.__name__
+        assert np.all(np.abs(burn.var(axis=1) - 1.0) < 0.3), sampler.__name__
+        assert 0.3 < acc <= 1.0
