@@ -155,6 +155,21 @@ int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, 
 /* :91 / :125  W_out[:, c] = W_swa + P * Z[:, c]   (N x C col-major)                                  */
 int32_t si_reconstruct(si_ctx* ctx, const double* Z /* M x C */, int64_t C, double* W_out);
 
+/* ---- on-device training step for Dense chains with the mse cost ----------------------------------
+ * Replaces the caller-side body of the reference's loop, src/subspace_construction.jl:39-43
+ *     gs = gradient(ps) do training_loss = cost(model, d...) end;  Flux.update!(opt, ps, gs)
+ * for cost = mse(m(x), y) and opt in {Descent (0), Momentum (1), ADAM (2)} with Flux 0.11.2 semantics (Float32 weights
+ * and optimiser state, Float64 arithmetic).  p1 = rho / beta1, p2 = beta2.  The whole (X, Y) is uploaded once; a step
+ * takes the observation indices of its batch (the DataLoader's permutation stays with the caller).                  */
+int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, const float* w0 /* N */,
+                       const double* X, const double* Y, int32_t in_dim, int32_t out_dim, int64_t B_total,
+                       int64_t batch_max, int32_t opt_kind, double eta, double p1, double p2);
+int32_t si_train_step(si_ctx* ctx, const int64_t* idx /* nb observation indices, 0-based */, int64_t nb,
+                      double* loss_out /* mse of the batch before the update; may be NULL (no host sync) */);
+/* :45-52 with W taken in place from the device-resident Float32 weights (no extract_params, no PCIe) */
+int32_t si_train_push(si_ctx* ctx, double n);
+int32_t si_train_get_weights(si_ctx* ctx, float* w_out /* N */);
+
 /* ---- host utility (no GPU needed): the K x K symmetric eigensolver used inside si_construct_finish.
  * a: n x n symmetric column-major, overwritten by the eigenvectors (columns); w: eigenvalues ascending. */
 int si_host_sym_eig(int n, double* a, double* w);

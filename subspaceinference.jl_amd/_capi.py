@@ -73,6 +73,11 @@ SIGNATURES = {
     "si_sample_rwmh": (c_int32, [c_void_p, c_int64, c_double, c_uint64, c_int32, c_int32, c_void_p, c_void_p,
                                  c_void_p]),
     "si_reconstruct": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "si_train_setup": (c_int32, [c_void_p, POINTER(SiLayer), c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_int32,
+                                 c_int32, c_int64, c_int64, c_int32, c_double, c_double, c_double]),
+    "si_train_step": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "si_train_push": (c_int32, [c_void_p, c_double]),
+    "si_train_get_weights": (c_int32, [c_void_p, c_void_p]),
     "si_host_sym_eig": (c_int, [c_int, c_void_p, c_void_p]),
 }
 
@@ -225,6 +230,34 @@ class Context:
         a = np.empty((self._n, int(nk)), dtype=np.float64, order="F")
         self._check(self.lib.si_construct_get_A(self.h, int(k0), int(nk), _ptr(a)))
         return a
+
+    # -- on-device training (f1)
+    def train_setup(self, table, n, w0, x, y, batch_max, opt_kind, eta, p1=0.0, p2=0.0):
+        arr = (SiLayer * len(table))()
+        for i, (fin, fout, act, w_off, b_off) in enumerate(table):
+            arr[i] = SiLayer(0, int(fin), int(fout), int(act), int(w_off), int(b_off))
+        x, y = _f64(x), _f64(y)
+        w0 = np.ascontiguousarray(w0, dtype=np.float32)
+        if w0.size != n or x.ndim != 2 or y.ndim != 2 or x.shape[1] != y.shape[1]:
+            raise SubspaceError("DimensionMismatch: w0 %s, X %s, Y %s" % (w0.shape, x.shape, y.shape))
+        self._check(self.lib.si_train_setup(self.h, arr, len(table), int(n), _ptr(w0), _ptr(x), _ptr(y), x.shape[0],
+                                            y.shape[0], x.shape[1], int(batch_max), int(opt_kind), float(eta), float(p1),
+                                            float(p2)))
+        self._tn = int(n)
+
+    def train_step(self, idx, want_loss=True):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        loss = np.empty(1, dtype=np.float64) if want_loss else None
+        self._check(self.lib.si_train_step(self.h, _ptr(idx), idx.size, _ptr(loss)))
+        return float(loss[0]) if want_loss else None
+
+    def train_push(self, n):
+        self._check(self.lib.si_train_push(self.h, float(n)))
+
+    def train_get_weights(self):
+        w = np.empty(self._tn, dtype=np.float32)
+        self._check(self.lib.si_train_get_weights(self.h, _ptr(w)))
+        return w
 
     # -- density + sampling
     def infer_setup(self, table, n, m, w_swa, p, x, y, sigma_m):

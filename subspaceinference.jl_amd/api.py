@@ -28,13 +28,18 @@ def _alg_name(alg):
 
 
 def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, *, device=0, ctx=None,
-                          max_cols=0, verbose=True, keep_on_device=False):
+                          max_cols=0, verbose=True, keep_on_device=False, device_training="auto"):
     """src/subspace_construction.jl:26-67.
 
     Per batch the host does `gradient` + `update!` (:39-43, caller side) and hands the flattened weights
     (`extract_params`, src/libs.jl:19-22, Float32) plus `n = i/c` to the device, which applies the SWA update,
     forms the deviation column and appends it (:45-52, kernel K1).  After the loop the device forms A'A
     (K2), the host solves the K x K eigenproblem (H1) and the device projects P = A*V_M (K3) == :61-65.
+
+    device_training ("auto" | True | False): when the cost is `flux.mse` and the optimiser is a fresh Descent /
+    Momentum / ADAM, the training step itself (:39-43) also runs on the GPU (si_train_step: forward, reverse sweep,
+    optimiser) and the weights are pushed in place (si_train_push) -- no weight vector crosses PCIe.  The model's
+    arrays receive the trained weights at the end, like Flux's in-place `update!`.
     """
     ps = flux.params(model)
     n_par = int(sum(p.size for p in ps))
@@ -43,19 +48,39 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
     if n_push == 0:
         # reference: reshape of an empty A, then psvd / U[:,1:M] fails
         raise SubspaceError("BoundsError: no snapshot was collected (mod(i,c) never 0 for i in 1:T)")
+    dev_opt = flux.device_optimiser(opt) if isinstance(cost, flux.MSE) and hasattr(data, "index_batches") else None
+    if device_training is True and dev_opt is None:
+        raise SubspaceError("device_training needs cost = flux.mse and a fresh Descent / Momentum / ADAM optimiser")
+    use_dev = dev_opt is not None and device_training in ("auto", True)
     ctx, own = _get_ctx(ctx, device)
     try:
         ctx.construct_begin(n_par, n_push, max_cols)
         training_loss = 0.0
+        if use_dev:
+            table, _ = flux.layer_table(model)
+            bmax = min(data.batchsize, data.nobs)
+            ctx.train_setup(table, n_par, flux.extract_params(ps), data.data[0], data.data[1], bmax, *dev_opt)
         for i in range(1, T + 1):
-            for d in data:
-                training_loss, gs = flux.gradient(cost, model, *d)
-                flux.update(opt, ps, gs)
-                if i % c == 0:
-                    ctx.construct_push(flux.extract_params(ps), i / c)
+            if use_dev:
+                last = (i % print_freq == 0) or (i == T)
+                batches = list(data.index_batches())
+                for j, ids in enumerate(batches):
+                    loss = ctx.train_step(ids, want_loss=last and j == len(batches) - 1)
+                    if loss is not None:
+                        training_loss = loss
+                    if i % c == 0:
+                        ctx.train_push(i / c)
+            else:
+                for d in data:
+                    training_loss, gs = flux.gradient(cost, model, *d)
+                    flux.update(opt, ps, gs)
+                    if i % c == 0:
+                        ctx.construct_push(flux.extract_params(ps), i / c)
             if (i % print_freq == 0) or (i == T):
                 if verbose:
                     print("Traing loss: ", training_loss, " Epoch: ", i)  # [sic] reference :57
+        if use_dev:
+            flux.load_flat(model, ctx.train_get_weights())
         w_swa, p, _, _ = ctx.construct_finish(M, want_swa=True, want_p=not keep_on_device)
         return w_swa, p
     finally:

@@ -16,6 +16,7 @@ ARCH = "gfx950"
 # three rounded operations.
 SOURCES = [
     ("capi.hip", []),
+    ("capi_train.hip", []),
     ("kernels_stream.hip", ["-ffp-contract=off"]),
     ("kernels_gemm.hip", []),
     ("kernels_gram.hip", []),

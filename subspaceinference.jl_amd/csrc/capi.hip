@@ -182,6 +182,7 @@ int32_t si_destroy(si_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   resolve_events(ctx);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  free_train(ctx);
   free_construct(ctx);
   free_infer(ctx);
   dev_free(ctx->d_wstage);

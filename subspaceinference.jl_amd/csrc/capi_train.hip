@@ -1,0 +1,226 @@
+// On-device training step for Dense chains with the mse cost.  Replaces the caller-side body of the
+// reference's loop, src/subspace_construction.jl:39-43
+//     gs = gradient(ps) do training_loss = cost(model, d...) end ;  Flux.update!(opt, ps, gs)
+// for `cost = (m, x, y) -> Flux.Losses.mse(m(x), y)` and opt in {Descent, Momentum, ADAM} (Flux 0.11.2 semantics:
+// Float32 parameters and Float32 optimiser state, Float64 arithmetic because the data are Float64).  The weights never
+// leave the GPU: si_train_push feeds K1 from the device-resident Float32 vector.
+#include <algorithm>
+#include <cmath>
+
+#include "si_internal.h"
+
+namespace si {
+
+__global__ __launch_bounds__(256) void gather_cols_kernel(const double* __restrict__ src, int rows, const int64_t* __restrict__ idx,
+                                                          int64_t nb, double* __restrict__ dst) {
+  const int64_t total = (int64_t)rows * nb;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t j = e / rows;
+    const int r = (int)(e - j * rows);
+    dst[e] = src[r + (int64_t)rows * idx[j]];
+  }
+}
+
+__global__ __launch_bounds__(256) void widen_kernel(const float* __restrict__ w32, int64_t n, double* __restrict__ w64) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) w64[i] = (double)w32[i];
+}
+
+// Flux 0.11.2 apply! + update!:  x .-= apply!(opt, x, g), state zero(x) (Float32), arithmetic in Float64
+__global__ __launch_bounds__(256) void optimiser_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                        const double* __restrict__ g, int64_t n, int kind, double eta,
+                                                        double p1, double p2, double bp1, double bp2) {
+#pragma clang fp contract(off)
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double gi = g[i];
+    double step;
+    if (kind == 0) {  // Descent: delta .*= eta
+      step = gi * eta;
+    } else if (kind == 1) {  // Momentum: v = rho*v - eta*delta; delta = -v
+      const float vn = (float)(p1 * (double)m[i] - eta * gi);
+      m[i] = vn;
+      step = -(double)vn;
+    } else {  // ADAM
+      const float mt = (float)(p1 * (double)m[i] + (1.0 - p1) * gi);
+      const float vt = (float)(p2 * (double)v[i] + (1.0 - p2) * (gi * gi));
+      m[i] = mt;
+      v[i] = vt;
+      step = (double)mt / (1.0 - bp1) / (sqrt((double)vt / (1.0 - bp2)) + 1e-8) * eta;
+    }
+    w[i] = (float)((double)w[i] - step);
+  }
+}
+
+static int grid_for(int64_t n, int num_cu) {
+  int64_t b = (n + 255) / 256;
+  if (b > (int64_t)num_cu * 8) b = (int64_t)num_cu * 8;
+  return (int)(b < 1 ? 1 : b);
+}
+
+template <typename T>
+static bool alloc(T** p, size_t count) {
+  *p = nullptr;
+  return hipMalloc(reinterpret_cast<void**>(p), (count ? count : 1) * sizeof(T)) == hipSuccess;
+}
+template <typename T>
+static void release(T*& p) {
+  if (p) (void)hipFree((void*)p);
+  p = nullptr;
+}
+
+void free_train(Ctx* c) {
+  TrainState* t = c->train;
+  if (!t) return;
+  release(t->X); release(t->Y); release(t->Xb); release(t->Yb); release(t->idx); release(t->w32); release(t->m32);
+  release(t->v32); release(t->w64); release(t->gw); release(t->delta[0]); release(t->delta[1]); release(t->bwpart);
+  release(t->rspart); release(t->ssepart); release(t->sse);
+  for (auto& h : t->hs) release(h);
+  delete t;
+  c->train = nullptr;
+}
+
+}  // namespace si
+
+using namespace si;
+
+extern "C" {
+
+int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, const float* w0, const double* X,
+                       const double* Y, int32_t in_dim, int32_t out_dim, int64_t B_total, int64_t batch_max,
+                       int32_t opt_kind, double eta, double p1, double p2) {
+  if (!ctx) return SI_ERR_INVALID;
+  if (!layers || L <= 0 || N <= 0 || !w0 || !X || !Y || in_dim <= 0 || out_dim <= 0 || B_total <= 0 || batch_max <= 0 ||
+      batch_max > B_total || opt_kind < 0 || opt_kind > 2)
+    return fail(ctx, SI_ERR_INVALID, "si_train_setup: bad argument");
+  int32_t width = in_dim;
+  int64_t maxw = 1;
+  size_t maxpart = 1;
+  for (int l = 0; l < L; ++l) {
+    const si_layer& ly = layers[l];
+    if (ly.kind != SI_LAYER_DENSE || ly.in != width || ly.out <= 0 || ly.act < 0 || ly.act > SI_ACT_SIGMOID ||
+        ly.w_off < 0 || ly.b_off < 0 || ly.w_off + (int64_t)ly.in * ly.out > N || ly.b_off + ly.out > N)
+      return fail(ctx, SI_ERR_INVALID, "Error: model_re function is not available for this model (Dense chain expected)");
+    width = ly.out;
+    maxw = std::max<int64_t>(maxw, ly.out);
+    int64_t ks;
+    const int ns = backward_weight_splits(ly.out, ly.in, batch_max, ctx->num_cu, &ks);
+    maxpart = std::max(maxpart, (size_t)ns * ly.out * ly.in);
+  }
+  if (width != out_dim) return fail(ctx, SI_ERR_INVALID, "si_train_setup: last layer width != out_dim");
+  SI_HIP(ctx, hipSetDevice(ctx->device));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  free_train(ctx);
+  TrainState* t = new TrainState();
+  ctx->train = t;
+  t->layers.assign(layers, layers + L);
+  t->N = N; t->Btot = B_total; t->Bmax = batch_max; t->in_dim = in_dim; t->out_dim = out_dim;
+  t->opt = opt_kind; t->eta = eta; t->p1 = p1; t->p2 = p2; t->bp1 = p1; t->bp2 = p2;  // ADAM: beta powers start at beta
+  t->sse_blocks = sse_num_blocks((int64_t)out_dim * batch_max, ctx->num_cu);
+  t->hs.assign((size_t)L, nullptr);
+  bool ok = alloc(&t->X, (size_t)in_dim * B_total) && alloc(&t->Y, (size_t)out_dim * B_total) &&
+            alloc(&t->Xb, (size_t)in_dim * batch_max) && alloc(&t->Yb, (size_t)out_dim * batch_max) &&
+            alloc(&t->idx, (size_t)batch_max) && alloc(&t->w32, (size_t)N) && alloc(&t->m32, (size_t)N) &&
+            alloc(&t->v32, (size_t)N) && alloc(&t->w64, (size_t)pad_ld(N)) && alloc(&t->gw, (size_t)pad_ld(N)) &&
+            alloc(&t->delta[0], (size_t)maxw * batch_max) && alloc(&t->delta[1], (size_t)maxw * batch_max) &&
+            alloc(&t->bwpart, maxpart) && alloc(&t->rspart, (size_t)rowsum_chunks() * maxw) &&
+            alloc(&t->ssepart, (size_t)t->sse_blocks) && alloc(&t->sse, 1);
+  for (int l = 0; l < L && ok; ++l) ok = alloc(&t->hs[(size_t)l], (size_t)layers[l].out * batch_max);
+  if (!ok) {
+    free_train(ctx);
+    return fail(ctx, SI_ERR_NOMEM, "si_train_setup: device allocation failed");
+  }
+  SI_HIP(ctx, hipMemcpyAsync(t->X, X, (size_t)in_dim * B_total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  SI_HIP(ctx, hipMemcpyAsync(t->Y, Y, (size_t)out_dim * B_total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  SI_HIP(ctx, hipMemcpyAsync(t->w32, w0, (size_t)N * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  SI_HIP(ctx, hipMemsetAsync(t->m32, 0, (size_t)N * sizeof(float), ctx->stream));
+  SI_HIP(ctx, hipMemsetAsync(t->v32, 0, (size_t)N * sizeof(float), ctx->stream));
+  SI_HIP(ctx, hipMemsetAsync(t->w64, 0, (size_t)pad_ld(N) * sizeof(double), ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+int32_t si_train_step(si_ctx* ctx, const int64_t* idx, int64_t nb, double* loss_out) {
+  if (!ctx) return SI_ERR_INVALID;
+  TrainState* t = ctx->train;
+  if (!t) return fail(ctx, SI_ERR_STATE, "si_train_step: call si_train_setup first");
+  if (!idx || nb <= 0 || nb > t->Bmax) return fail(ctx, SI_ERR_INVALID, "si_train_step: bad batch");
+  for (int64_t j = 0; j < nb; ++j)
+    if (idx[j] < 0 || idx[j] >= t->Btot) return fail(ctx, SI_ERR_INVALID, "si_train_step: BoundsError: batch index out of range");
+  SI_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int64_t N = t->N;
+  const size_t nl = t->layers.size();
+  SI_HIP(ctx, hipMemcpyAsync(t->idx, idx, (size_t)nb * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  SI_HIP(ctx, hipStreamSynchronize(st));  // idx is caller-owned
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(grid_for((int64_t)t->in_dim * nb, ctx->num_cu)), dim3(256), 0, st, t->X,
+                     t->in_dim, t->idx, nb, t->Xb);
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(grid_for((int64_t)t->out_dim * nb, ctx->num_cu)), dim3(256), 0, st, t->Y,
+                     t->out_dim, t->idx, nb, t->Yb);
+  hipLaunchKernelGGL(widen_kernel, dim3(grid_for(N, ctx->num_cu)), dim3(256), 0, st, t->w32, N, t->w64);
+  const double* h = t->Xb;
+  for (size_t l = 0; l < nl; ++l) {
+    const si_layer& ly = t->layers[l];
+    ProfScope ps(ctx, SI_K_DENSE, 2.0 * (double)ly.in * ly.out * (double)nb, 0.0);
+    launch_dense_f64(st, t->w64 + ly.w_off, t->w64 + ly.b_off, h, t->hs[l], ly.out, ly.in, nb, ly.act);
+    h = t->hs[l];
+  }
+  const int64_t d = (int64_t)t->out_dim * nb;
+  launch_sse(st, h, t->Yb, d, t->ssepart, sse_num_blocks(d, ctx->num_cu), t->sse);
+  {
+    double bflops = 0.0;
+    for (const auto& ly : t->layers) bflops += 4.0 * (double)ly.in * ly.out * (double)nb;
+    ProfScope ps(ctx, SI_K_BACKWARD, bflops, 0.0);
+    SI_HIP(ctx, hipMemsetAsync(t->gw, 0, (size_t)pad_ld(N) * sizeof(double), st));
+    int cur = 0;
+    // d mse / d yhat = 2 (yhat - y) / d
+    launch_delta_out(st, t->Yb, h, d, -2.0 / (double)d, t->layers[nl - 1].act, t->delta[cur]);
+    for (size_t li = nl; li-- > 0;) {
+      const si_layer& ly = t->layers[li];
+      const double* hprev = li > 0 ? t->hs[li - 1] : t->Xb;
+      launch_rowsum(st, t->delta[cur], ly.out, nb, t->rspart, t->gw + ly.b_off);
+      int64_t ks;
+      const int ns = backward_weight_splits(ly.out, ly.in, nb, ctx->num_cu, &ks);
+      launch_backward_weight(st, t->delta[cur], hprev, t->bwpart, ly.out, ly.in, nb, ns, ks);
+      launch_split_reduce(st, t->bwpart, ns, (int64_t)ly.out * ly.in, t->gw + ly.w_off);
+      if (li > 0) {
+        launch_backward_data(st, t->w64 + ly.w_off, t->delta[cur], hprev, t->delta[cur ^ 1], ly.out, ly.in, nb,
+                             t->layers[li - 1].act);
+        cur ^= 1;
+      }
+    }
+    hipLaunchKernelGGL(optimiser_kernel, dim3(grid_for(N, ctx->num_cu)), dim3(256), 0, st, t->w32, t->m32, t->v32, t->gw,
+                       N, t->opt, t->eta, t->p1, t->p2, t->bp1, t->bp2);
+  }
+  SI_HIP(ctx, hipGetLastError());
+  if (t->opt == 2) {
+    t->bp1 *= t->p1;
+    t->bp2 *= t->p2;
+  }
+  if (loss_out) {
+    double sse = 0.0;
+    SI_HIP(ctx, hipMemcpyAsync(&sse, t->sse, sizeof(double), hipMemcpyDeviceToHost, st));
+    SI_HIP(ctx, hipStreamSynchronize(st));
+    *loss_out = sse / (double)d;  // mse of the batch BEFORE the update, as Zygote's forward value
+  }
+  return SI_OK;
+}
+
+int32_t si_train_push(si_ctx* ctx, double n) {
+  if (!ctx) return SI_ERR_INVALID;
+  if (!ctx->train) return fail(ctx, SI_ERR_STATE, "si_train_push: call si_train_setup first");
+  if (ctx->train->N != ctx->N) return fail(ctx, SI_ERR_INVALID, "si_train_push: construction and training sizes differ");
+  return si_construct_push_dev(ctx, ctx->train->w32, SI_F32, n);
+}
+
+int32_t si_train_get_weights(si_ctx* ctx, float* w_out) {
+  if (!ctx) return SI_ERR_INVALID;
+  if (!ctx->train || !w_out) return fail(ctx, SI_ERR_STATE, "si_train_get_weights: no training state / NULL output");
+  SI_HIP(ctx, hipSetDevice(ctx->device));
+  SI_HIP(ctx, hipMemcpyAsync(w_out, ctx->train->w32, (size_t)ctx->train->N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+}  // extern "C"

@@ -21,8 +21,26 @@ struct EventPair {
   int cls;
 };
 
+// on-device training (capi_train.hip)
+struct TrainState {
+  std::vector<si_layer> layers;
+  int64_t N = 0, Btot = 0, Bmax = 0;
+  int32_t in_dim = 0, out_dim = 0;
+  double *X = nullptr, *Y = nullptr, *Xb = nullptr, *Yb = nullptr;
+  int64_t* idx = nullptr;
+  float *w32 = nullptr, *m32 = nullptr, *v32 = nullptr;
+  double *w64 = nullptr, *gw = nullptr;
+  std::vector<double*> hs;
+  double* delta[2] = {nullptr, nullptr};
+  double *bwpart = nullptr, *rspart = nullptr, *ssepart = nullptr, *sse = nullptr;
+  int sse_blocks = 0;
+  int opt = 0;
+  double eta = 0.0, p1 = 0.0, p2 = 0.0, bp1 = 0.0, bp2 = 0.0;
+};
+
 struct Ctx {
   int device = -1;
+  TrainState* train = nullptr;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::string err;
@@ -97,6 +115,8 @@ struct Ctx {
   int64_t* d_nacc = nullptr;  // C
   int32_t chains_cap = 0;
 };
+
+void free_train(Ctx* c);
 
 // error helpers -------------------------------------------------------------------------------
 int32_t fail(Ctx* c, int32_t code, const std::string& msg);

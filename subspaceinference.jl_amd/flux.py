@@ -120,11 +120,15 @@ class DataLoader:
         n = self.nobs / self.batchsize
         return int(np.ceil(n)) if self.partial else int(np.floor(n))
 
-    def __iter__(self):
+    def index_batches(self):
+        """The observation indices of every batch of one epoch (one permutation per epoch when shuffle=true)."""
         idx = self.rng.permutation(self.nobs) if self.shuffle else np.arange(self.nobs)
         imax = self.nobs if self.partial else self.nobs - self.batchsize + 1
         for i in range(0, imax, self.batchsize):
-            ids = idx[i:i + self.batchsize]
+            yield idx[i:i + self.batchsize]
+
+    def __iter__(self):
+        for ids in self.index_batches():
             yield tuple(d[..., ids] for d in self.data)
 
 
@@ -177,9 +181,9 @@ class Momentum:
         self.eta, self.rho, self.v = eta, rho, {}
 
     def apply(self, x, g):
-        v = self.v.setdefault(id(x), np.zeros_like(g))
-        v[...] = self.rho * v - self.eta * g
-        return -v
+        v = self.v.setdefault(id(x), np.zeros_like(x))  # zero(x): Float32 state, Float64 arithmetic (Flux 0.11.2)
+        v[...] = self.rho * v.astype(np.float64) - self.eta * g  # Float64 arithmetic (ρ::Float64), stored as Float32
+        return -v.astype(np.float64)
 
 
 class ADAM:
@@ -187,18 +191,30 @@ class ADAM:
         self.eta, self.beta, self.state = eta, beta, {}
 
     def apply(self, x, g):
-        st = self.state.setdefault(id(x), [np.zeros_like(g), np.zeros_like(g), list(self.beta)])
+        st = self.state.setdefault(id(x), [np.zeros_like(x), np.zeros_like(x), list(self.beta)])  # (zero(x), zero(x), β)
         mt, vt, bp = st
         b1, b2 = self.beta
-        mt[...] = b1 * mt + (1 - b1) * g
-        vt[...] = b2 * vt + (1 - b2) * g * g
-        d = mt / (1 - bp[0]) / (np.sqrt(vt / (1 - bp[1])) + 1e-8) * self.eta
+        mt[...] = b1 * mt.astype(np.float64) + (1 - b1) * g
+        vt[...] = b2 * vt.astype(np.float64) + (1 - b2) * g * g
+        d = mt.astype(np.float64) / (1 - bp[0]) / (np.sqrt(vt.astype(np.float64) / (1 - bp[1])) + 1e-8) * self.eta
         bp[0] *= b1
         bp[1] *= b2
         return d
 
 
+def device_optimiser(opt):
+    """(kind, eta, p1, p2) for si_train_setup, or None when the optimiser cannot run on the device (unknown type, or
+    it already carries state from earlier host steps)."""
+    if isinstance(opt, Descent):
+        return 0, opt.eta, 0.0, 0.0
+    if isinstance(opt, Momentum) and not opt.v:
+        return 1, opt.eta, opt.rho, 0.0
+    if isinstance(opt, ADAM) and not opt.state:
+        return 2, opt.eta, opt.beta[0], opt.beta[1]
+    return None
+
+
 def update(opt, ps, gs):
-    """Flux.update!(opt, ps, gs): in place, result rounded to the parameter's own dtype (Float32)."""
+    """Flux.update!(opt, ps, gs): `x .-= apply!(opt, x, g)` -- Float32 x minus Float64 step, rounded once to Float32."""
     for p, g in zip(ps, gs):
-        p -= opt.apply(p, g).astype(p.dtype)
+        p[...] = (p.astype(np.float64) - opt.apply(p, np.asarray(g, dtype=np.float64))).astype(p.dtype)

@@ -410,3 +410,49 @@ def test_api_mala_and_hmc(si, gpu_ctx):
         assert len(chn) == 20 and chn[0].shape == (w_swa.size,) and np.all(np.isfinite(lp))
     with pytest.raises(si.SubspaceError):
         si.sub_inference(m, data, w_swa, p, M=3, alg=":nuts", ctx=gpu_ctx)
+
+
+# ----------------------------------------------------------------------------------------------- on-device training (f1)
+@pytest.mark.parametrize("optname", ["descent", "momentum", "adam"])
+def test_device_training_matches_host_step(si, gpu_ctx, optname):
+    """si_train_step vs the host stand-in of `gradient` + `Flux.update!` (flux.py) on the same batches."""
+    from subspaceinference_jl_amd import flux
+    mk = {"descent": lambda: flux.Descent(0.05), "momentum": lambda: flux.Momentum(0.01, 0.9),
+          "adam": lambda: flux.ADAM(0.01)}[optname]
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal((7, 96)), rng.standard_normal((2, 96))
+    def model():
+        wr = np.random.default_rng(5)
+        return flux.Chain(flux.Dense(7, 33, flux.tanh, rng=wr), flux.Dense(33, 18, flux.relu, rng=wr), flux.Dense(18, 2, rng=wr))
+    mh, md = model(), model()
+    opt_h = mk()
+    table, n = flux.layer_table(md)
+    gpu_ctx.train_setup(table, n, flux.extract_params(flux.params(md)), x, y, 32, *flux.device_optimiser(mk()))
+    batches = [np.arange(0, 32), np.arange(32, 64), np.arange(64, 96), np.array([5, 1, 77, 30, 2])] * 3
+    for ids in batches:
+        loss_h, gs = flux.mse.value_and_grad(mh, x[:, ids], y[:, ids])
+        flux.update(opt_h, flux.params(mh), gs)
+        loss_d = gpu_ctx.train_step(ids)
+        assert np.isclose(loss_d, loss_h, rtol=1e-5)
+    wd, wh = gpu_ctx.train_get_weights(), flux.extract_params(flux.params(mh))
+    assert wd.dtype == np.float32 and np.allclose(wd, wh, rtol=2e-4, atol=2e-6)
+
+
+def test_construction_with_device_training(si, gpu_ctx):
+    """README-toy flow with the training loop on the GPU: same W_swa / P as the host-stepped run (fp32 weights)."""
+    from subspaceinference_jl_amd import flux
+    rng = np.random.default_rng(0)
+    x, y = rng.random((10, 100)), rng.random((2, 100))
+    outs = []
+    for dev in (True, False):
+        wr = np.random.default_rng(2)
+        m = flux.Chain(flux.Dense(10, 20, flux.tanh, rng=wr), flux.Dense(20, 20, flux.relu, rng=wr), flux.Dense(20, 2, rng=wr))
+        data = flux.DataLoader(x, y, batchsize=25, shuffle=True, rng=np.random.default_rng(7))
+        w_swa, p = si.subspace_construction(m, flux.mse, data, flux.ADAM(0.01), T=4, c=2, M=3, ctx=gpu_ctx,
+                                            verbose=False, device_training=dev)
+        outs.append((w_swa, p, flux.extract_params(flux.params(m))))
+    (wd, pd, md), (wh, ph, mh) = outs
+    assert np.allclose(md, mh, rtol=1e-3, atol=1e-5)          # trained weights written back into the model
+    assert np.allclose(wd, wh, rtol=1e-3, atol=1e-5)
+    sign = np.sign(np.sum(pd * ph, axis=0))
+    assert np.allclose(pd * sign, ph, rtol=2e-2, atol=2e-4 * np.abs(ph).max())
