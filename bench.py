@@ -168,6 +168,27 @@ def main():
         dt = float(tt.item())
     value = world * args.steps / dt
 
+    # ---- extras (outside every timed region above): the "next" rows at the same workload
+    extras = {}
+    if rank == 0:
+        ctx.reset_stats()
+        zz = np.ascontiguousarray(z[:, 0, 0])
+        ctx.logdensity_grad(zz)  # warm-up (workspace allocation)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ctx.logdensity_grad(zz)
+        extras["logdensity_grad_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+        ctx.train_setup(table, n_par, glorot_flat(1), x, y, B, 2, 1e-3, 0.9, 0.999)  # ADAM, full batch
+        ids = np.arange(B)
+        ctx.train_step(ids)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ctx.train_step(ids, want_loss=False)
+        ctx.synchronize()
+        extras["train_step_full_batch_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+        bs = ctx.stats()["backward"]
+        extras["backward_sweep_tflops"] = bs["flops"] / max(bs["ms"], 1e-9) / 1e9
+
     if rank == 0:
         dm = st["dense_main"]
         avg_ms = dm["ms"] / max(1, dm["launches"])
@@ -194,6 +215,7 @@ def main():
                          "frac": achieved / PEAK_F64_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "flops_per_launch": fl, "launches": dm["launches"]},
             "device": ctx.device_name(),
+            "next_rows": extras,
         }
         if world == 1 and not args.no_cpu_baseline:
             # W_swa / P of the construction just timed, brought to the host only for the CPU leg (outside all timers)

@@ -115,11 +115,21 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_f64_kernel(
   double* sAbuf = smem;                           // [2][SA::LDS_ELEMS]
   double* sBbuf = smem + 2 * SA::LDS_ELEMS;       // [2][SB::LDS_ELEMS]
 
+  // nNt >= 8: XCD-grouped map of the forward kernel (the nMt row tiles of one column panel share an XCD's L2).
+  // nNt < 8 (weight gradients of narrow layers): that map would leave XCDs empty (measured: a 960x128 dW on ONE XCD,
+  // 7x slower), so the tiles are numbered plainly and the split index spreads the blocks over the XCDs.
   const int64_t bid = blockIdx.x;
-  const int xcd = (int)(bid & 7);
-  const int64_t j = bid >> 3;
-  const int mt = (int)(j % nMt);
-  const int64_t nt = (j / nMt) * 8 + xcd;
+  int mt;
+  int64_t nt;
+  if (nNt >= 8) {
+    const int xcd = (int)(bid & 7);
+    const int64_t j = bid >> 3;
+    mt = (int)(j % nMt);
+    nt = (j / nMt) * 8 + xcd;
+  } else {
+    mt = (int)(bid % nMt);
+    nt = bid / nMt;
+  }
   if (nt >= nNt) return;
   const int64_t k0 = (int64_t)blockIdx.y * ksplit;
   int64_t klen = Kdim - k0;
@@ -285,7 +295,7 @@ static void launch_gemm(hipStream_t st, const double* A, int64_t lda, const doub
   constexpr size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(double);
   const int nMt = (Mrows + BM - 1) / BM;
   const int64_t nNt = (Ncols + BN - 1) / BN;
-  const int64_t grid = (nNt + 7) / 8 * nMt * 8;
+  const int64_t grid = nNt >= 8 ? (nNt + 7) / 8 * nMt * 8 : nNt * nMt;
   // 16-B staging: pairs run along the fast index of each operand, so that extent and the leading dimensions must be
   // even and the bases 16-B aligned; the k-fast pairs also need every split to start at an even k
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
@@ -313,21 +323,33 @@ static void launch_gemm(hipStream_t st, const double* A, int64_t lda, const doub
   }
 }
 
+// row tile that pads `rows` least (same rule as the forward kernel)
+static int pick_bm_bwd(int32_t rows) {
+  if (rows <= 64) return 64;
+  auto padded = [&](int bm) { return (rows + bm - 1) / bm * bm; };
+  const int p96 = padded(96), p128 = padded(128), p64 = padded(64);
+  if (p96 <= p128 && p96 <= p64) return 96;
+  return p128 <= p64 ? 128 : 64;
+}
+
 // Delta_prev[in x B] = (W' * Delta) .* act_prev'(Hprev);  W is out x in (column-major) inside the flat vector
 void launch_backward_data(hipStream_t st, const double* W, const double* Delta, const double* Hprev, double* DeltaPrev,
                           int32_t out, int32_t in, int64_t B, int32_t act_prev) {
   // A(m = in idx, k = out idx) = W[k + out*m]: k-fast;  B(k, n = b) = Delta[k + out*n]: k-fast
-  if (in > 64)
-    launch_gemm<128, 128, 1, 1, EPI_DACT>(st, W, out, Delta, out, DeltaPrev, in, in, B, out, 1, ((int64_t)out + 15) / 16 * 16, Hprev, act_prev);
-  else
-    launch_gemm<64, 128, 1, 1, EPI_DACT>(st, W, out, Delta, out, DeltaPrev, in, in, B, out, 1, ((int64_t)out + 15) / 16 * 16, Hprev, act_prev);
+  const int64_t ks = ((int64_t)out + 15) / 16 * 16;
+  switch (pick_bm_bwd(in)) {
+    case 96: launch_gemm<96, 128, 1, 1, EPI_DACT>(st, W, out, Delta, out, DeltaPrev, in, in, B, out, 1, ks, Hprev, act_prev); break;
+    case 128: launch_gemm<128, 128, 1, 1, EPI_DACT>(st, W, out, Delta, out, DeltaPrev, in, in, B, out, 1, ks, Hprev, act_prev); break;
+    default: launch_gemm<64, 128, 1, 1, EPI_DACT>(st, W, out, Delta, out, DeltaPrev, in, in, B, out, 1, ks, Hprev, act_prev); break;
+  }
 }
 
 // partial dW[split][out x in] = Delta[:, split's columns] * Hprev[:, split's columns]';  returns nsplit
 int backward_weight_splits(int32_t out, int32_t in, int64_t B, int num_cu, int64_t* ksplit_out) {
-  const int bm = out > 64 ? 128 : 64;
+  const int bm = pick_bm_bwd(out);
   const int64_t tiles = (int64_t)((out + bm - 1) / bm) * ((in + 127) / 128);
-  int64_t nsplit = ((int64_t)num_cu * 3 + tiles - 1) / tiles;
+  // fill the chip's 2 x CU workgroup slots as exactly as the tile count allows (one full round, no ragged second one)
+  int64_t nsplit = (int64_t)num_cu * 2 / tiles;
   const int64_t maxsplit = (B + 255) / 256;
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit < 1) nsplit = 1;
@@ -340,10 +362,11 @@ int backward_weight_splits(int32_t out, int32_t in, int64_t B, int num_cu, int64
 void launch_backward_weight(hipStream_t st, const double* Delta, const double* Hprev, double* part, int32_t out,
                             int32_t in, int64_t B, int nsplit, int64_t ksplit) {
   // A(m = out idx, k = b) = Delta[m + out*k]: row-fast;  B(k = b, n = in idx) = Hprev[n + in*k]: row-fast
-  if (out > 64)
-    launch_gemm<128, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0);
-  else
-    launch_gemm<64, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0);
+  switch (pick_bm_bwd(out)) {
+    case 96: launch_gemm<96, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0); break;
+    case 128: launch_gemm<128, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0); break;
+    default: launch_gemm<64, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0); break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ small kernels
