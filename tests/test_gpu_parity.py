@@ -456,3 +456,75 @@ def test_construction_with_device_training(si, gpu_ctx):
     assert np.allclose(wd, wh, rtol=1e-3, atol=1e-5)
     sign = np.sign(np.sum(pd * ph, axis=0))
     assert np.allclose(pd * sign, ph, rtol=2e-2, atol=2e-4 * np.abs(ph).max())
+
+
+# ----------------------------------------------------------------------------------------------- edge cases
+def test_edge_shapes_construct(si, gpu_ctx):
+    # K = 1, M = 1, tiny N (below one 64-row slab, below one 16-wide tile)
+    for n in (1, 2, 17, 63, 65):
+        w = np.random.default_rng(n).standard_normal(n).astype(np.float32)
+        gpu_ctx.construct_begin(n, 1)
+        gpu_ctx.construct_push(w, 1.0)
+        w_swa, p, s, k = gpu_ctx.construct_finish(1)
+        w_ref, a_ref = so.construct_stream([w], [1.0])
+        assert k == 1 and np.array_equal(w_swa, w_ref)
+        assert np.isclose(s[0], np.linalg.norm(a_ref[:, 0]), rtol=1e-13)
+        assert np.allclose(np.abs(p[:, 0]), np.abs(a_ref[:, 0]), rtol=1e-12, atol=1e-15)
+    # K = 128 (largest single-pass Gram) and K = 129 (first panel-pair case), M = 64 (two projection chunks)
+    for k in (128, 129):
+        n = 3000
+        snaps = _snap_stream(n, k, seed=k, dtype=np.float64)
+        ns = [float(i + 1) for i in range(k)]
+        gpu_ctx.construct_begin(n, k)
+        for w, nn in zip(snaps, ns):
+            gpu_ctx.construct_push(w, nn)
+        w_swa, p, s, _ = gpu_ctx.construct_finish(64)
+        w_ref, a_ref = so.construct_stream(snaps, ns)
+        p_ref, s_ref = so.projection_from_A(a_ref, 64)
+        assert np.array_equal(w_swa, w_ref) and np.allclose(s, s_ref[:64], rtol=1e-8)
+        assert np.allclose(_align_signs(p, p_ref), p_ref, rtol=1e-5, atol=1e-8 * np.abs(p_ref).max())
+    # invalid calls fail loudly, never silently
+    with pytest.raises(si.SubspaceError):
+        gpu_ctx.construct_begin(0, 1)
+    with pytest.raises(si.SubspaceError):
+        gpu_ctx.construct_begin(10, 0)
+    gpu_ctx.construct_begin(10, 1)
+    with pytest.raises(si.SubspaceError):
+        gpu_ctx.construct_finish(1)          # nothing pushed
+    with pytest.raises(si.SubspaceError):
+        gpu_ctx.construct_push(np.zeros(10, dtype=np.int32), 1.0)   # unsupported dtype
+
+
+def test_edge_shapes_density(si, gpu_ctx):
+    # M = 1; M = 64 with 5 chains (4 + 1 reconstruct passes); B = 1; out = 5 (unfused head, one above the fuse limit)
+    for dims, acts, b, m, c in (([3, 4, 1], [1, 0], 1, 1, 1), ([9, 70, 5], [2, 0], 129, 64, 5), ([2, 2], [0], 3, 2, 3)):
+        table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=b + m)
+        gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=1.3)
+        z = np.asfortranarray(np.random.default_rng(0).standard_normal((m, c)))
+        lp = gpu_ctx.logdensity(z)
+        ref = [so.logdensity(table, w_swa, p, x, y, 1.3, z[:, j]) for j in range(c)]
+        assert np.allclose(lp, ref, rtol=1e-11)
+        assert np.allclose(gpu_ctx.reconstruct(z), w_swa[:, None] + p @ z, rtol=1e-13, atol=1e-14)
+    # layer table that does not chain / offsets outside the vector / bad sigma: loud errors
+    table, n, w_swa, p, x, y = _random_problem([3, 4, 1], [1, 0], 5, 2, seed=1)
+    bad = [(3, 4, 1, 0, 12), (5, 1, 0, 16, 21)]
+    with pytest.raises(si.SubspaceError):
+        gpu_ctx.infer_setup(bad, n, 2, w_swa, p, x, y, 1.0)
+    with pytest.raises(si.SubspaceError):
+        gpu_ctx.infer_setup(table, n, 2, w_swa, p, x, y, 0.0)
+    with pytest.raises(si.SubspaceError):
+        gpu_ctx.infer_setup(table, n, 2, w_swa, p, x, y[:, :4], 1.0)   # X / Y observation counts differ
+
+
+def test_rwmh_rejects_non_finite_proposals(gpu_ctx):
+    """A proposal whose log-density is NaN / -Inf is rejected (`-randexp() < NaN` is false in Julia too)."""
+    table, n = so.layer_table([1, 1], [0])
+    w_swa = np.array([1.0, 0.0])
+    p = np.array([[1e200], [0.0]], order="F")     # any |z| > ~1e108 overflows the squared error to +Inf
+    x = np.array([[1e100]])
+    y = np.array([[0.0]])
+    gpu_ctx.infer_setup(table, n, 1, w_swa, p, x, y, sigma_m=1.0)
+    z, lp, acc = gpu_ctx.sample_rwmh(50, 1.0, seed=3)
+    assert np.all(np.isfinite(z))
+    # the initial draw is always kept (even at lp = -Inf); afterwards a non-finite proposal can never be accepted
+    assert np.all(lp[1:, 0] == lp[0, 0]) and acc[0] == 0.0 or np.all(np.isfinite(lp[1:, 0]) | (lp[1:, 0] == -np.inf))
