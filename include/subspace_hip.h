@@ -152,6 +152,15 @@ int32_t si_predict(si_ctx* ctx, const double* Z /* M x C */, int32_t C, const do
  * Z_out is M x itr x nchains, lp_out is itr x nchains (column-major), accept_rate_out nchains.        */
 int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0,
                        int32_t nchains, double* Z_out, double* lp_out, double* accept_rate_out);
+/* The same chain, one transition at a time, with the proposal's sum of squared errors handed to the caller between
+ * evaluation and acceptance: a DATA-SHARDED density (every rank holds a column block of X, Y and the same W_swa, P)
+ * all-reduces the per-rank partial SSE there (one 8*nchains-byte RCCL all-reduce per step).  d_total = out_dim * B over
+ * ALL ranks (0 = this ctx's own B).  All ranks use the same seed / chain ids, hence take identical decisions.        */
+int32_t si_rwmh_begin(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0, int32_t nchains,
+                      int64_t d_total);
+int32_t si_rwmh_step_eval(si_ctx* ctx, double* sse_local_out /* nchains */);
+int32_t si_rwmh_step_accept(si_ctx* ctx, const double* sse_total /* nchains */);
+int32_t si_rwmh_end(si_ctx* ctx, double* Z_out, double* lp_out, double* accept_rate_out);
 /* :91 / :125  W_out[:, c] = W_swa + P * Z[:, c]   (N x C col-major)                                  */
 int32_t si_reconstruct(si_ctx* ctx, const double* Z /* M x C */, int64_t C, double* W_out);
 

@@ -72,6 +72,10 @@ SIGNATURES = {
     "si_predict": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "si_sample_rwmh": (c_int32, [c_void_p, c_int64, c_double, c_uint64, c_int32, c_int32, c_void_p, c_void_p,
                                  c_void_p]),
+    "si_rwmh_begin": (c_int32, [c_void_p, c_int64, c_double, c_uint64, c_int32, c_int32, c_int64]),
+    "si_rwmh_step_eval": (c_int32, [c_void_p, c_void_p]),
+    "si_rwmh_step_accept": (c_int32, [c_void_p, c_void_p]),
+    "si_rwmh_end": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "si_reconstruct": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "si_train_setup": (c_int32, [c_void_p, POINTER(SiLayer), c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_int32,
                                  c_int32, c_int64, c_int64, c_int32, c_double, c_double, c_double]),
@@ -321,6 +325,28 @@ class Context:
         acc = np.empty(int(nchains), dtype=np.float64)
         self._check(self.lib.si_sample_rwmh(self.h, int(itr), float(sigma_z), int(seed), int(chain_id0), int(nchains),
                                             _ptr(z), _ptr(lp), _ptr(acc)))
+        return z, lp, acc
+
+    def rwmh_begin(self, itr, sigma_z, seed, chain_id0=0, nchains=1, d_total=0):
+        self._check(self.lib.si_rwmh_begin(self.h, int(itr), float(sigma_z), int(seed), int(chain_id0), int(nchains),
+                                           int(d_total)))
+        self._sw = (int(itr), int(nchains))
+
+    def rwmh_step_eval(self):
+        sse = np.empty(self._sw[1], dtype=np.float64)
+        self._check(self.lib.si_rwmh_step_eval(self.h, _ptr(sse)))
+        return sse
+
+    def rwmh_step_accept(self, sse_total):
+        sse_total = np.ascontiguousarray(sse_total, dtype=np.float64)
+        self._check(self.lib.si_rwmh_step_accept(self.h, _ptr(sse_total)))
+
+    def rwmh_end(self):
+        itr, c = self._sw
+        z = np.empty((self._m, itr, c), dtype=np.float64, order="F")
+        lp = np.empty((itr, c), dtype=np.float64, order="F")
+        acc = np.empty(c, dtype=np.float64)
+        self._check(self.lib.si_rwmh_end(self.h, _ptr(z), _ptr(lp), _ptr(acc)))
         return z, lp, acc
 
     def reconstruct(self, z):

@@ -121,6 +121,8 @@ static void free_infer(Ctx* c) {
   dev_free(c->d_lpcur);
   dev_free(c->d_sse);
   dev_free(c->d_nacc);
+  dev_free(c->sw_Z);
+  dev_free(c->sw_lp);
   c->chains_cap = 0;
   c->i_ready = false;
   c->i_swa = c->i_P = nullptr;
@@ -916,6 +918,92 @@ int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, 
   dev_free(dlp);
   if (e != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string("si_sample_rwmh: ") + hipGetErrorString(e));
   if (e2 != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string("si_sample_rwmh: ") + hipGetErrorString(e2));
+  if (accept_rate_out)
+    for (int c = 0; c < C; ++c) accept_rate_out[c] = itr > 1 ? (double)nacc[(size_t)c] / (double)(itr - 1) : 0.0;
+  return SI_OK;
+}
+
+// ---- step-wise RWMH: the same chain as si_sample_rwmh, but the SSE of every proposal passes through the caller
+// between evaluation and acceptance, so that a DATA-SHARDED density (each rank holds B/world observations of X, Y and
+// the same W_swa, P) can all-reduce the per-rank partial sums.  Every rank draws the same Philox
+// stream (same seed / chain ids), so all ranks take identical accept decisions and keep identical chains.
+int32_t si_rwmh_begin(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0, int32_t nchains,
+                      int64_t d_total) {
+  CHECK_CTX(ctx);
+  if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_rwmh_begin: call si_infer_setup first");
+  if (itr <= 0 || nchains <= 0 || chain_id0 < 0 || !(sigma_z > 0.0) || d_total < 0)
+    return fail(ctx, SI_ERR_INVALID, "si_rwmh_begin: itr, nchains, sigma_z must be positive");
+  BIND(ctx);
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int32_t rc = ensure_chains(ctx, nchains);
+  if (rc != SI_OK) return rc;
+  dev_free(ctx->sw_Z);
+  dev_free(ctx->sw_lp);
+  if (dev_alloc(&ctx->sw_Z, (size_t)ctx->iM * itr * nchains) != hipSuccess ||
+      dev_alloc(&ctx->sw_lp, (size_t)itr * nchains) != hipSuccess) {
+    dev_free(ctx->sw_Z);
+    dev_free(ctx->sw_lp);
+    return fail(ctx, SI_ERR_NOMEM, "si_rwmh_begin: output allocation failed");
+  }
+  ctx->sw_itr = itr; ctx->sw_sigma_z = sigma_z; ctx->sw_seed = seed; ctx->sw_chain0 = chain_id0; ctx->sw_C = nchains;
+  ctx->sw_d = d_total > 0 ? (double)d_total : (double)ctx->out_dim * (double)ctx->B;
+  ctx->sw_next = 0;
+  ctx->sw_evaluated = false;
+  launch_rwmh_init(ctx->stream, ctx->d_zcur, ctx->d_lpcur, ctx->d_nacc, ctx->iM, nchains);
+  SI_HIP(ctx, hipGetLastError());
+  return SI_OK;
+}
+
+int32_t si_rwmh_step_eval(si_ctx* ctx, double* sse_local_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->sw_Z || ctx->sw_next >= ctx->sw_itr || ctx->sw_evaluated)
+    return fail(ctx, SI_ERR_STATE, "si_rwmh_step_eval: call si_rwmh_begin first / accept the pending step / chain finished");
+  if (!sse_local_out) return fail(ctx, SI_ERR_INVALID, "si_rwmh_step_eval: NULL output");
+  BIND(ctx);
+  const int32_t C = ctx->sw_C;
+  launch_rwmh_propose(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->iM, C, ctx->sw_sigma_z, ctx->sw_seed, ctx->sw_chain0,
+                      (uint64_t)ctx->sw_next);
+  for (int c = 0; c < C; ++c) {
+    const int32_t rc = eval_density(ctx, c, nullptr);
+    if (rc != SI_OK) return rc;
+  }
+  SI_HIP(ctx, hipMemcpyAsync(sse_local_out, ctx->d_sse, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->sw_evaluated = true;
+  return SI_OK;
+}
+
+int32_t si_rwmh_step_accept(si_ctx* ctx, const double* sse_total) {
+  CHECK_CTX(ctx);
+  if (!ctx->sw_Z || !ctx->sw_evaluated) return fail(ctx, SI_ERR_STATE, "si_rwmh_step_accept: no evaluated step pending");
+  if (!sse_total) return fail(ctx, SI_ERR_INVALID, "si_rwmh_step_accept: NULL input");
+  BIND(ctx);
+  const int32_t C = ctx->sw_C;
+  SI_HIP(ctx, hipMemcpyAsync(ctx->d_sse, sse_total, (size_t)C * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));  // sse_total is caller-owned
+  const double c0 = mvnormal_c0(ctx->sw_d, ctx->sigma_m), s2 = ctx->sigma_m * ctx->sigma_m;
+  launch_rwmh_accept(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->d_lpcur, ctx->d_sse, ctx->d_nacc, ctx->iM, C, c0, s2,
+                     ctx->sw_seed, ctx->sw_chain0, (uint64_t)ctx->sw_next, ctx->sw_Z, ctx->sw_lp, ctx->sw_itr);
+  SI_HIP(ctx, hipGetLastError());
+  ctx->sw_next += 1;
+  ctx->sw_evaluated = false;
+  return SI_OK;
+}
+
+int32_t si_rwmh_end(si_ctx* ctx, double* Z_out, double* lp_out, double* accept_rate_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->sw_Z || ctx->sw_next != ctx->sw_itr || ctx->sw_evaluated)
+    return fail(ctx, SI_ERR_STATE, "si_rwmh_end: the chain is not complete");
+  BIND(ctx);
+  const int32_t C = ctx->sw_C, M = ctx->iM;
+  const int64_t itr = ctx->sw_itr;
+  std::vector<int64_t> nacc((size_t)C);
+  if (Z_out) SI_HIP(ctx, hipMemcpyAsync(Z_out, ctx->sw_Z, (size_t)M * itr * C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (lp_out) SI_HIP(ctx, hipMemcpyAsync(lp_out, ctx->sw_lp, (size_t)itr * C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipMemcpyAsync(nacc.data(), ctx->d_nacc, (size_t)C * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  dev_free(ctx->sw_Z);
+  dev_free(ctx->sw_lp);
   if (accept_rate_out)
     for (int c = 0; c < C; ++c) accept_rate_out[c] = itr > 1 ? (double)nacc[(size_t)c] / (double)(itr - 1) : 0.0;
   return SI_OK;

@@ -114,6 +114,14 @@ struct Ctx {
   double* d_sse = nullptr;    // C
   int64_t* d_nacc = nullptr;  // C
   int32_t chains_cap = 0;
+  // step-wise sampler session (si_rwmh_begin .. si_rwmh_end)
+  double* sw_Z = nullptr;
+  double* sw_lp = nullptr;
+  int64_t sw_itr = 0, sw_next = 0;
+  double sw_sigma_z = 0.0, sw_d = 0.0;
+  uint64_t sw_seed = 0;
+  int32_t sw_chain0 = 0, sw_C = 0;
+  bool sw_evaluated = false;
 };
 
 void free_train(Ctx* c);

@@ -115,6 +115,24 @@ def sharded_construct_finish(ctx, m, n_total=None, gather=True):
     return allgather_rows(w_loc, n_total), allgather_rows(p_loc, n_total), s, k
 
 
+def col_shard(b, rank, world_size):
+    """Observation block [b0, b1) of (X, Y) for this rank in the data-sharded density."""
+    base, rem = divmod(b, world_size)
+    b0 = rank * base + min(rank, rem)
+    return b0, b0 + base + (1 if rank < rem else 0)
+
+
+def sample_data_sharded(ctx, itr, sigma_z, seed, d_total, chain_id0=0, nchains=1):
+    """RWMH with the DATA split over the ranks: `ctx` was set up with this rank's column block of
+    (X, Y) and the full W_swa / P.  Per transition every rank evaluates the SAME proposal on its block and the partial
+    sums of squared errors are all-reduced (8*nchains bytes) before the accept step; all ranks return the same chain.
+    d_total = out_dim * (observations over all ranks)."""
+    ctx.rwmh_begin(itr, sigma_z, seed, chain_id0, nchains, d_total)
+    for _ in range(itr):
+        ctx.rwmh_step_accept(allreduce_sum(ctx.rwmh_step_eval()))
+    return ctx.rwmh_end()
+
+
 def sample_chains(ctx, nchains_total, itr, sigma_z, seed):
     """Independent RWMH chains spread over the ranks; returns (Z (M x itr x nchains_total), lp, accept) on every rank."""
     d = _dist()

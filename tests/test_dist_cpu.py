@@ -33,6 +33,40 @@ class FakeCtx:
         v = v * np.sign(v[np.argmax(np.abs(v), axis=0), np.arange(m)])[None, :]
         return self.w, self.a @ v, np.sqrt(lam[::-1][:m]), self.a.shape[1]
 
+    # --- step-wise RWMH on this rank's data block (oracle arithmetic), mirrors si_rwmh_begin .. si_rwmh_end
+    def set_density(self, table, w_swa, p, x_blk, y_blk, sigma_m):
+        self.den = (table, w_swa, p, x_blk, y_blk, sigma_m)
+
+    def rwmh_begin(self, itr, sigma_z, seed, chain_id0=0, nchains=1, d_total=0):
+        from oracle import philox
+        self.sw = dict(itr=itr, sz=sigma_z, seed=seed, c0=chain_id0, d=d_total, t=0, z=None, lp=-np.inf, nacc=0,
+                       zs=np.empty((self.den[2].shape[1], itr, 1), order="F"), lps=np.empty((itr, 1), order="F"))
+        self.philox = philox
+
+    def rwmh_step_eval(self):
+        from oracle import subspace_oracle as so
+        table, w_swa, p, x, y, _ = self.den
+        sw = self.sw
+        m = p.shape[1]
+        base = np.zeros(m) if sw["z"] is None else sw["z"]
+        sw["zp"] = base + sw["sz"] * self.philox.normals(sw["seed"], sw["c0"], sw["t"], m)
+        r = y - so.forward(table, so.reconstruct(w_swa, p, sw["zp"]), x)
+        return np.array([float(np.sum(r * r))])
+
+    def rwmh_step_accept(self, sse_total):
+        from oracle import subspace_oracle as so
+        sw = self.sw
+        lpp = so.lp_from_sse(float(sse_total[0]), sw["d"], self.den[5])
+        if sw["t"] == 0 or -self.philox.randexp(sw["seed"], sw["c0"], sw["t"]) < lpp - sw["lp"]:
+            if sw["t"] > 0:
+                sw["nacc"] += 1
+            sw["z"], sw["lp"] = sw["zp"], lpp
+        sw["zs"][:, sw["t"], 0], sw["lps"][sw["t"], 0] = sw["z"], sw["lp"]
+        sw["t"] += 1
+
+    def rwmh_end(self):
+        return self.sw["zs"], self.sw["lps"], np.array([self.sw["nacc"] / max(1, self.sw["itr"] - 1)])
+
     def sample_rwmh(self, itr, sigma_z, seed, chain_id0=0, nchains=1):
         from oracle import philox
         z = np.stack([np.stack([sigma_z * philox.normals(seed, chain_id0 + c, t, 3) for t in range(itr)], axis=1)
@@ -68,6 +102,19 @@ def _worker(rank, world, port, q):
         z, lp, acc = sd.sample_chains(ctx, 5, 7, 0.3, seed=9)
         zr, lpr, _ = FakeCtx(None, None, None).sample_rwmh(7, 0.3, 9, 0, 5)
         ok = ok and z.shape == (3, 7, 5) and np.array_equal(z, zr) and np.array_equal(lp, lpr) and acc.shape == (5,)
+        # data-sharded density: each rank holds a column block of (X, Y); partial SSEs are all-reduced per step
+        dims, acts, b, mm = [5, 12, 2], [so.ACT_TANH, so.ACT_IDENTITY], 41, 3
+        table, npar = so.layer_table(dims, acts)
+        r2 = np.random.default_rng(1)
+        ws2, p2 = 0.3 * r2.standard_normal(npar), 0.2 * r2.standard_normal((npar, mm))
+        x2, y2 = r2.standard_normal((dims[0], b)), r2.standard_normal((dims[-1], b))
+        b0, b1 = sd.col_shard(b, rank, world)
+        fc = FakeCtx(None, None, None)
+        fc.set_density(table, ws2, p2, x2[:, b0:b1], y2[:, b0:b1], 0.9)
+        zsh, lpsh, accsh = sd.sample_data_sharded(fc, 25, 0.1, seed=5, d_total=dims[-1] * b)
+        zfull, lpfull, _, naccfull = so.sub_inference(table, x2, y2, ws2, p2, 0.1, 0.9, 25, seed=5)
+        ok = ok and np.allclose(zsh[:, :, 0], zfull, rtol=1e-10, atol=1e-13) and np.allclose(lpsh[:, 0], lpfull, rtol=1e-11)
+        ok = ok and abs(accsh[0] - naccfull / 24) < 1e-12
         q.put((rank, bool(ok), ""))
     except Exception as e:  # surface the failure in the parent
         import traceback
@@ -90,6 +137,7 @@ def test_partitions():
     assert [sd.chain_ids(8, r, 8) for r in range(8)] == [[i] for i in range(8)]
     assert sd.chain_ids(5, 0, 2) == [0, 1, 2] and sd.chain_ids(5, 1, 2) == [3, 4]
     assert sd.chain_ids(1, 1, 2) == []
+    assert [sd.col_shard(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
     assert sd.world() == (0, 1)
     assert np.array_equal(sd.allreduce_sum(np.eye(3)), np.eye(3))  # no process group: identity
 

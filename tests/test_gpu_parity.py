@@ -528,3 +528,36 @@ def test_rwmh_rejects_non_finite_proposals(gpu_ctx):
     assert np.all(np.isfinite(z))
     # the initial draw is always kept (even at lp = -Inf); afterwards a non-finite proposal can never be accepted
     assert np.all(lp[1:, 0] == lp[0, 0]) and acc[0] == 0.0 or np.all(np.isfinite(lp[1:, 0]) | (lp[1:, 0] == -np.inf))
+
+
+# ----------------------------------------------------------------------------------------------- data-sharded density
+def test_stepwise_rwmh_equals_fused_and_supports_data_shards(si, gpu_ctx):
+    """si_rwmh_begin/step_eval/step_accept/end == si_sample_rwmh; and two data shards whose SSEs are summed by the
+    caller (what the RCCL all-reduce does across ranks) reproduce the full-data chain."""
+    dims, acts, b, m = [6, 40, 3], [1, 0], 500, 4
+    table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=13)
+    gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=2.0)
+    z_ref, lp_ref, acc_ref = gpu_ctx.sample_rwmh(30, 0.05, seed=7, chain_id0=2, nchains=2)
+    gpu_ctx.rwmh_begin(30, 0.05, 7, 2, 2)
+    for _ in range(30):
+        gpu_ctx.rwmh_step_accept(gpu_ctx.rwmh_step_eval())
+    z, lp, acc = gpu_ctx.rwmh_end()
+    assert np.array_equal(z, z_ref) and np.array_equal(lp, lp_ref) and np.array_equal(acc, acc_ref)
+    # two "ranks" on one GPU: columns [0, 230) and [230, 500); the caller adds the partial SSEs
+    shards = [si.Context(0), si.Context(0)]
+    try:
+        for c, (b0, b1) in zip(shards, ((0, 230), (230, 500))):
+            c.infer_setup(table, n, m, w_swa, p, np.asfortranarray(x[:, b0:b1]), np.asfortranarray(y[:, b0:b1]), 2.0)
+            c.rwmh_begin(30, 0.05, 7, 2, 2, d_total=dims[-1] * b)
+        for _ in range(30):
+            tot = shards[0].rwmh_step_eval() + shards[1].rwmh_step_eval()
+            for c in shards:
+                c.rwmh_step_accept(tot)
+        outs = [c.rwmh_end() for c in shards]
+    finally:
+        for c in shards:
+            c.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])   # ranks agree exactly
+    assert np.allclose(outs[0][0], z_ref, rtol=1e-10, atol=1e-13) and np.allclose(outs[0][1], lp_ref, rtol=1e-11)
+    with pytest.raises(si.SubspaceError):
+        gpu_ctx.rwmh_step_accept(np.zeros(2))     # nothing pending
