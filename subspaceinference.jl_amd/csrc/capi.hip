@@ -121,6 +121,7 @@ static void free_infer(Ctx* c) {
   dev_free(c->d_lpcur);
   dev_free(c->d_sse);
   dev_free(c->d_nacc);
+  dev_free(c->d_steps);
   dev_free(c->sw_Z);
   dev_free(c->sw_lp);
   c->chains_cap = 0;
@@ -619,10 +620,11 @@ static int32_t ensure_chains(si_ctx* ctx, int32_t C) {
   dev_free(ctx->d_lpcur);
   dev_free(ctx->d_sse);
   dev_free(ctx->d_nacc);
+  dev_free(ctx->d_steps);
   ctx->chains_cap = 0;
   if (dev_alloc(&ctx->d_zcur, (size_t)ctx->iM * C) != hipSuccess || dev_alloc(&ctx->d_zprop, (size_t)ctx->iM * C) != hipSuccess ||
       dev_alloc(&ctx->d_lpcur, (size_t)C) != hipSuccess || dev_alloc(&ctx->d_sse, (size_t)C) != hipSuccess ||
-      dev_alloc(&ctx->d_nacc, (size_t)C) != hipSuccess)
+      dev_alloc(&ctx->d_nacc, (size_t)C) != hipSuccess || dev_alloc(&ctx->d_steps, (size_t)C) != hipSuccess)
     return fail(ctx, SI_ERR_NOMEM, "sampler state allocation failed");
   ctx->chains_cap = C;
   return SI_OK;
@@ -885,25 +887,32 @@ int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, 
   const double c0 = mvnormal_c0(d, ctx->sigma_m), s2 = ctx->sigma_m * ctx->sigma_m;
   {
     ProfScope ps(ctx, SI_K_RWMH, 0, 0);
-    launch_rwmh_init(ctx->stream, ctx->d_zcur, ctx->d_lpcur, ctx->d_nacc, M, C);
+    launch_rwmh_init(ctx->stream, ctx->d_zcur, ctx->d_lpcur, ctx->d_nacc, ctx->d_steps, M, C);
   }
-  for (int64_t t = 0; t < itr; ++t) {
+  // one transition for all chains; the transition index is a device-side counter, so the launches are identical
+  auto transition = [&]() -> int32_t {
     {
       ProfScope ps(ctx, SI_K_RWMH, 0, 0);
-      launch_rwmh_propose(ctx->stream, ctx->d_zcur, ctx->d_zprop, M, C, sigma_z, seed, chain_id0, (uint64_t)t);
+      launch_rwmh_propose(ctx->stream, ctx->d_zcur, ctx->d_zprop, M, C, sigma_z, seed, chain_id0, ctx->d_steps);
     }
-    for (int c = 0; c < C; ++c)
-      if ((rc = eval_density(ctx, c, nullptr)) != SI_OK) {
-        (void)hipStreamSynchronize(ctx->stream);
-        dev_free(dZ);
-        dev_free(dlp);
-        return rc;
-      }
-    {
-      ProfScope ps(ctx, SI_K_RWMH, 0, 0);
-      launch_rwmh_accept(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->d_lpcur, ctx->d_sse, ctx->d_nacc, M, C, c0, s2,
-                         seed, chain_id0, (uint64_t)t, dZ, dlp, itr);
+    for (int c = 0; c < C; ++c) {
+      const int32_t r = eval_density(ctx, c, nullptr);
+      if (r != SI_OK) return r;
     }
+    ProfScope ps(ctx, SI_K_RWMH, 0, 0);
+    launch_rwmh_accept(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->d_lpcur, ctx->d_sse, ctx->d_nacc, M, C, c0, s2, seed,
+                       chain_id0, ctx->d_steps, dZ, dlp, itr);
+    return SI_OK;
+  };
+  // Replaying one captured transition as a hipGraph was measured and dropped: the README-toy transition takes 27.8 us
+  // graphed vs 25.7 us eager -- it is bound by the serial latency of its 8 dependent small kernels, not by host
+  // launches -- and at cfg2 a transition is 3.3 ms of kernel time.
+  for (int64_t t = 0; t < itr && rc == SI_OK; ++t) rc = transition();
+  if (rc != SI_OK) {
+    (void)hipStreamSynchronize(ctx->stream);
+    dev_free(dZ);
+    dev_free(dlp);
+    return rc;
   }
   hipError_t e = hipGetLastError();
   std::vector<int64_t> nacc((size_t)C);
@@ -949,7 +958,7 @@ int32_t si_rwmh_begin(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, i
   ctx->sw_d = d_total > 0 ? (double)d_total : (double)ctx->out_dim * (double)ctx->B;
   ctx->sw_next = 0;
   ctx->sw_evaluated = false;
-  launch_rwmh_init(ctx->stream, ctx->d_zcur, ctx->d_lpcur, ctx->d_nacc, ctx->iM, nchains);
+  launch_rwmh_init(ctx->stream, ctx->d_zcur, ctx->d_lpcur, ctx->d_nacc, ctx->d_steps, ctx->iM, nchains);
   SI_HIP(ctx, hipGetLastError());
   return SI_OK;
 }
@@ -962,7 +971,7 @@ int32_t si_rwmh_step_eval(si_ctx* ctx, double* sse_local_out) {
   BIND(ctx);
   const int32_t C = ctx->sw_C;
   launch_rwmh_propose(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->iM, C, ctx->sw_sigma_z, ctx->sw_seed, ctx->sw_chain0,
-                      (uint64_t)ctx->sw_next);
+                      ctx->d_steps);
   for (int c = 0; c < C; ++c) {
     const int32_t rc = eval_density(ctx, c, nullptr);
     if (rc != SI_OK) return rc;
@@ -983,7 +992,7 @@ int32_t si_rwmh_step_accept(si_ctx* ctx, const double* sse_total) {
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));  // sse_total is caller-owned
   const double c0 = mvnormal_c0(ctx->sw_d, ctx->sigma_m), s2 = ctx->sigma_m * ctx->sigma_m;
   launch_rwmh_accept(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->d_lpcur, ctx->d_sse, ctx->d_nacc, ctx->iM, C, c0, s2,
-                     ctx->sw_seed, ctx->sw_chain0, (uint64_t)ctx->sw_next, ctx->sw_Z, ctx->sw_lp, ctx->sw_itr);
+                     ctx->sw_seed, ctx->sw_chain0, ctx->d_steps, ctx->sw_Z, ctx->sw_lp, ctx->sw_itr);
   SI_HIP(ctx, hipGetLastError());
   ctx->sw_next += 1;
   ctx->sw_evaluated = false;

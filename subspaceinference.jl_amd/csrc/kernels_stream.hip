@@ -300,19 +300,23 @@ void launch_sse(hipStream_t st, const double* yhat, const double* y, int64_t d, 
 //   step 0: z0 ~ N(0, sigma_z^2 I), always kept;  step t: z' = z + sigma_z*eps, accept iff -Exp(1) < lp'-lp
 // State stays on the device; one block per chain.
 // ------------------------------------------------------------------------------------------------
-__global__ void rwmh_init_kernel(double* zcur, double* lpcur, int64_t* nacc, int32_t M) {
+__global__ void rwmh_init_kernel(double* zcur, double* lpcur, int64_t* nacc, uint64_t* steps, int32_t M) {
   const int c = blockIdx.x;
   for (int m = threadIdx.x; m < M; m += blockDim.x) zcur[m + c * M] = 0.0;
   if (threadIdx.x == 0) {
     lpcur[c] = -__builtin_inf();
     nacc[c] = 0;
+    steps[c] = 0;
   }
 }
 
 __global__ void rwmh_propose_kernel(const double* __restrict__ zcur, double* __restrict__ zprop,
                                     int32_t M, double sigma_z, uint64_t seed, int32_t chain_id0,
-                                    uint64_t step) {
+                                    const uint64_t* __restrict__ steps) {
+  // the transition index lives on the device (one counter per chain, advanced by the accept kernel): the kernel
+  // arguments of a transition never change, so a captured hipGraph of one transition can be replayed itr-1 times
   const int c = blockIdx.x;
+  const uint64_t step = steps[c];
   const uint32_t chain = (uint32_t)(chain_id0 + c);
   const int nblk = (M + 1) >> 1;
   for (int j = threadIdx.x; j < nblk; j += blockDim.x) {
@@ -327,10 +331,11 @@ __global__ void rwmh_propose_kernel(const double* __restrict__ zcur, double* __r
 __global__ void rwmh_accept_kernel(double* __restrict__ zcur, const double* __restrict__ zprop,
                                    double* __restrict__ lpcur, const double* __restrict__ sse,
                                    int64_t* __restrict__ nacc, int32_t M, double c0, double sigma2,
-                                   uint64_t seed, int32_t chain_id0, uint64_t step,
+                                   uint64_t seed, int32_t chain_id0, uint64_t* __restrict__ steps,
                                    double* __restrict__ Z_out, double* __restrict__ lp_out,
                                    int64_t itr) {
   const int c = blockIdx.x;
+  const uint64_t step = steps[c];
   const uint32_t chain = (uint32_t)(chain_id0 + c);
   // Distributions.logpdf(MvNormal(mu, sigma), y) = c0 - (sse / sigma^2) / 2
   const double lp_new = c0 - (sse[c] / sigma2) / 2.0;
@@ -353,22 +358,23 @@ __global__ void rwmh_accept_kernel(double* __restrict__ zcur, const double* __re
     lpcur[c] = lp_keep;
     lp_out[step + (uint64_t)itr * c] = lp_keep;
     if (accept && step > 0) nacc[c] += 1;
+    steps[c] = step + 1;
   }
 }
 
-void launch_rwmh_init(hipStream_t st, double* zcur, double* lpcur, int64_t* nacc, int32_t M, int32_t C) {
-  hipLaunchKernelGGL(rwmh_init_kernel, dim3(C), dim3(64), 0, st, zcur, lpcur, nacc, M);
+void launch_rwmh_init(hipStream_t st, double* zcur, double* lpcur, int64_t* nacc, uint64_t* steps, int32_t M, int32_t C) {
+  hipLaunchKernelGGL(rwmh_init_kernel, dim3(C), dim3(64), 0, st, zcur, lpcur, nacc, steps, M);
 }
 void launch_rwmh_propose(hipStream_t st, const double* zcur, double* zprop, int32_t M, int32_t C,
-                         double sigma_z, uint64_t seed, int32_t chain_id0, uint64_t step) {
-  hipLaunchKernelGGL(rwmh_propose_kernel, dim3(C), dim3(64), 0, st, zcur, zprop, M, sigma_z, seed, chain_id0, step);
+                         double sigma_z, uint64_t seed, int32_t chain_id0, const uint64_t* steps) {
+  hipLaunchKernelGGL(rwmh_propose_kernel, dim3(C), dim3(64), 0, st, zcur, zprop, M, sigma_z, seed, chain_id0, steps);
 }
 void launch_rwmh_accept(hipStream_t st, double* zcur, const double* zprop, double* lpcur,
                         const double* sse, int64_t* nacc, int32_t M, int32_t C, double c0,
-                        double sigma2, uint64_t seed, int32_t chain_id0, uint64_t step,
+                        double sigma2, uint64_t seed, int32_t chain_id0, uint64_t* steps,
                         double* Z_out, double* lp_out, int64_t itr) {
   hipLaunchKernelGGL(rwmh_accept_kernel, dim3(C), dim3(64), 0, st, zcur, zprop, lpcur, sse, nacc, M, c0,
-                     sigma2, seed, chain_id0, step, Z_out, lp_out, itr);
+                     sigma2, seed, chain_id0, steps, Z_out, lp_out, itr);
 }
 
 }  // namespace si

@@ -113,6 +113,7 @@ struct Ctx {
   double* d_lpcur = nullptr;  // C
   double* d_sse = nullptr;    // C
   int64_t* d_nacc = nullptr;  // C
+  uint64_t* d_steps = nullptr;  // C: transition counter of every chain (device-resident)
   int32_t chains_cap = 0;
   // step-wise sampler session (si_rwmh_begin .. si_rwmh_end)
   double* sw_Z = nullptr;
@@ -192,12 +193,12 @@ int rowsum_chunks();
 void launch_ptg(hipStream_t st, const double* P, int64_t ldP, int64_t N, int M, const double* g, double* part, double* gz);
 int ptg_blocks();
 // K6
-void launch_rwmh_init(hipStream_t st, double* zcur, double* lpcur, int64_t* nacc, int32_t M, int32_t C);
+void launch_rwmh_init(hipStream_t st, double* zcur, double* lpcur, int64_t* nacc, uint64_t* steps, int32_t M, int32_t C);
 void launch_rwmh_propose(hipStream_t st, const double* zcur, double* zprop, int32_t M, int32_t C,
-                         double sigma_z, uint64_t seed, int32_t chain_id0, uint64_t step);
+                         double sigma_z, uint64_t seed, int32_t chain_id0, const uint64_t* steps);
 void launch_rwmh_accept(hipStream_t st, double* zcur, const double* zprop, double* lpcur,
                         const double* sse, int64_t* nacc, int32_t M, int32_t C, double c0,
-                        double sigma2, uint64_t seed, int32_t chain_id0, uint64_t step,
+                        double sigma2, uint64_t seed, int32_t chain_id0, uint64_t* steps,
                         double* Z_out, double* lp_out, int64_t itr);
 
 // host symmetric eigensolver (eig.cpp): a is n x n symmetric col-major, overwritten by eigenvectors
