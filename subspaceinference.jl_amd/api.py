@@ -101,9 +101,9 @@ def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=10
     σ_z = σ_z if sigma_z is None else sigma_z
     σ_m = σ_m if sigma_m is None else sigma_m
     a = _alg_name(alg)
-    if a in ("nuts", "advi"):
-        raise SubspaceError("%s is outside what this build accelerates (SURVEY section 2 / 8f)" % a)
-    if a not in _RWMH_ALGS and a not in ("mala", "hmc"):
+    if a == "advi":
+        raise SubspaceError("advi is outside what this build accelerates (SURVEY section 2)")
+    if a not in _RWMH_ALGS and a not in ("mala", "hmc", "nuts"):
         raise SubspaceError("%s is not available" % a)  # reference :162
     if not isinstance(in_model, flux.Chain):
         raise SubspaceError("Error: density function is not avaliable for this model")  # [sic] reference :103
@@ -124,10 +124,10 @@ def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=10
             z, lp, _ = ctx.sample_rwmh(itr, σ_z, seed, chain_id, 1)
             z, lp = z[:, :, 0], lp[:, 0]
         else:
-            # :mala (:117-120) / :hmc (:139-160): the sampler logic is host control flow, every density + gradient
+            # :mala (:117-120) / :hmc, :nuts (:139-160): the sampler logic is host control flow, every density + gradient
             # evaluation is the device reverse sweep (si_logdensity_grad) instead of M-wide ForwardDiff duals (:107)
             rng = np.random.default_rng([int(seed), int(chain_id)])
-            fn = samplers.mala if a == "mala" else samplers.hmc
+            fn = {"mala": samplers.mala, "hmc": samplers.hmc, "nuts": samplers.nuts}[a]
             z, lp, _ = fn(ctx.logdensity_grad, M, itr, σ_z, rng)
         if return_z:
             return z, lp

@@ -10,7 +10,11 @@ vendored.  What is restated [upstream, unverifiable offline]:
   * HMC: `StaticTrajectory(Leapfrog(ε), 1)` -- ONE leapfrog step per sample, `DiagEuclideanMetric(M)`, ε from
     `find_good_stepsize`, adapted for `n_adapts = round(itr/2)` iterations by dual averaging to an acceptance of 0.8.
     AdvancedHMC's windowed mass-matrix adaptation (StanHMCAdaptor) is NOT restated: the metric stays the identity
-    (documented deviation).  `:nuts` is not built.
+    (documented deviation).
+  * NUTS: `NUTS{MultinomialTS, GeneralisedNoUTurn}(Leapfrog(ε))` -- multinomial trajectory sampling with the
+    generalised (momentum-sum) no-U-turn criterion, biased progressive sub-tree sampling, max depth 10, divergence
+    threshold ΔH > 1000 (the published algorithm of Betancourt 2017 / Stan that AdvancedHMC implements); same step-size
+    search and dual averaging as above, identity metric.
 The random stream is NumPy's PCG64 seeded by the caller (the reference uses Julia's global MersenneTwister).
 """
 import math
@@ -86,6 +90,94 @@ def hmc(logdensity_grad, m, itr, sigma_z, rng, delta=0.8):
         a = min(1.0, math.exp(h1 - h0)) if np.isfinite(h1) else 0.0
         if rng.random() < a:
             z, lp, g = zp, lpp, gp
+        zs[:, t], lps[t], acc[t] = z, lp, a
+        if t < n_adapts:
+            it = t + 1
+            hbar = (1.0 - 1.0 / (it + t0)) * hbar + (delta - a) / (it + t0)
+            log_eps = mu - math.sqrt(it) / gamma * hbar
+            eta = it ** (-kappa)
+            log_eps_bar = eta * log_eps + (1.0 - eta) * log_eps_bar
+            eps = math.exp(log_eps)
+            if it == n_adapts:
+                eps = math.exp(log_eps_bar)
+    return zs, lps, float(acc.mean())
+
+
+def _uturn(rho, r_minus, r_plus):
+    return float(rho @ r_minus) <= 0.0 or float(rho @ r_plus) <= 0.0
+
+
+def nuts(logdensity_grad, m, itr, sigma_z, rng, delta=0.8, max_depth=10, max_dh=1000.0):
+    z = sigma_z * rng.standard_normal(m)
+    lp, g = logdensity_grad(z)
+    eps = find_good_stepsize(logdensity_grad, z, lp, g, rng)
+    n_adapts = int(round(itr / 2))
+    mu, gamma, t0, kappa = math.log(10.0 * eps), 0.05, 10.0, 0.75
+    hbar, log_eps_bar = 0.0, 0.0
+    zs = np.empty((m, itr), order="F")
+    lps = np.empty(itr)
+    acc = np.empty(itr)
+
+    def build(zc, rc, gc, v, depth, h0):
+        """2**depth leapfrog steps from (zc, rc) in direction v.  Returns the sub-tree summary."""
+        if depth == 0:
+            z1, r1, lp1, g1 = _leapfrog(logdensity_grad, zc, rc, gc, v * eps)
+            h1 = lp1 - 0.5 * float(r1 @ r1)
+            if not np.isfinite(h1):
+                h1 = -np.inf
+            dh = h1 - h0
+            return dict(zm=z1, rm=r1, gm=g1, zp=z1, rp=r1, gp=g1, zprop=z1, lpprop=lp1, gprop=g1, logw=dh, rho=r1.copy(),
+                        alpha=min(1.0, math.exp(dh)) if dh < 0 else 1.0, n=1, stop=(-dh) > max_dh)
+        a = build(zc, rc, gc, v, depth - 1, h0)
+        if a["stop"]:
+            return a
+        if v > 0:
+            b = build(a["zp"], a["rp"], a["gp"], v, depth - 1, h0)
+        else:
+            b = build(a["zm"], a["rm"], a["gm"], v, depth - 1, h0)
+        logw = np.logaddexp(a["logw"], b["logw"])
+        out = dict(a)
+        if v > 0:
+            out.update(zp=b["zp"], rp=b["rp"], gp=b["gp"])
+        else:
+            out.update(zm=b["zm"], rm=b["rm"], gm=b["gm"])
+        if not b["stop"] and math.log(rng.random()) < b["logw"] - logw:   # multinomial sampling inside the sub-tree
+            out.update(zprop=b["zprop"], lpprop=b["lpprop"], gprop=b["gprop"])
+        out["rho"] = a["rho"] + b["rho"]
+        out["logw"] = logw
+        out["alpha"] = a["alpha"] + b["alpha"]
+        out["n"] = a["n"] + b["n"]
+        out["stop"] = b["stop"] or _uturn(out["rho"], out["rm"], out["rp"])
+        return out
+
+    for t in range(itr):
+        r0 = rng.standard_normal(m)
+        h0 = lp - 0.5 * float(r0 @ r0)
+        tree = dict(zm=z, rm=r0, gm=g, zp=z, rp=r0, gp=g, rho=r0.copy(), logw=0.0)
+        zn, lpn, gn = z, lp, g
+        alpha_sum, n_alpha = 0.0, 0
+        for depth in range(max_depth):
+            v = 1.0 if rng.random() < 0.5 else -1.0
+            if v > 0:
+                sub = build(tree["zp"], tree["rp"], tree["gp"], v, depth, h0)
+            else:
+                sub = build(tree["zm"], tree["rm"], tree["gm"], v, depth, h0)
+            alpha_sum += sub["alpha"]
+            n_alpha += sub["n"]
+            if sub["stop"]:
+                break
+            if math.log(rng.random()) < sub["logw"] - tree["logw"]:          # biased progressive sampling
+                zn, lpn, gn = sub["zprop"], sub["lpprop"], sub["gprop"]
+            if v > 0:
+                tree.update(zp=sub["zp"], rp=sub["rp"], gp=sub["gp"])
+            else:
+                tree.update(zm=sub["zm"], rm=sub["rm"], gm=sub["gm"])
+            tree["rho"] = tree["rho"] + sub["rho"]
+            tree["logw"] = np.logaddexp(tree["logw"], sub["logw"])
+            if _uturn(tree["rho"], tree["rm"], tree["rp"]):
+                break
+        z, lp, g = zn, lpn, gn
+        a = alpha_sum / max(1, n_alpha)
         zs[:, t], lps[t], acc[t] = z, lp, a
         if t < n_adapts:
             it = t + 1

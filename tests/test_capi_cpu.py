@@ -118,9 +118,9 @@ def test_gradient_samplers_on_gaussian_target():
     from subspaceinference_jl_amd import samplers
     mu = np.array([0.5, -1.0, 2.0])
     fn = lambda z: (-0.5 * float((z - mu) @ (z - mu)), -(z - mu))
-    for sampler, s in ((samplers.mala, 0.9), (samplers.hmc, 1.0)):
-        z, lp, acc = sampler(fn, 3, 6000, s, np.random.default_rng(1))
-        burn = z[:, 1000:]
+    for sampler, s in ((samplers.mala, 0.9), (samplers.hmc, 1.0), (samplers.nuts, 1.0)):
+        z, lp, acc = sampler(fn, 3, 6000 if sampler is not samplers.nuts else 2500, s, np.random.default_rng(1))
+        burn = z[:, 500:]
         assert np.all(np.abs(burn.mean(axis=1) - mu) < 0.2), sampler.__name__
         assert np.all(np.abs(burn.var(axis=1) - 1.0) < 0.3), sampler.__name__
         assert 0.3 < acc <= 1.0
