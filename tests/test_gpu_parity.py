@@ -561,3 +561,41 @@ def test_stepwise_rwmh_equals_fused_and_supports_data_shards(si, gpu_ctx):
     assert np.allclose(outs[0][0], z_ref, rtol=1e-10, atol=1e-13) and np.allclose(outs[0][1], lp_ref, rtol=1e-11)
     with pytest.raises(si.SubspaceError):
         gpu_ctx.rwmh_step_accept(np.zeros(2))     # nothing pending
+
+
+def test_conditioning_limits_of_the_gram_route(si, gpu_ctx):
+    """The Gram route squares the condition number.  Singular values down to 1e-5*s_1 must still meet north_star's
+    rtol 1e-4 on s and on P (columns up to sign); below ~1e-6*s_1 the library must refuse (BoundsError) instead of
+    returning noise."""
+    n, k = 4000, 10
+    rng = np.random.default_rng(0)
+    u, _ = np.linalg.qr(rng.standard_normal((n, k)))
+    v, _ = np.linalg.qr(rng.standard_normal((k, k)))
+
+    def push_matrix(svals):
+        a = (u * svals[None, :]) @ v.T            # deviation matrix with prescribed singular values
+        # feed it through the reference recurrence: with n -> infinity weights the mean barely moves; instead build
+        # snapshots whose deviations ARE the columns: w_j = a_j + s_j where s follows the SWA recursion
+        s = np.zeros(n)
+        gpu_ctx.construct_begin(n, k)
+        for j in range(k):
+            nn = float(j + 1)
+            # dev = w - s', s' = (nn*s + w)/(nn+1)  =>  w = s + dev*(nn+1)/nn
+            w = s + a[:, j] * (nn + 1.0) / nn
+            gpu_ctx.construct_push(w, nn)
+            s = (nn * s + w) / (nn + 1.0)
+        return gpu_ctx.construct_get_A(0, k)
+
+    sv = np.logspace(0, -5, k)
+    a_dev = push_matrix(sv)
+    p_ref, s_ref = so.projection_from_A(a_dev, k)
+    w_swa, p, s, _ = gpu_ctx.construct_finish(k)
+    assert np.allclose(s, s_ref, rtol=1e-4)
+    assert np.allclose(_align_signs(p, p_ref), p_ref, rtol=1e-4, atol=1e-4 * np.abs(p_ref[:, -1]).max())
+    # ten decades of spread: the small ones are below what A'A resolves in fp64 -> loud refusal for M = K ...
+    push_matrix(np.logspace(0, -10, k))
+    with pytest.raises(si.BoundsError):
+        gpu_ctx.construct_finish(k)
+    # ... while the well-resolved leading part is still delivered
+    w_swa, p, s, _ = gpu_ctx.construct_finish(4)
+    assert np.allclose(s, np.logspace(0, -10, k)[:4], rtol=1e-4)
