@@ -90,13 +90,17 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
 
 def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=100, M=3, alg="rwmh",
                   backend="forwarddiff", *, sigma_z=None, sigma_m=None, sigma_p=None, device=0, ctx=None,
-                  seed=0, chain_id=0, return_z=False):
+                  seed=0, chain_id=0, return_z=False, nchains=1):
     """src/space_inference.jl:82-164 for a Chain model and alg = :rwmh.
 
     `density(z)` (:90-95: W_swa + P*z -> model_re -> forward over the FULL data -> Gaussian log-likelihood,
     prior term dead) and the RWMH loop (:111-116) run on the device; the output map (:125) materialises
     `W_swa + P*z` for every sample like the reference unless `return_z=True` (then chn is the M x itr matrix
     of subspace samples).  σ_p is accepted and unused, exactly as in the reference (quirk Q4).
+
+    `nchains > 1` (RWMH only; not in the reference, which runs one chain per call) runs the independent chains
+    chain_id .. chain_id+nchains-1 stacked in every launch of the forward pass: chn becomes a list over chains
+    (or the M x itr x nchains array with return_z) and lp is itr x nchains.
     """
     σ_z = σ_z if sigma_z is None else sigma_z
     σ_m = σ_m if sigma_m is None else sigma_m
@@ -120,6 +124,17 @@ def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=10
                 # reference: MvNormal(zeros(M), σ_z) proposal against an N x size(P,2) matrix -> DimensionMismatch in P*z
                 raise SubspaceError("DimensionMismatch: P has %d columns but M = %d" % (P.shape[1], M))
             ctx.infer_setup(table, n_par, M, W_swa, P, x, y, σ_m)
+        if nchains != 1 and a not in _RWMH_ALGS:
+            raise SubspaceError("nchains > 1 is available for alg = :rwmh / :mh only")
+        if a in _RWMH_ALGS and nchains > 1:
+            z, lp, _ = ctx.sample_rwmh(itr, σ_z, seed, chain_id, nchains)
+            if return_z:
+                return z, lp
+            out = []
+            for c in range(nchains):
+                w = ctx.reconstruct(z[:, :, c])
+                out.append([w[:, t] for t in range(w.shape[1])])
+            return out, lp
         if a in _RWMH_ALGS:
             z, lp, _ = ctx.sample_rwmh(itr, σ_z, seed, chain_id, 1)
             z, lp = z[:, :, 0], lp[:, 0]

@@ -125,6 +125,7 @@ static void free_infer(Ctx* c) {
   dev_free(c->sw_Z);
   dev_free(c->sw_lp);
   c->chains_cap = 0;
+  c->fw_slots = 0;
   c->i_ready = false;
   c->i_swa = c->i_P = nullptr;
 }
@@ -523,6 +524,23 @@ int32_t si_construct_get_A(si_ctx* ctx, int64_t k0, int64_t nk, double* A_out) {
 // =================================================================================================
 // density + sampling
 // =================================================================================================
+// forward workspace for `slots` chains evaluated in one launch (grid.y = chain slot)
+static bool alloc_forward(si_ctx* ctx, int slots) {
+  dev_free(ctx->d_w); dev_free(ctx->d_act[0]); dev_free(ctx->d_act[1]); dev_free(ctx->d_ssepart); dev_free(ctx->d_part);
+  dev_free(ctx->d_yhat);
+  ctx->fw_slots = 0;
+  const size_t S = (size_t)slots, dB = (size_t)ctx->out_dim * (size_t)ctx->B;
+  if (dev_alloc(&ctx->d_w, S * (size_t)pad_ld(ctx->iN)) != hipSuccess ||
+      dev_alloc(&ctx->d_act[0], S * (size_t)ctx->act_elems) != hipSuccess ||
+      dev_alloc(&ctx->d_act[1], S * (size_t)ctx->act_elems) != hipSuccess ||
+      dev_alloc(&ctx->d_ssepart, S * (size_t)ctx->sse_blocks) != hipSuccess ||
+      (ctx->fuse_tail && (dev_alloc(&ctx->d_part, S * (size_t)ctx->fuse_slots * dB) != hipSuccess ||
+                          dev_alloc(&ctx->d_yhat, S * dB) != hipSuccess)))
+    return false;
+  ctx->fw_slots = slots;
+  return true;
+}
+
 int32_t si_infer_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, int32_t M, const double* W_swa,
                        const double* P, const double* X, const double* Y, int32_t in_dim, int32_t out_dim,
                        int64_t B, double sigma_m, int32_t compute_dtype) {
@@ -594,14 +612,11 @@ int32_t si_infer_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
   ctx->fuse_slots = ctx->fuse_tail ? dense_fused_slots(layers[L - 2].out) : 0;
   int64_t maxstored = 1;
   for (int l = 0; l < (ctx->fuse_tail ? L - 2 : L); ++l) maxstored = std::max<int64_t>(maxstored, layers[l].out);
-  ctx->act_elems = maxstored * B;
+  ctx->max_stored = maxstored;
+  ctx->act_elems = pad_ld(maxstored * B);
   ctx->sse_blocks = sse_num_blocks((int64_t)out_dim * B, ctx->num_cu);
   if (dev_alloc(&ctx->d_X, (size_t)in_dim * B) != hipSuccess || dev_alloc(&ctx->d_Y, (size_t)out_dim * B) != hipSuccess ||
-      dev_alloc(&ctx->d_w, (size_t)pad_ld(N)) != hipSuccess || dev_alloc(&ctx->d_act[0], (size_t)ctx->act_elems) != hipSuccess ||
-      dev_alloc(&ctx->d_act[1], (size_t)ctx->act_elems) != hipSuccess ||
-      dev_alloc(&ctx->d_ssepart, (size_t)ctx->sse_blocks) != hipSuccess ||
-      (ctx->fuse_tail && (dev_alloc(&ctx->d_part, (size_t)ctx->fuse_slots * out_dim * B) != hipSuccess ||
-                          dev_alloc(&ctx->d_yhat, (size_t)out_dim * B) != hipSuccess))) {
+      !alloc_forward(ctx, 1)) {
     free_infer(ctx);
     return fail(ctx, SI_ERR_NOMEM, "si_infer_setup: device allocation failed");
   }
@@ -612,7 +627,29 @@ int32_t si_infer_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
   return SI_OK;
 }
 
+// How many chains one forward launch carries.  Small models leave most of the 256 CUs idle with one chain per launch
+// (a 20-wide Dense layer on 1000 observations is 8 workgroups), so independent chains are stacked in grid.y; the
+// workspace for that is capped so that a model whose single chain already fills the chip (cfg2: 1.5 GB of activations
+// per chain) keeps one slot.
+static constexpr double SI_BATCH_BYTES = 2.0 * 1024.0 * 1024.0 * 1024.0;
+static int batch_width(const si_ctx* ctx, int C) {
+  const double per = 8.0 * (2.0 * (double)ctx->act_elems + ((double)ctx->fuse_slots + 1.0) * (double)ctx->out_dim * (double)ctx->B +
+                            (double)pad_ld(ctx->iN) + (double)ctx->sse_blocks);
+  const double fit = std::floor(SI_BATCH_BYTES / per);
+  return (int)std::max(1.0, std::min({(double)C, fit, 1024.0}));
+}
+
 static int32_t ensure_chains(si_ctx* ctx, int32_t C) {
+  const int want = batch_width(ctx, C);
+  if (ctx->fw_slots < want) {
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!alloc_forward(ctx, want)) {
+      if (!alloc_forward(ctx, 1)) {
+        ctx->i_ready = false;
+        return fail(ctx, SI_ERR_NOMEM, "forward workspace allocation failed");
+      }
+    }
+  }
   if (ctx->chains_cap >= C) return SI_OK;
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   dev_free(ctx->d_zcur);
@@ -630,56 +667,75 @@ static int32_t ensure_chains(si_ctx* ctx, int32_t C) {
   return SI_OK;
 }
 
-// one density evaluation for chain slot c: d_zprop[:, c] -> d_sse[c]; optionally leaves the model output in *yhat
-static int32_t eval_density(si_ctx* ctx, int c, const double** yhat_out) {
-  const int64_t N = ctx->iN, B = ctx->B;
+// density evaluations for chain slots [c0, c0 + nc), nc <= fw_slots, in ONE pass of launches:
+// d_zprop[:, c] -> d_sse[c]; with nc == 1 optionally leaves the model output in *yhat
+static int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out) {
+  const int64_t N = ctx->iN, B = ctx->B, ldw = pad_ld(N);
   const int32_t M = ctx->iM;
+  const double dn = (double)nc;
   {
-    ProfScope ps(ctx, SI_K_RECON, 2.0 * (double)N * M, (double)N * (M + 2) * 8.0);
-    launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, ctx->d_zprop + (size_t)c * M, 1, ctx->d_w,
-                       pad_ld(N), ctx->num_cu);
+    ProfScope ps(ctx, SI_K_RECON, 2.0 * (double)N * M * dn, (double)N * (M + 1 + dn) * 8.0);
+    launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, ctx->d_zprop + (size_t)c0 * M, nc, ctx->d_w, ldw,
+                       ctx->num_cu);
   }
+  ChainBatch cb;
+  cb.n = nc;
+  cb.w = ldw;
+  cb.hin = 0;  // X is shared by all chains
+  cb.hout = ctx->act_elems;
+  cb.part = (int64_t)ctx->fuse_slots * ctx->out_dim * B;
   const double* h = ctx->d_X;
   const size_t nl = ctx->layers.size();
   const size_t nstored = ctx->fuse_tail ? nl - 2 : nl;
   for (size_t l = 0; l < nstored; ++l) {
     const si_layer& ly = ctx->layers[l];
     double* o = ctx->d_act[l & 1];
-    const double fl = 2.0 * (double)ly.in * (double)ly.out * (double)B;
-    const double by = ((double)ly.in * ly.out + ly.out + (double)(ly.in + ly.out) * (double)B) * 8.0;
+    const double fl = 2.0 * (double)ly.in * (double)ly.out * (double)B * dn;
+    const double by = ((double)ly.in * ly.out + ly.out + (double)(ly.in + ly.out) * (double)B) * 8.0 * dn;
     {
       ProfScope ps(ctx, SI_K_DENSE, fl, by);
       ProfScope pm((int)l == ctx->main_layer ? ctx : nullptr, SI_K_DENSE_MAIN, fl, by);
-      launch_dense_f64(ctx->stream, ctx->d_w + ly.w_off, ctx->d_w + ly.b_off, h, o, ly.out, ly.in, B, ly.act);
+      launch_dense_f64(ctx->stream, ctx->d_w + ly.w_off, ctx->d_w + ly.b_off, h, o, ly.out, ly.in, B, ly.act, cb);
     }
     h = o;
+    cb.hin = ctx->act_elems;
   }
   const int64_t d = (int64_t)ctx->out_dim * B;
   if (ctx->fuse_tail) {
     const si_layer& ly = ctx->layers[nl - 2];
     const si_layer& ll = ctx->layers[nl - 1];
-    const double fl = 2.0 * (double)ly.in * (double)ly.out * (double)B + 2.0 * (double)ll.in * (double)ll.out * (double)B;
-    const double by = ((double)ly.in * ly.out + ly.out + (double)ly.in * (double)B + (double)ll.in * ll.out) * 8.0 +
-                      (double)ctx->fuse_slots * ll.out * (double)B * 8.0;
+    const double fl = (2.0 * (double)ly.in * (double)ly.out * (double)B + 2.0 * (double)ll.in * (double)ll.out * (double)B) * dn;
+    const double by = (((double)ly.in * ly.out + ly.out + (double)ly.in * (double)B + (double)ll.in * ll.out) * 8.0 +
+                       (double)ctx->fuse_slots * ll.out * (double)B * 8.0) * dn;
     {
       ProfScope ps(ctx, SI_K_DENSE, fl, by);
       ProfScope pm(((int)nl - 2 == ctx->main_layer || (int)nl - 1 == ctx->main_layer) ? ctx : nullptr, SI_K_DENSE_MAIN, fl, by);
       launch_dense_f64_fused(ctx->stream, ctx->d_w + ly.w_off, ctx->d_w + ly.b_off, h, ly.out, ly.in, B, ly.act,
-                             ctx->d_w + ll.w_off, ll.out, ctx->d_part);
+                             ctx->d_w + ll.w_off, ll.out, ctx->d_part, cb);
     }
     {
-      ProfScope ps(ctx, SI_K_SSE, (3.0 + ctx->fuse_slots) * (double)d, (16.0 + 8.0 * ctx->fuse_slots) * (double)d);
+      ProfScope ps(ctx, SI_K_SSE, (3.0 + ctx->fuse_slots) * (double)d * dn, (16.0 + 8.0 * ctx->fuse_slots) * (double)d * dn);
       launch_tail_sse(ctx->stream, ctx->d_part, ctx->fuse_slots, ll.out, B, ctx->d_w + ll.b_off, ll.act, ctx->d_Y,
-                      yhat_out ? ctx->d_yhat : nullptr, ctx->d_ssepart, ctx->sse_blocks);
-      launch_sse_final(ctx->stream, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c);
+                      yhat_out ? ctx->d_yhat : nullptr, ctx->d_ssepart, ctx->sse_blocks, cb);
+      launch_sse_final(ctx->stream, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, nc);
     }
     h = ctx->d_yhat;
   } else {
-    ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d, 16.0 * (double)d);
-    launch_sse(ctx->stream, h, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c);
+    ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d * dn, 16.0 * (double)d * dn);
+    launch_sse(ctx->stream, h, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, nc, ctx->act_elems);
   }
   SI_HIP(ctx, hipGetLastError());
   if (yhat_out) *yhat_out = h;
+  return SI_OK;
+}
+
+// all C chain slots, fw_slots at a time
+static int32_t eval_density_all(si_ctx* ctx, int C) {
+  const int w = std::max(1, ctx->fw_slots);
+  for (int c0 = 0; c0 < C; c0 += w) {
+    const int32_t rc = eval_density(ctx, c0, std::min(w, C - c0), nullptr);
+    if (rc != SI_OK) return rc;
+  }
   return SI_OK;
 }
 
@@ -696,8 +752,7 @@ int32_t si_logdensity(si_ctx* ctx, const double* Z, int32_t C, double* lp_out) {
   int32_t rc = ensure_chains(ctx, C);
   if (rc != SI_OK) return rc;
   SI_HIP(ctx, hipMemcpyAsync(ctx->d_zprop, Z, (size_t)ctx->iM * C * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  for (int c = 0; c < C; ++c)
-    if ((rc = eval_density(ctx, c, nullptr)) != SI_OK) return rc;
+  if ((rc = eval_density_all(ctx, C)) != SI_OK) return rc;
   std::vector<double> sse((size_t)C);
   SI_HIP(ctx, hipMemcpyAsync(sse.data(), ctx->d_sse, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -811,7 +866,7 @@ int32_t si_forward(si_ctx* ctx, const double* z, double* Yhat_out) {
   if (rc != SI_OK) return rc;
   SI_HIP(ctx, hipMemcpyAsync(ctx->d_zprop, z, (size_t)ctx->iM * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   const double* yh = nullptr;
-  if ((rc = eval_density(ctx, 0, &yh)) != SI_OK) return rc;
+  if ((rc = eval_density(ctx, 0, 1, &yh)) != SI_OK) return rc;
   SI_HIP(ctx, hipMemcpyAsync(Yhat_out, yh, (size_t)ctx->out_dim * ctx->B * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SI_OK;
@@ -832,7 +887,7 @@ int32_t si_predict(si_ctx* ctx, const double* Z, int32_t C, const double* Xnew, 
     int sse_blocks;
   } sv{ctx->d_X, ctx->d_Y, ctx->d_act[0], ctx->d_act[1], ctx->d_ssepart, ctx->d_part, ctx->d_yhat,
        ctx->B, ctx->act_elems, ctx->sse_blocks};
-  const int64_t act_elems = sv.act_elems / sv.B * Bn;
+  const int64_t act_elems = pad_ld(ctx->max_stored * Bn);
   const int sse_blocks = sse_num_blocks((int64_t)ctx->out_dim * Bn, ctx->num_cu);
   double *tX = nullptr, *tY = nullptr, *tA0 = nullptr, *tA1 = nullptr, *tS = nullptr, *tP = nullptr, *tYh = nullptr;
   bool ok = dev_alloc(&tX, (size_t)ctx->in_dim * Bn) == hipSuccess && dev_alloc(&tY, (size_t)ctx->out_dim * Bn) == hipSuccess &&
@@ -850,7 +905,7 @@ int32_t si_predict(si_ctx* ctx, const double* Z, int32_t C, const double* Xnew, 
     ctx->d_yhat = tYh; ctx->B = Bn; ctx->act_elems = act_elems; ctx->sse_blocks = sse_blocks;
     for (int c = 0; c < C && e == hipSuccess && rc == SI_OK; ++c) {
       const double* yh = nullptr;
-      rc = eval_density(ctx, c, &yh);
+      rc = eval_density(ctx, c, 1, &yh);
       if (rc == SI_OK)
         e = hipMemcpyAsync(Yhat_out + (size_t)c * ctx->out_dim * Bn, yh, (size_t)ctx->out_dim * Bn * sizeof(double),
                            hipMemcpyDeviceToHost, ctx->stream);
@@ -895,10 +950,8 @@ int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, 
       ProfScope ps(ctx, SI_K_RWMH, 0, 0);
       launch_rwmh_propose(ctx->stream, ctx->d_zcur, ctx->d_zprop, M, C, sigma_z, seed, chain_id0, ctx->d_steps);
     }
-    for (int c = 0; c < C; ++c) {
-      const int32_t r = eval_density(ctx, c, nullptr);
-      if (r != SI_OK) return r;
-    }
+    const int32_t r = eval_density_all(ctx, C);
+    if (r != SI_OK) return r;
     ProfScope ps(ctx, SI_K_RWMH, 0, 0);
     launch_rwmh_accept(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->d_lpcur, ctx->d_sse, ctx->d_nacc, M, C, c0, s2, seed,
                        chain_id0, ctx->d_steps, dZ, dlp, itr);
@@ -972,8 +1025,8 @@ int32_t si_rwmh_step_eval(si_ctx* ctx, double* sse_local_out) {
   const int32_t C = ctx->sw_C;
   launch_rwmh_propose(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->iM, C, ctx->sw_sigma_z, ctx->sw_seed, ctx->sw_chain0,
                       ctx->d_steps);
-  for (int c = 0; c < C; ++c) {
-    const int32_t rc = eval_density(ctx, c, nullptr);
+  {
+    const int32_t rc = eval_density_all(ctx, C);
     if (rc != SI_OK) return rc;
   }
   SI_HIP(ctx, hipMemcpyAsync(sse_local_out, ctx->d_sse, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -49,7 +49,21 @@ template <int BM, int BN, int WM, int WN, int MINW, bool VEC, bool KEDGE, bool F
 __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f64_kernel(
     const double* __restrict__ W, const double* __restrict__ bias, const double* __restrict__ Hin,
     double* __restrict__ Hout, int out, int in, int64_t B, int act, int nMt, int64_t nNt,
-    const double* __restrict__ Wlast, int out_last, double* __restrict__ part) {
+    const double* __restrict__ Wlast, int out_last, double* __restrict__ part, ChainBatch cb) {
+  // chain batching: blockIdx.y is the chain slot; every operand that differs per chain moves by its slot stride
+  // (block-uniform scalar arithmetic; for a single chain all strides are unused)
+  if (blockIdx.y != 0) {
+    const int64_t ch = blockIdx.y;
+    W += ch * cb.w;
+    bias += ch * cb.w;
+    Hin += ch * cb.hin;
+    if constexpr (FUSE) {
+      Wlast += ch * cb.w;
+      part += ch * cb.part;
+    } else {
+      Hout += ch * cb.hout;
+    }
+  }
 #ifdef SI_GEMM_DEBUG_KNOB
   const int dbg = si_gemm_dbg;  // harness only, bit mask: 1 = every block loads tile (0,0) (L2-hot), 2 = no global loads in the k loop,
                                 // 4 = no barrier in the k loop, 8 = no LDS stores in the k loop (4 and 8 give wrong results: timing only)
@@ -378,6 +392,7 @@ struct FuseArgs {
   const double* Wlast = nullptr;  // out_last x out, column-major (the last layer's weights inside the flat vector)
   int out_last = 0;
   double* part = nullptr;         // [slots][out_last][B]
+  ChainBatch cb;                  // chain slots in grid.y
 };
 
 template <int BM, int BN, int WM, int WN, int MINW, bool VEC, bool KEDGE, bool FUSE>
@@ -398,8 +413,8 @@ static void launch_dense_inst(hipStream_t st, const double* W, const double* bia
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, W, bias, Hin, Hout, (int)out, (int)in, B,
-                     (int)act, nMt, nNt, fa.Wlast, fa.out_last, fa.part);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)fa.cb.n), dim3(NT), lds, st, W, bias, Hin, Hout, (int)out,
+                     (int)in, B, (int)act, nMt, nNt, fa.Wlast, fa.out_last, fa.part, fa.cb);
 }
 
 template <int BM, int BN, int WM, int WN, int MINW, bool FUSE = false>
@@ -409,7 +424,8 @@ void launch_dense_cfg(hipStream_t st, const double* W, const double* bias, const
   // weight vector: layer 3 of cfg2 starts at an odd element); a ragged k edge (in % 16 != 0) needs zero-fill
   const bool vec = (out % 2 == 0) && (in % 2 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0) &&
                    ((reinterpret_cast<uintptr_t>(Hin) & 15u) == 0) &&
-                   (FUSE || (((reinterpret_cast<uintptr_t>(Hout) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(bias) & 15u) == 0)));
+                   (FUSE || (((reinterpret_cast<uintptr_t>(Hout) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(bias) & 15u) == 0))) &&
+                   (((fa.cb.w | fa.cb.hin | fa.cb.hout) & 1) == 0);
   const bool kedge = (in % 16) != 0;
   if (vec && !kedge)
     launch_dense_inst<BM, BN, WM, WN, MINW, true, false, FUSE>(st, W, bias, Hin, Hout, out, in, B, act, fa);
@@ -435,12 +451,14 @@ static int pick_bm(int32_t out) {
 }
 
 void launch_dense_f64(hipStream_t st, const double* W, const double* bias, const double* Hin,
-                      double* Hout, int32_t out, int32_t in, int64_t B, int32_t act) {
+                      double* Hout, int32_t out, int32_t in, int64_t B, int32_t act, const ChainBatch& cb) {
+  FuseArgs fa;
+  fa.cb = cb;
   switch (pick_bm(out)) {
-    case 32: launch_dense_cfg<32, 128, 1, 4, 2>(st, W, bias, Hin, Hout, out, in, B, act); break;
-    case 96: launch_dense_cfg<96, 128, 2, 4, 4>(st, W, bias, Hin, Hout, out, in, B, act); break;
-    case 128: launch_dense_cfg<128, 128, 2, 4, 4>(st, W, bias, Hin, Hout, out, in, B, act); break;
-    default: launch_dense_cfg<64, 128, 2, 4, 4>(st, W, bias, Hin, Hout, out, in, B, act); break;
+    case 32: launch_dense_cfg<32, 128, 1, 4, 2>(st, W, bias, Hin, Hout, out, in, B, act, fa); break;
+    case 96: launch_dense_cfg<96, 128, 2, 4, 4>(st, W, bias, Hin, Hout, out, in, B, act, fa); break;
+    case 128: launch_dense_cfg<128, 128, 2, 4, 4>(st, W, bias, Hin, Hout, out, in, B, act, fa); break;
+    default: launch_dense_cfg<64, 128, 2, 4, 4>(st, W, bias, Hin, Hout, out, in, B, act, fa); break;
   }
 }
 
@@ -452,11 +470,13 @@ int dense_fused_slots(int32_t out) {
 }
 
 void launch_dense_f64_fused(hipStream_t st, const double* W, const double* bias, const double* Hin, int32_t out,
-                            int32_t in, int64_t B, int32_t act, const double* Wlast, int32_t out_last, double* part) {
+                            int32_t in, int64_t B, int32_t act, const double* Wlast, int32_t out_last, double* part,
+                            const ChainBatch& cb) {
   FuseArgs fa;
   fa.Wlast = Wlast;
   fa.out_last = out_last;
   fa.part = part;
+  fa.cb = cb;
   switch (pick_bm(out)) {
     case 32: launch_dense_cfg<32, 128, 1, 4, 2, true>(st, W, bias, Hin, nullptr, out, in, B, act, fa); break;
     case 96: launch_dense_cfg<96, 128, 2, 4, 4, true>(st, W, bias, Hin, nullptr, out, in, B, act, fa); break;
@@ -473,10 +493,17 @@ void launch_dense_f64_fused(hipStream_t st, const double* W, const double* bias,
 __global__ __launch_bounds__(256) void tail_sse_kernel(const double* __restrict__ part, int slots, int out_last,
                                                        int64_t B, const double* __restrict__ bias_last, int act_last,
                                                        const double* __restrict__ Y, double* __restrict__ yhat,
-                                                       double* __restrict__ blockpart) {
+                                                       double* __restrict__ blockpart, ChainBatch cb) {
   __shared__ double red[4];
   double accv = 0.0;
   const int64_t d = (int64_t)out_last * B;
+  {  // chain slot in grid.y: own partial products, last-layer bias, output and block partials; Y is shared
+    const int64_t ch = blockIdx.y;
+    part += ch * cb.part;
+    bias_last += ch * cb.w;
+    if (yhat) yhat += ch * d;
+    blockpart += ch * gridDim.x;
+  }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < d; idx += stride) {
     const int o = (int)(idx % out_last);
@@ -500,9 +527,9 @@ __global__ __launch_bounds__(256) void tail_sse_kernel(const double* __restrict_
 }
 
 void launch_tail_sse(hipStream_t st, const double* part, int slots, int out_last, int64_t B, const double* bias_last,
-                     int act_last, const double* Y, double* yhat, double* blockpart, int nblocks) {
-  hipLaunchKernelGGL(tail_sse_kernel, dim3(nblocks), dim3(256), 0, st, part, slots, out_last, B, bias_last, act_last, Y,
-                     yhat, blockpart);
+                     int act_last, const double* Y, double* yhat, double* blockpart, int nblocks, const ChainBatch& cb) {
+  hipLaunchKernelGGL(tail_sse_kernel, dim3(nblocks, cb.n), dim3(256), 0, st, part, slots, out_last, B, bias_last,
+                     act_last, Y, yhat, blockpart, cb);
 }
 #endif
 

@@ -253,9 +253,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 __global__ __launch_bounds__(256) void sse_partial_kernel(const double* __restrict__ yhat,
                                                           const double* __restrict__ y, int64_t d,
-                                                          double* __restrict__ part) {
+                                                          double* __restrict__ part, int64_t yhat_stride) {
   __shared__ double red[4];
   double acc = 0.0;
+  yhat += (int64_t)blockIdx.y * yhat_stride;  // chain slot
+  part += (int64_t)blockIdx.y * gridDim.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d; i += stride) {
     const double r = y[i] - yhat[i];
@@ -271,11 +273,12 @@ __global__ __launch_bounds__(256) void sse_final_kernel(const double* __restrict
                                                         double* __restrict__ out) {
   __shared__ double red[4];
   double acc = 0.0;
+  part += (int64_t)blockIdx.x * n;  // one block per chain slot
   for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 int sse_num_blocks(int64_t d, int num_cu) {
@@ -285,14 +288,14 @@ int sse_num_blocks(int64_t d, int num_cu) {
   return (int)b;
 }
 
-void launch_sse_final(hipStream_t st, const double* blockpart, int nblocks, double* sse_out) {
-  hipLaunchKernelGGL(sse_final_kernel, dim3(1), dim3(256), 0, st, blockpart, nblocks, sse_out);
+void launch_sse_final(hipStream_t st, const double* blockpart, int nblocks, double* sse_out, int nch) {
+  hipLaunchKernelGGL(sse_final_kernel, dim3(nch), dim3(256), 0, st, blockpart, nblocks, sse_out);
 }
 
 void launch_sse(hipStream_t st, const double* yhat, const double* y, int64_t d, double* part,
-                int nblocks, double* sse_out) {
-  hipLaunchKernelGGL(sse_partial_kernel, dim3(nblocks), dim3(256), 0, st, yhat, y, d, part);
-  hipLaunchKernelGGL(sse_final_kernel, dim3(1), dim3(256), 0, st, part, nblocks, sse_out);
+                int nblocks, double* sse_out, int nch, int64_t yhat_stride) {
+  hipLaunchKernelGGL(sse_partial_kernel, dim3(nblocks, nch), dim3(256), 0, st, yhat, y, d, part, yhat_stride);
+  hipLaunchKernelGGL(sse_final_kernel, dim3(nch), dim3(256), 0, st, part, nblocks, sse_out);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -88,14 +88,16 @@ struct Ctx {
   int32_t in_dim = 0, out_dim = 0;
   int64_t B = 0;
   double sigma_m = 1.0;
-  double* d_w = nullptr;       // reconstructed weights, N
-  double* d_act[2] = {nullptr, nullptr};  // ping-pong activations, maxwidth x B
-  int64_t act_elems = 0;
-  double* d_ssepart = nullptr;  // per-block SSE partials
+  // forward workspace: `fw_slots` chain slots (1 after si_infer_setup; grown by ensure_batch for multi-chain calls)
+  int fw_slots = 0;
+  double* d_w = nullptr;       // reconstructed weights, fw_slots x pad_ld(N)
+  double* d_act[2] = {nullptr, nullptr};  // ping-pong activations, fw_slots x act_elems (maxwidth x B padded)
+  int64_t act_elems = 0, max_stored = 0;  // act_elems = pad_ld(max_stored * B): slot stride of d_act
+  double* d_ssepart = nullptr;  // per-block SSE partials, fw_slots x sse_blocks
   bool fuse_tail = false;       // last layer folded into the epilogue of the layer in front of it
   int fuse_slots = 0;
-  double* d_part = nullptr;     // [slots][out_last][B] partial last-layer products
-  double* d_yhat = nullptr;     // out_dim x B, only filled on request (si_forward)
+  double* d_part = nullptr;     // fw_slots x [slots][out_last][B] partial last-layer products
+  double* d_yhat = nullptr;     // fw_slots x out_dim x B, only filled on request (si_forward)
   int sse_blocks = 0;
   int main_layer = 0;
   // gradient workspace (allocated on the first si_logdensity_grad)
@@ -163,23 +165,34 @@ void launch_project(hipStream_t st, const double* A, int64_t ldA, int64_t N, int
 // K4: w[c*ldw + r] = swa[r] + sum_m P[r + m*ldP] * Z[m + c*M]
 void launch_reconstruct(hipStream_t st, const double* swa, const double* P, int64_t ldP, int64_t N,
                         int32_t M, const double* Z, int32_t C, double* w, int64_t ldw, int num_cu);
+// Chain batching of the forward pass: `n` chain slots run in ONE launch (grid.y = slot).  Strides, in elements, from
+// one slot to the next: `w` of the reconstructed weight vectors (W, bias, Wlast all live in it), `hin` / `hout` of
+// the layer's input / output activations (hin = 0 for the first layer: X is shared), `part` of the fused-tail partials.
+struct ChainBatch {
+  int n = 1;
+  int64_t w = 0, hin = 0, hout = 0, part = 0;
+};
 // K5: Hout[i + out*b] = act(sum_k W[i + out*k] * Hin[k + in*b] + bias[i])
 void launch_dense_f64(hipStream_t st, const double* W, const double* bias, const double* Hin,
-                      double* Hout, int32_t out, int32_t in, int64_t B, int32_t act);
+                      double* Hout, int32_t out, int32_t in, int64_t B, int32_t act, const ChainBatch& cb = ChainBatch());
 // K5 fused tail: the layer in front of a narrow (out_last <= SI_FUSE_MAX_OUT) last layer does not store its output;
 // it writes per-slot partial products with the last layer's weights, summed by launch_tail_sse (block partials of
 // (y - yhat)^2 to `blockpart`, to be finished by sse_final via launch_sse_final)
 constexpr int SI_FUSE_MAX_OUT = 4;
 int dense_fused_slots(int32_t out);
 void launch_dense_f64_fused(hipStream_t st, const double* W, const double* bias, const double* Hin, int32_t out,
-                            int32_t in, int64_t B, int32_t act, const double* Wlast, int32_t out_last, double* part);
+                            int32_t in, int64_t B, int32_t act, const double* Wlast, int32_t out_last, double* part,
+                            const ChainBatch& cb = ChainBatch());
 void launch_tail_sse(hipStream_t st, const double* part, int slots, int out_last, int64_t B, const double* bias_last,
-                     int act_last, const double* Y, double* yhat, double* blockpart, int nblocks);
-void launch_sse_final(hipStream_t st, const double* blockpart, int nblocks, double* sse_out);
+                     int act_last, const double* Y, double* yhat, double* blockpart, int nblocks,
+                     const ChainBatch& cb = ChainBatch());
+// sse_out[ch] = sum of blockpart[ch*nblocks .. +nblocks) for ch < nch
+void launch_sse_final(hipStream_t st, const double* blockpart, int nblocks, double* sse_out, int nch = 1);
 // K5: sse = sum (y - yhat)^2 over d elements; deterministic two-stage
 int sse_num_blocks(int64_t d, int num_cu);
+// (nch chain slots: yhat advances by yhat_stride per slot, y is shared, part holds nch*nblocks partials)
 void launch_sse(hipStream_t st, const double* yhat, const double* y, int64_t d, double* part,
-                int nblocks, double* sse_out);
+                int nblocks, double* sse_out, int nch = 1, int64_t yhat_stride = 0);
 // backward pass (kernels_bwd.hip): gradient of the log-density w.r.t. the flat weights and its pull-back P' g
 void launch_backward_data(hipStream_t st, const double* W, const double* Delta, const double* Hprev, double* DeltaPrev,
                           int32_t out, int32_t in, int64_t B, int32_t act_prev);

@@ -196,6 +196,39 @@ def test_forward_and_logdensity(gpu_ctx, dims, acts, b, m):
     assert np.allclose(w, w_ref, rtol=1e-13, atol=1e-14)
 
 
+@pytest.mark.parametrize("dims,acts,b,m", [
+    ([10, 20, 20, 2], [0, 0, 0], 100, 3),                 # fused tail, three layers
+    ([2, 200, 50, 50, 50, 1], [1, 1, 1, 1, 0], 333, 5),   # fused tail after stored layers (ping-pong slot strides)
+    ([6, 40, 8], [1, 0], 300, 3),                         # unfused tail
+    ([10, 5], [2], 77, 2),                                # single layer: X shared by all slots
+    ([3, 100, 97, 2], [1, 2, 3], 130, 4),                 # odd widths: scalar staging with slot strides
+])
+def test_chain_batched_density_is_bit_identical(gpu_ctx, dims, acts, b, m):
+    """Independent chains stacked in grid.y of ONE forward pass (capi.hip eval_density, ChainBatch) give exactly the
+    bits of one-chain-at-a-time evaluation, and agree with the oracle."""
+    table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=11 + sum(dims))
+    gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=0.9)
+    c = 37
+    zs = np.asfortranarray(np.random.default_rng(5).standard_normal((m, c)))
+    lp_single = np.array([gpu_ctx.logdensity(np.asfortranarray(zs[:, j:j + 1]))[0] for j in range(c)])  # one slot
+    lp_batch = gpu_ctx.logdensity(zs)                                                                    # 37 slots
+    assert np.array_equal(lp_batch, lp_single)
+    lp_ref = np.array([so.logdensity(table, w_swa, p, x, y, 0.9, zs[:, j]) for j in range(0, c, 9)])
+    assert np.allclose(lp_batch[::9], lp_ref, rtol=1e-11)
+    # the batched workspace must not disturb the single-slot calls that follow
+    yhat = gpu_ctx.forward(zs[:, 3])
+    assert np.allclose(yhat, so.forward(table, so.reconstruct(w_swa, p, zs[:, 3]), x), rtol=1e-10, atol=1e-11)
+    xn = np.asfortranarray(np.random.default_rng(6).standard_normal((dims[0], 41)))
+    yp = gpu_ctx.predict(zs[:, :4], xn)
+    for j in range(4):
+        assert np.allclose(yp[:, :, j], so.forward(table, so.reconstruct(w_swa, p, zs[:, j]), xn), rtol=1e-10, atol=1e-11)
+    # chains: 5 stacked chains == the same chains run one at a time
+    z5, lp5, acc5 = gpu_ctx.sample_rwmh(25, 0.05, seed=3, chain_id0=0, nchains=5)
+    for j in (0, 4):
+        z1, lp1, acc1 = gpu_ctx.sample_rwmh(25, 0.05, seed=3, chain_id0=j, nchains=1)
+        assert np.array_equal(z5[:, :, j], z1[:, :, 0]) and np.array_equal(lp5[:, j], lp1[:, 0]) and acc5[j] == acc1[0]
+
+
 @pytest.mark.parametrize("dims,acts", [([10, 20, 20, 2], [0, 0, 0]), ([6, 40, 8], [1, 0]), ([4, 50, 1], [2, 0])])
 def test_predict_new_inputs(gpu_ctx, dims, acts):
     table, n, w_swa, p, x, y = _random_problem(dims, acts, 64, 3, seed=21)
@@ -599,3 +632,20 @@ def test_conditioning_limits_of_the_gram_route(si, gpu_ctx):
     # ... while the well-resolved leading part is still delivered
     w_swa, p, s, _ = gpu_ctx.construct_finish(4)
     assert np.allclose(s, np.logspace(0, -10, k)[:4], rtol=1e-4)
+
+def test_api_multi_chain(si, gpu_ctx):
+    from subspaceinference_jl_amd import flux
+    rng = np.random.default_rng(0)
+    model = flux.Chain(flux.Dense(4, 8, "relu", rng=rng), flux.Dense(8, 1, rng=rng))
+    x, y = rng.standard_normal((4, 50)), rng.standard_normal((1, 50))
+    data = flux.DataLoader(x, y, batchsize=50)
+    _, n = flux.layer_table(model)
+    w_swa, p = 0.1 * rng.standard_normal(n), 0.05 * rng.standard_normal((n, 3))
+    z, lp = si.sub_inference(model, data, w_swa, p, σ_z=0.1, itr=12, M=3, ctx=gpu_ctx, seed=5, nchains=4, return_z=True)
+    assert z.shape == (3, 12, 4) and lp.shape == (12, 4)
+    z1, lp1 = si.sub_inference(model, data, w_swa, p, σ_z=0.1, itr=12, M=3, ctx=gpu_ctx, seed=5, chain_id=2, return_z=True)
+    assert np.array_equal(z[:, :, 2], z1) and np.array_equal(lp[:, 2], lp1)
+    chn, _ = si.sub_inference(model, data, w_swa, p, σ_z=0.1, itr=12, M=3, ctx=gpu_ctx, seed=5, nchains=4)
+    assert len(chn) == 4 and len(chn[0]) == 12 and np.allclose(chn[2][5], w_swa + p @ z[:, 5, 2], rtol=1e-13)
+    with pytest.raises(si.SubspaceError):
+        si.sub_inference(model, data, w_swa, p, itr=5, M=3, ctx=gpu_ctx, alg="hmc", nchains=2)
