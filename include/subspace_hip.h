@@ -178,6 +178,19 @@ int32_t si_train_step(si_ctx* ctx, const int64_t* idx /* nb observation indices,
 /* :45-52 with W taken in place from the device-resident Float32 weights (no extract_params, no PCIe) */
 int32_t si_train_push(si_ctx* ctx, double n);
 int32_t si_train_get_weights(si_ctx* ctx, float* w_out /* N */);
+/* Data-parallel form of si_train_step (one gradient all-reduce per step).  Every rank holds the same
+ * weights / optimiser state and its own nb of the nb_total observations of the batch:
+ *   si_train_grad   forward + reverse sweep; leaves  d mse(whole batch)/dw  restricted to this rank's observations
+ *                   (i.e. scaled by 1/(out_dim*nb_total)) in a device buffer and returns the local SSE;
+ *   the caller sums that buffer over the ranks IN PLACE: RCCL all-reduce on the device pointer of si_train_grad_ptr
+ *                   (N doubles; valid until the next si_train_setup), or si_train_grad_get / _set through the host;
+ *   si_train_apply  Flux.update!(opt, ps, gs) (:43) from the summed gradient.
+ * With nb_total == nb and no exchange, grad + apply is exactly si_train_step.                                       */
+int32_t si_train_grad(si_ctx* ctx, const int64_t* idx, int64_t nb, int64_t nb_total, double* sse_local_out /* may be NULL */);
+int32_t si_train_grad_ptr(si_ctx* ctx, double** grad_dev_out, int64_t* n_out);
+int32_t si_train_grad_get(si_ctx* ctx, double* g_out /* N */);
+int32_t si_train_grad_set(si_ctx* ctx, const double* g_in /* N */);
+int32_t si_train_apply(si_ctx* ctx);
 
 /* ---- host utility (no GPU needed): the K x K symmetric eigensolver used inside si_construct_finish.
  * a: n x n symmetric column-major, overwritten by the eigenvectors (columns); w: eigenvalues ascending. */

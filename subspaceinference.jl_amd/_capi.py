@@ -82,6 +82,11 @@ SIGNATURES = {
     "si_train_step": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "si_train_push": (c_int32, [c_void_p, c_double]),
     "si_train_get_weights": (c_int32, [c_void_p, c_void_p]),
+    "si_train_grad": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "si_train_grad_ptr": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "si_train_grad_get": (c_int32, [c_void_p, c_void_p]),
+    "si_train_grad_set": (c_int32, [c_void_p, c_void_p]),
+    "si_train_apply": (c_int32, [c_void_p]),
     "si_host_sym_eig": (c_int, [c_int, c_void_p, c_void_p]),
 }
 
@@ -248,12 +253,44 @@ class Context:
                                             y.shape[0], x.shape[1], int(batch_max), int(opt_kind), float(eta), float(p1),
                                             float(p2)))
         self._tn = int(n)
+        self._tout = int(y.shape[0])
 
     def train_step(self, idx, want_loss=True):
         idx = np.ascontiguousarray(idx, dtype=np.int64)
         loss = np.empty(1, dtype=np.float64) if want_loss else None
         self._check(self.lib.si_train_step(self.h, _ptr(idx), idx.size, _ptr(loss)))
         return float(loss[0]) if want_loss else None
+
+    # data-parallel form: grad -> (caller's all-reduce) -> apply
+    def train_grad(self, idx, nb_total):
+        """Gradient of mse over the WHOLE batch (nb_total observations) restricted to this rank's idx; returns local SSE."""
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        sse = np.empty(1, dtype=np.float64)
+        self._check(self.lib.si_train_grad(self.h, _ptr(idx), idx.size, int(nb_total), _ptr(sse)))
+        return float(sse[0])
+
+    def train_grad_ptr(self):
+        """(device address, element count) of the fp64 gradient buffer, for an in-place RCCL all-reduce."""
+        ptr, n = c_void_p(), c_int64()
+        self._check(self.lib.si_train_grad_ptr(self.h, byref(ptr), byref(n)))
+        return int(ptr.value), int(n.value)
+
+    def train_grad_get(self):
+        g = np.empty(self._tn, dtype=np.float64)
+        self._check(self.lib.si_train_grad_get(self.h, _ptr(g)))
+        return g
+
+    def train_grad_set(self, g):
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        if g.size != self._tn:
+            raise SubspaceError("DimensionMismatch: gradient of %d elements for %d weights" % (g.size, self._tn))
+        self._check(self.lib.si_train_grad_set(self.h, _ptr(g)))
+
+    def train_apply(self):
+        self._check(self.lib.si_train_apply(self.h))
+
+    def train_out_dim(self):
+        return self._tout
 
     def train_push(self, n):
         self._check(self.lib.si_train_push(self.h, float(n)))

@@ -13,7 +13,7 @@ Python identifiers may be Greek, so `σ_z=` works as in Julia; `sigma_z=` is acc
 """
 import numpy as np
 
-from . import flux, samplers
+from . import dist, flux, samplers
 from ._capi import Context, SubspaceError
 
 _RWMH_ALGS = ("rwmh", "mh")
@@ -40,6 +40,11 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
     Momentum / ADAM, the training step itself (:39-43) also runs on the GPU (si_train_step: forward, reverse sweep,
     optimiser) and the weights are pushed in place (si_train_push) -- no weight vector crosses PCIe.  The model's
     arrays receive the trained weights at the end, like Flux's in-place `update!`.
+
+    Under a torch.distributed process group (one process per GPU, dist.init) the device training step is
+    data-parallel: every rank must be called with the same model, data and DataLoader seed; each takes its share
+    of every batch and the gradient is all-reduced once per step (dist.train_step_data_parallel), so all ranks
+    return the same (W_swa, P).
     """
     ps = flux.params(model)
     n_par = int(sum(p.size for p in ps))
@@ -56,6 +61,7 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
     try:
         ctx.construct_begin(n_par, n_push, max_cols)
         training_loss = 0.0
+        dp_rank, dp_world = dist.world() if use_dev else (0, 1)
         if use_dev:
             table, _ = flux.layer_table(model)
             bmax = min(data.batchsize, data.nobs)
@@ -65,7 +71,12 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
                 last = (i % print_freq == 0) or (i == T)
                 batches = list(data.index_batches())
                 for j, ids in enumerate(batches):
-                    loss = ctx.train_step(ids, want_loss=last and j == len(batches) - 1)
+                    if dp_world > 1:
+                        # data-parallel step: this rank's share of the batch, one gradient all-reduce (dist.py)
+                        c0, c1 = dist.col_shard(len(ids), dp_rank, dp_world)
+                        loss = dist.train_step_data_parallel(ctx, np.asarray(ids)[c0:c1], len(ids))
+                    else:
+                        loss = ctx.train_step(ids, want_loss=last and j == len(batches) - 1)
                     if loss is not None:
                         training_loss = loss
                     if i % c == 0:

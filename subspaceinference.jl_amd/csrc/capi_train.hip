@@ -6,6 +6,7 @@
 // leave the GPU: si_train_push feeds K1 from the device-resident Float32 vector.
 #include <algorithm>
 #include <cmath>
+#include <string>
 
 #include "si_internal.h"
 
@@ -141,13 +142,16 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
   return SI_OK;
 }
 
-int32_t si_train_step(si_ctx* ctx, const int64_t* idx, int64_t nb, double* loss_out) {
-  if (!ctx) return SI_ERR_INVALID;
+// forward + reverse sweep of the mse cost on the observations idx[0..nb): the gradient w.r.t. the flat weights, scaled
+// as if the batch were part of d_total = out_dim * (observations of the WHOLE batch), is left in t->gw; t->sse holds the
+// local sum of squared errors
+static int32_t train_gradient(si_ctx* ctx, const char* who, const int64_t* idx, int64_t nb, double d_total) {
   TrainState* t = ctx->train;
-  if (!t) return fail(ctx, SI_ERR_STATE, "si_train_step: call si_train_setup first");
-  if (!idx || nb <= 0 || nb > t->Bmax) return fail(ctx, SI_ERR_INVALID, "si_train_step: bad batch");
+  if (!t) return fail(ctx, SI_ERR_STATE, std::string(who) + ": call si_train_setup first");
+  if (!idx || nb <= 0 || nb > t->Bmax) return fail(ctx, SI_ERR_INVALID, std::string(who) + ": bad batch");
   for (int64_t j = 0; j < nb; ++j)
-    if (idx[j] < 0 || idx[j] >= t->Btot) return fail(ctx, SI_ERR_INVALID, "si_train_step: BoundsError: batch index out of range");
+    if (idx[j] < 0 || idx[j] >= t->Btot)
+      return fail(ctx, SI_ERR_INVALID, std::string(who) + ": BoundsError: batch index out of range");
   SI_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int64_t N = t->N;
@@ -175,7 +179,7 @@ int32_t si_train_step(si_ctx* ctx, const int64_t* idx, int64_t nb, double* loss_
     SI_HIP(ctx, hipMemsetAsync(t->gw, 0, (size_t)pad_ld(N) * sizeof(double), st));
     int cur = 0;
     // d mse / d yhat = 2 (yhat - y) / d
-    launch_delta_out(st, t->Yb, h, d, -2.0 / (double)d, t->layers[nl - 1].act, t->delta[cur]);
+    launch_delta_out(st, t->Yb, h, d, -2.0 / d_total, t->layers[nl - 1].act, t->delta[cur]);
     for (size_t li = nl; li-- > 0;) {
       const si_layer& ly = t->layers[li];
       const double* hprev = li > 0 ? t->hs[li - 1] : t->Xb;
@@ -190,21 +194,99 @@ int32_t si_train_step(si_ctx* ctx, const int64_t* idx, int64_t nb, double* loss_
         cur ^= 1;
       }
     }
-    hipLaunchKernelGGL(optimiser_kernel, dim3(grid_for(N, ctx->num_cu)), dim3(256), 0, st, t->w32, t->m32, t->v32, t->gw,
-                       N, t->opt, t->eta, t->p1, t->p2, t->bp1, t->bp2);
   }
+  SI_HIP(ctx, hipGetLastError());
+  t->grad_ready = true;
+  return SI_OK;
+}
+
+// Flux.update!(opt, ps, gs) from the gradient in t->gw
+static int32_t train_apply(si_ctx* ctx) {
+  TrainState* t = ctx->train;
+  hipLaunchKernelGGL(optimiser_kernel, dim3(grid_for(t->N, ctx->num_cu)), dim3(256), 0, ctx->stream, t->w32, t->m32, t->v32,
+                     t->gw, t->N, t->opt, t->eta, t->p1, t->p2, t->bp1, t->bp2);
   SI_HIP(ctx, hipGetLastError());
   if (t->opt == 2) {
     t->bp1 *= t->p1;
     t->bp2 *= t->p2;
   }
+  t->grad_ready = false;
+  return SI_OK;
+}
+
+int32_t si_train_step(si_ctx* ctx, const int64_t* idx, int64_t nb, double* loss_out) {
+  if (!ctx) return SI_ERR_INVALID;
+  TrainState* t = ctx->train;
+  const double d = t ? (double)t->out_dim * (double)nb : 1.0;
+  int32_t rc = train_gradient(ctx, "si_train_step", idx, nb, d);
+  if (rc != SI_OK) return rc;
+  ProfScope ps(ctx, SI_K_BACKWARD, 0.0, 0.0);
+  if ((rc = train_apply(ctx)) != SI_OK) return rc;
   if (loss_out) {
     double sse = 0.0;
-    SI_HIP(ctx, hipMemcpyAsync(&sse, t->sse, sizeof(double), hipMemcpyDeviceToHost, st));
-    SI_HIP(ctx, hipStreamSynchronize(st));
-    *loss_out = sse / (double)d;  // mse of the batch BEFORE the update, as Zygote's forward value
+    SI_HIP(ctx, hipMemcpyAsync(&sse, t->sse, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *loss_out = sse / d;  // mse of the batch BEFORE the update, as Zygote's forward value
   }
   return SI_OK;
+}
+
+// ---- data-parallel form of the same step ("add one gradient all-reduce per step"): every rank holds the
+// same weights / optimiser state and its own share of the batch.  si_train_grad leaves d(mse over the WHOLE batch)/dw
+// restricted to this rank's observations in a device buffer, the caller sums that buffer over the ranks IN PLACE
+// (RCCL all-reduce on the pointer from si_train_grad_ptr; or _get/_set through the host), si_train_apply updates.
+int32_t si_train_grad(si_ctx* ctx, const int64_t* idx, int64_t nb, int64_t nb_total, double* sse_local_out) {
+  if (!ctx) return SI_ERR_INVALID;
+  if (nb_total < nb) return fail(ctx, SI_ERR_INVALID, "si_train_grad: nb_total < nb");
+  TrainState* t = ctx->train;
+  const double d_total = t ? (double)t->out_dim * (double)nb_total : 1.0;
+  if (t && nb == 0 && nb_total > 0) {  // a rank without a share of a small batch contributes a zero gradient
+    SI_HIP(ctx, hipSetDevice(ctx->device));
+    SI_HIP(ctx, hipMemsetAsync(t->gw, 0, (size_t)pad_ld(t->N) * sizeof(double), ctx->stream));
+    SI_HIP(ctx, hipMemsetAsync(t->sse, 0, sizeof(double), ctx->stream));
+    t->grad_ready = true;
+    if (sse_local_out) *sse_local_out = 0.0;
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SI_OK;
+  }
+  const int32_t rc = train_gradient(ctx, "si_train_grad", idx, nb, d_total);
+  if (rc != SI_OK) return rc;
+  if (sse_local_out) SI_HIP(ctx, hipMemcpyAsync(sse_local_out, t->sse, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the gradient is complete when the caller starts its collective
+  return SI_OK;
+}
+
+int32_t si_train_grad_ptr(si_ctx* ctx, double** grad_dev_out, int64_t* n_out) {
+  if (!ctx) return SI_ERR_INVALID;
+  if (!ctx->train || !grad_dev_out || !n_out) return fail(ctx, SI_ERR_STATE, "si_train_grad_ptr: no training state / NULL output");
+  *grad_dev_out = ctx->train->gw;
+  *n_out = ctx->train->N;
+  return SI_OK;
+}
+
+int32_t si_train_grad_get(si_ctx* ctx, double* g_out) {
+  if (!ctx) return SI_ERR_INVALID;
+  if (!ctx->train || !ctx->train->grad_ready || !g_out) return fail(ctx, SI_ERR_STATE, "si_train_grad_get: no gradient pending / NULL output");
+  SI_HIP(ctx, hipSetDevice(ctx->device));
+  SI_HIP(ctx, hipMemcpyAsync(g_out, ctx->train->gw, (size_t)ctx->train->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+int32_t si_train_grad_set(si_ctx* ctx, const double* g_in) {
+  if (!ctx) return SI_ERR_INVALID;
+  if (!ctx->train || !ctx->train->grad_ready || !g_in) return fail(ctx, SI_ERR_STATE, "si_train_grad_set: no gradient pending / NULL input");
+  SI_HIP(ctx, hipSetDevice(ctx->device));
+  SI_HIP(ctx, hipMemcpyAsync(ctx->train->gw, g_in, (size_t)ctx->train->N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+int32_t si_train_apply(si_ctx* ctx) {
+  if (!ctx) return SI_ERR_INVALID;
+  if (!ctx->train || !ctx->train->grad_ready) return fail(ctx, SI_ERR_STATE, "si_train_apply: no gradient pending (call si_train_grad)");
+  SI_HIP(ctx, hipSetDevice(ctx->device));
+  return train_apply(ctx);
 }
 
 int32_t si_train_push(si_ctx* ctx, double n) {

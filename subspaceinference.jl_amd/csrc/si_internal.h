@@ -36,6 +36,7 @@ struct TrainState {
   int sse_blocks = 0;
   int opt = 0;
   double eta = 0.0, p1 = 0.0, p2 = 0.0, bp1 = 0.0, bp2 = 0.0;
+  bool grad_ready = false;  // gw holds a gradient that has not been applied yet
 };
 
 struct Ctx {

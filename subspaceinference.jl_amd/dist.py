@@ -15,12 +15,13 @@ import os
 import numpy as np
 
 
-def init(backend=None, device=None):
-    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.  Returns (rank, world)."""
+def init(backend=None, device=None, force=False):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.  Returns (rank, world).
+    A world of one joins no group unless `force` (used to rehearse the RCCL path on a single GPU)."""
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
@@ -35,6 +36,9 @@ def init(backend=None, device=None):
 
 
 def _dist():
+    import sys
+    if "torch.distributed" not in sys.modules:  # never imported => no process group; keeps torch out of 1-GPU runs
+        return None
     import torch.distributed as dist
     return dist if dist.is_available() and dist.is_initialized() else None
 
@@ -131,6 +135,36 @@ def sample_data_sharded(ctx, itr, sigma_z, seed, d_total, chain_id0=0, nchains=1
     for _ in range(itr):
         ctx.rwmh_step_accept(allreduce_sum(ctx.rwmh_step_eval()))
     return ctx.rwmh_end()
+
+
+class _DeviceBuffer:
+    """Zero-copy view of a device buffer owned by the HIP library (`__cuda_array_interface__`), so that
+    torch.distributed can all-reduce it in place over RCCL."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def train_step_data_parallel(ctx, idx_local, nb_total):
+    """One data-parallel `gradient(ps) do cost(model, d...) end; Flux.update!(opt, ps, gs)` (src/subspace_construction.jl:
+    39-43, SURVEY 8e last paragraph): `idx_local` are this rank's observations of the batch of `nb_total`; every rank
+    holds the same weights and optimiser state before and after.  The only exchange is ONE all-reduce(sum) of the
+    N-double gradient -- in place on the library's device buffer over RCCL, through host staging under gloo -- plus the
+    8-byte SSE.  Returns the mse of the whole batch before the update."""
+    d = _dist()
+    sse = ctx.train_grad(idx_local, nb_total)
+    if d is not None:
+        if d.get_backend() == "nccl":
+            import torch
+            ptr, n = ctx.train_grad_ptr()
+            g = torch.as_tensor(_DeviceBuffer(ptr, n), device="cuda")  # si_train_grad has synchronised the library's stream
+            d.all_reduce(g, op=d.ReduceOp.SUM)
+            torch.cuda.current_stream().synchronize()                 # RCCL ran on torch's stream
+        else:
+            ctx.train_grad_set(allreduce_sum(ctx.train_grad_get()))
+        sse = float(allreduce_sum(np.array([sse]))[0])
+    ctx.train_apply()
+    return sse / (ctx.train_out_dim() * nb_total)
 
 
 def sample_chains(ctx, nchains_total, itr, sigma_z, seed):

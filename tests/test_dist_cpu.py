@@ -67,6 +67,30 @@ class FakeCtx:
     def rwmh_end(self):
         return self.sw["zs"], self.sw["lps"], np.array([self.sw["nacc"] / max(1, self.sw["itr"] - 1)])
 
+    # --- data-parallel training step (mirrors si_train_grad / _grad_get / _grad_set / _apply) on a linear model
+    # yhat = W x with plain gradient descent; the full-batch result is checked in closed form by the caller
+    def set_linear(self, w, x_all, y_all, eta):
+        self.lw, self.lx, self.ly, self.eta, self.lg = np.array(w, dtype=np.float64), x_all, y_all, eta, None
+
+    def train_out_dim(self):
+        return self.ly.shape[0]
+
+    def train_grad(self, idx, nb_total):
+        x, y = self.lx[:, idx], self.ly[:, idx]
+        r = self.lw @ x - y
+        self.lg = (2.0 / (y.shape[0] * nb_total)) * (r @ x.T)
+        return float(np.sum(r * r))
+
+    def train_grad_get(self):
+        return self.lg.ravel(order="F").copy()
+
+    def train_grad_set(self, g):
+        self.lg = np.asarray(g).reshape(self.lw.shape, order="F")
+
+    def train_apply(self):
+        self.lw = self.lw - self.eta * self.lg
+        self.lg = None
+
     def sample_rwmh(self, itr, sigma_z, seed, chain_id0=0, nchains=1):
         from oracle import philox
         z = np.stack([np.stack([sigma_z * philox.normals(seed, chain_id0 + c, t, 3) for t in range(itr)], axis=1)
@@ -115,6 +139,19 @@ def _worker(rank, world, port, q):
         zfull, lpfull, _, naccfull = so.sub_inference(table, x2, y2, ws2, p2, 0.1, 0.9, 25, seed=5)
         ok = ok and np.allclose(zsh[:, :, 0], zfull, rtol=1e-10, atol=1e-13) and np.allclose(lpsh[:, 0], lpfull, rtol=1e-11)
         ok = ok and abs(accsh[0] - naccfull / 24) < 1e-12
+        # data-parallel training: each rank takes its share of every batch; one gradient all-reduce per step
+        r3 = np.random.default_rng(2)
+        xl, yl, w0 = r3.standard_normal((4, 30)), r3.standard_normal((2, 30)), r3.standard_normal((2, 4))
+        ft = FakeCtx(None, None, None)
+        ft.set_linear(w0, xl, yl, 0.05)
+        wref = w0.copy()
+        for batch in (np.arange(0, 17), np.arange(17, 30), np.array([3, 9, 1])):
+            c0, c1 = sd.col_shard(batch.size, rank, world)
+            loss = sd.train_step_data_parallel(ft, batch[c0:c1], batch.size)
+            rr = wref @ xl[:, batch] - yl[:, batch]
+            ok = ok and np.isclose(loss, np.mean(rr * rr), rtol=1e-12)
+            wref = wref - 0.05 * (2.0 / rr.size) * (rr @ xl[:, batch].T)
+            ok = ok and np.allclose(ft.lw, wref, rtol=1e-12, atol=1e-14)
         q.put((rank, bool(ok), ""))
     except Exception as e:  # surface the failure in the parent
         import traceback

@@ -471,6 +471,158 @@ def test_device_training_matches_host_step(si, gpu_ctx, optname):
     assert wd.dtype == np.float32 and np.allclose(wd, wh, rtol=2e-4, atol=2e-6)
 
 
+def test_data_parallel_training_step(si, gpu_ctx):
+    """si_train_grad + si_train_apply is si_train_step bit for bit; two contexts that each take half of every batch and
+    exchange the summed gradient (the all-reduce of dist.train_step_data_parallel, done by hand here) follow the
+    single-context run."""
+    from subspaceinference_jl_amd import flux
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal((7, 96)), rng.standard_normal((2, 96))
+    wr = np.random.default_rng(5)
+    mdl = flux.Chain(flux.Dense(7, 33, flux.tanh, rng=wr), flux.Dense(33, 18, flux.relu, rng=wr), flux.Dense(18, 2, rng=wr))
+    table, n = flux.layer_table(mdl)
+    w0 = flux.extract_params(flux.params(mdl))
+    opt = flux.device_optimiser(flux.ADAM(0.01))
+    ranks = [si.Context(0), si.Context(0)]
+    try:
+        gpu_ctx.train_setup(table, n, w0, x, y, 32, *opt)
+        for c in ranks:
+            c.train_setup(table, n, w0, x, y, 32, *opt)
+        with pytest.raises(si.SubspaceError):
+            ranks[0].train_apply()                      # no gradient pending
+        batches = [np.arange(0, 32), np.arange(32, 64), np.array([5, 1, 77, 30, 2, 95, 40]), np.array([3])] * 2
+        for i, ids in enumerate(batches):   # the one-observation batch leaves rank 0 without a share (zero gradient)
+            loss = gpu_ctx.train_step(ids)
+            h = ids.size // 2
+            parts = [ids[:h], ids[h:]]
+            sse = [c.train_grad(part, ids.size) for c, part in zip(ranks, parts)]
+            g = ranks[0].train_grad_get() + ranks[1].train_grad_get()
+            for c in ranks:
+                c.train_grad_set(g)
+                c.train_apply()
+            assert np.isclose(sum(sse) / (2 * ids.size), loss, rtol=1e-12) and (ids.size > 1 or sse[0] == 0.0)
+        w_single = gpu_ctx.train_get_weights()
+        w_a, w_b = ranks[0].train_get_weights(), ranks[1].train_get_weights()
+        assert np.array_equal(w_a, w_b)                                   # replicas stay identical
+        assert np.allclose(w_a, w_single, rtol=1e-5, atol=1e-7)           # fp64 summation order differs, fp32 weights
+        # grad + apply without an exchange == train_step, bit for bit
+        ranks[0].train_setup(table, n, w0, x, y, 32, *opt)
+        gpu_ctx.train_setup(table, n, w0, x, y, 32, *opt)
+        for ids in batches:
+            gpu_ctx.train_step(ids, want_loss=False)
+            ranks[0].train_grad(ids, ids.size)
+            ranks[0].train_apply()
+        assert np.array_equal(ranks[0].train_get_weights(), gpu_ctx.train_get_weights())
+        ptr, cnt = ranks[0].train_grad_ptr()
+        assert ptr != 0 and cnt == n
+    finally:
+        for c in ranks:
+            c.close()
+
+
+_DP_RCCL_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["SI_ROOT"])
+import subspaceinference_jl_amd as si
+from subspaceinference_jl_amd import dist as sd, flux
+rank, world = sd.init(backend="nccl", device=0, force=True)
+import torch.distributed as td
+assert td.is_initialized() and td.get_backend() == "nccl"
+rng = np.random.default_rng(0)
+x, y = rng.standard_normal((6, 64)), rng.standard_normal((1, 64))
+wr = np.random.default_rng(1)
+m = flux.Chain(flux.Dense(6, 40, flux.relu, rng=wr), flux.Dense(40, 1, rng=wr))
+table, n = flux.layer_table(m)
+w0 = flux.extract_params(flux.params(m))
+a, b = si.Context(0), si.Context(0)
+for c in (a, b):
+    c.train_setup(table, n, w0, x, y, 64, *flux.device_optimiser(flux.Momentum(0.01, 0.9)))
+for ids in (np.arange(0, 64), np.arange(10, 50)):
+    la = a.train_step(ids)
+    lb = sd.train_step_data_parallel(b, ids, ids.size)   # world 1: the in-place RCCL all-reduce is the identity
+    assert np.isclose(la, lb, rtol=1e-12), (la, lb)
+assert np.array_equal(a.train_get_weights(), b.train_get_weights())
+td.destroy_process_group()
+print("DP_RCCL_OK")
+"""
+
+
+def test_data_parallel_step_over_rccl_zero_copy(tmp_path):
+    """dist.train_step_data_parallel with backend nccl (= RCCL): torch all-reduces the library's device gradient buffer in
+    place through __cuda_array_interface__ (world 1 on the one GPU of the test box; world 2 is the gloo CPU test)."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_rccl.py"
+    script.write_text(_DP_RCCL_SCRIPT)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SI_ROOT=root, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "DP_RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_DP_API_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["SI_ROOT"])
+import subspaceinference_jl_amd as si
+from subspaceinference_jl_amd import dist as sd, flux
+rank, world = sd.init(backend="gloo")
+rng = np.random.default_rng(0)
+x, y = rng.random((10, 100)), rng.random((2, 100))
+wr = np.random.default_rng(2)
+m = flux.Chain(flux.Dense(10, 20, flux.tanh, rng=wr), flux.Dense(20, 20, flux.relu, rng=wr), flux.Dense(20, 2, rng=wr))
+data = flux.DataLoader(x, y, batchsize=25, shuffle=True, rng=np.random.default_rng(7))   # same seed on every rank
+w_swa, p = si.subspace_construction(m, flux.mse, data, flux.ADAM(0.01), T=4, c=2, M=3, verbose=False, device_training=True)
+np.savez(os.environ["SI_OUT"] + "_%d.npz" % rank, w_swa=w_swa, p=p, w=flux.extract_params(flux.params(m)))
+import torch.distributed as td
+td.destroy_process_group()
+print("DP_API_OK")
+"""
+
+
+def test_api_construction_data_parallel_two_processes(si, gpu_ctx, tmp_path):
+    """subspace_construction under a 2-process group (gloo, both processes on the one GPU of the test box): each rank
+    trains on its share of every batch with one gradient all-reduce per step; both return the single-process result."""
+    import socket
+    import subprocess
+    import sys
+    from subspaceinference_jl_amd import flux
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_api.py"
+    script.write_text(_DP_API_SCRIPT)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, SI_ROOT=root, SI_OUT=str(tmp_path / "out"), RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=400) for p in procs]
+    for p, (so_, se_) in zip(procs, outs):
+        assert p.returncode == 0 and "DP_API_OK" in so_, so_[-2000:] + se_[-4000:]
+    a, b = np.load(str(tmp_path / "out_0.npz")), np.load(str(tmp_path / "out_1.npz"))
+    assert np.array_equal(a["w_swa"], b["w_swa"]) and np.array_equal(a["p"], b["p"]) and np.array_equal(a["w"], b["w"])
+    rng = np.random.default_rng(0)
+    x, y = rng.random((10, 100)), rng.random((2, 100))
+    wr = np.random.default_rng(2)
+    m = flux.Chain(flux.Dense(10, 20, flux.tanh, rng=wr), flux.Dense(20, 20, flux.relu, rng=wr), flux.Dense(20, 2, rng=wr))
+    data = flux.DataLoader(x, y, batchsize=25, shuffle=True, rng=np.random.default_rng(7))
+    w_swa, p = si.subspace_construction(m, flux.mse, data, flux.ADAM(0.01), T=4, c=2, M=3, ctx=gpu_ctx, verbose=False,
+                                        device_training=True)
+    assert np.allclose(a["w"], flux.extract_params(flux.params(m)), rtol=1e-4, atol=1e-6)
+    assert np.allclose(a["w_swa"], w_swa, rtol=1e-4, atol=1e-6)
+    sign = np.sign(np.sum(a["p"] * p, axis=0))
+    assert np.allclose(a["p"] * sign, p, rtol=2e-2, atol=2e-4 * np.abs(p).max())
+
+
 def test_construction_with_device_training(si, gpu_ctx):
     """README-toy flow with the training loop on the GPU: same W_swa / P as the host-stepped run (fp32 weights)."""
     from subspaceinference_jl_amd import flux
