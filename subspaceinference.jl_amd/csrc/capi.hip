@@ -838,7 +838,7 @@ int32_t si_logdensity_grad(si_ctx* ctx, const double* z, double* lp_out, double*
       launch_rowsum(ctx->stream, ctx->d_delta[cur], ly.out, B, ctx->d_rspart, ctx->d_gw + ly.b_off);
       int64_t ks;
       const int ns = backward_weight_splits(ly.out, ly.in, B, ctx->num_cu, &ks);
-      launch_backward_weight(ctx->stream, ctx->d_delta[cur], hprev, ctx->d_bwpart, ly.out, ly.in, B, ns, ks);
+      launch_backward_weight(ctx->stream, ctx->d_delta[cur], hprev, ctx->d_bwpart, ly.out, ly.in, B, ns, ks, ctx->num_cu);
       launch_split_reduce(ctx->stream, ctx->d_bwpart, ns, (int64_t)ly.out * ly.in, ctx->d_gw + ly.w_off);
       if (li > 0) {
         launch_backward_data(ctx->stream, ctx->d_w + ly.w_off, ctx->d_delta[cur], hprev, ctx->d_delta[cur ^ 1], ly.out,

@@ -186,7 +186,7 @@ static int32_t train_gradient(si_ctx* ctx, const char* who, const int64_t* idx, 
       launch_rowsum(st, t->delta[cur], ly.out, nb, t->rspart, t->gw + ly.b_off);
       int64_t ks;
       const int ns = backward_weight_splits(ly.out, ly.in, nb, ctx->num_cu, &ks);
-      launch_backward_weight(st, t->delta[cur], hprev, t->bwpart, ly.out, ly.in, nb, ns, ks);
+      launch_backward_weight(st, t->delta[cur], hprev, t->bwpart, ly.out, ly.in, nb, ns, ks, ctx->num_cu);
       launch_split_reduce(st, t->bwpart, ns, (int64_t)ly.out * ly.in, t->gw + ly.w_off);
       if (li > 0) {
         launch_backward_data(st, t->w64 + ly.w_off, t->delta[cur], hprev, t->delta[cur ^ 1], ly.out, ly.in, nb,

@@ -23,6 +23,11 @@ namespace si {
 
 enum { EPI_DACT = 1, EPI_RAW = 2 };
 
+#ifdef SI_BWD_DEBUG_KNOB
+__device__ int si_bwd_dbg = 0;  // harness only: 1 = every block reads split 0 / tile (0,0) (cache-hot), 2 = no global loads in the k loop
+#endif
+
+
 __device__ __forceinline__ double dact_from_output(double h, int act) {
   switch (act) {
     case SI_ACT_RELU: return h > 0.0 ? 1.0 : 0.0;       // relu'(z) = [z > 0] = [relu(z) > 0]
@@ -71,8 +76,36 @@ struct Stager {
     }
     base = LAY == 0 ? X + r0 + ld * k0 : X + ld * r0 + k0;
   }
-  // klen = k values that remain from this tile's first k (>= 1)
-  __device__ __forceinline__ void load(int kt, int64_t klen_total) {
+  // Hot path (every k tile but a ragged last one): loop-invariant per-thread offsets from a block-uniform pointer, no
+  // clamps, no selects -- one address add per load and a bare ds_write per store, like the forward kernel.  (With the
+  // edge logic inline the 16-deep tile cost ~60 VALU instructions per wave next to its 24 MFMAs, and the split-K weight
+  // gradient ran at 51 TFLOP/s.)
+  __device__ __forceinline__ void load(int kt) {
+    const double* p = base + (LAY == 0 ? ld * 16 : (int64_t)16) * kt;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      if constexpr (VEC) {
+        const double2 v = *reinterpret_cast<const double2*>(p + go[r]);
+        reg[r][0] = v.x;
+        reg[r][1] = v.y;
+      } else {
+        reg[r][0] = p[go[r]];
+      }
+    }
+  }
+  __device__ __forceinline__ void store(double* dst) const {
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      if (!live[r]) continue;
+      if constexpr (VEC)
+        *reinterpret_cast<double2*>(dst + lds[r]) = make_double2(reg[r][0], reg[r][1]);
+      else
+        dst[lds[r]] = reg[r][0];
+    }
+  }
+  // Ragged last tile (klen % 16 != 0): k indices past the end are clamped to a legal address and zero-filled in LDS
+  // (they would add into valid outputs).  klen_total = k values of this block's split.
+  __device__ __forceinline__ void load_edge(int kt, int64_t klen_total) {
     const double* p = base + (LAY == 0 ? ld * 16 : (int64_t)16) * kt;
     const int64_t kmax = klen_total - (LAY == 1 ? E : 1) - (int64_t)kt * 16;  // last legal k (pair start) in this tile
 #pragma unroll
@@ -88,11 +121,11 @@ struct Stager {
       }
     }
   }
-  __device__ __forceinline__ void store(double* dst, int kt, int64_t klen_total) const {
+  __device__ __forceinline__ void store_edge(double* dst, int kt, int64_t klen_total) const {
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
       if (!live[r]) continue;
-      const bool ok = (int64_t)kt * 16 + kk[r] < klen_total;  // zero-fill a ragged k edge (it would add into outputs)
+      const bool ok = (int64_t)kt * 16 + kk[r] < klen_total;
       if constexpr (VEC)
         *reinterpret_cast<double2*>(dst + lds[r]) = make_double2(ok ? reg[r][0] : 0.0, ok ? reg[r][1] : 0.0);
       else
@@ -118,9 +151,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_f64_kernel(
   // nNt >= 8: XCD-grouped map of the forward kernel (the nMt row tiles of one column panel share an XCD's L2).
   // nNt < 8 (weight gradients of narrow layers): that map would leave XCDs empty (measured: a 960x128 dW on ONE XCD,
   // 7x slower), so the tiles are numbered plainly and the split index spreads the blocks over the XCDs.
+  // (A map in which every XCD owns whole k-ranges of a split-K launch -- each element of both operands enters exactly
+  // one L2 -- was measured too: same speed, the kernel is not bound by L2 misses; not kept.)
   const int64_t bid = blockIdx.x;
   int mt;
   int64_t nt;
+  const int64_t split = blockIdx.y;
   if (nNt >= 8) {
     const int xcd = (int)(bid & 7);
     const int64_t j = bid >> 3;
@@ -131,7 +167,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_f64_kernel(
     nt = bid / nMt;
   }
   if (nt >= nNt) return;
-  const int64_t k0 = (int64_t)blockIdx.y * ksplit;
+  const int64_t k0 = split * ksplit;
   int64_t klen = Kdim - k0;
   if (klen > ksplit) klen = ksplit;
   if (klen <= 0) return;
@@ -150,22 +186,29 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_f64_kernel(
 
   SA sa;
   SB sb;
+#ifdef SI_BWD_DEBUG_KNOB
+  const int dbg = si_bwd_dbg;
+  sa.init(A, lda, (dbg & 1) ? 0 : m0, Mrows, (dbg & 1) ? 0 : k0, tid);
+  sb.init(Bm, ldb, (dbg & 1) ? 0 : n0, Ncols, (dbg & 1) ? 0 : k0, tid);
+#else
+  constexpr int dbg = 0;
   sa.init(A, lda, m0, Mrows, k0, tid);
   sb.init(Bm, ldb, n0, Ncols, k0, tid);
+#endif
   const int nk = (int)((klen + 15) / 16);
 
   double fa[2][TM], fb[2][TN];
   const int aw = wm * (BM / WM) + c, bw = wn * (BN / WN) + c;
-  auto read_frags = [&](int buf, int s, auto SET) {
-    constexpr int set = decltype(SET)::value;
-    const double* pa = sAbuf + buf * SA::LDS_ELEMS;
-    const double* pb = sBbuf + buf * SB::LDS_ELEMS;
+  const double* pa0 = sAbuf + (ALAY == 0 ? q * SA::RP + aw : aw * SA::KP + q);
+  const double* pb0 = sBbuf + (BLAY == 0 ? q * SB::RP + bw : bw * SB::KP + q);
+  auto read_frags = [&](auto BUF, auto S, auto SET) {
+    constexpr int buf = decltype(BUF)::value, s = decltype(S)::value, set = decltype(SET)::value;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
-      fa[set][a] = ALAY == 0 ? pa[(4 * s + q) * SA::RP + aw + a * 16] : pa[(aw + a * 16) * SA::KP + 4 * s + q];
+      fa[set][a] = pa0[buf * SA::LDS_ELEMS + (ALAY == 0 ? 4 * s * SA::RP + a * 16 : a * 16 * SA::KP + 4 * s)];
 #pragma unroll
     for (int b = 0; b < TN; ++b)
-      fb[set][b] = BLAY == 0 ? pb[(4 * s + q) * SB::RP + bw + b * 16] : pb[(bw + b * 16) * SB::KP + 4 * s + q];
+      fb[set][b] = pb0[buf * SB::LDS_ELEMS + (BLAY == 0 ? 4 * s * SB::RP + b * 16 : b * 16 * SB::KP + 4 * s)];
   };
   auto mfma_half = [&](auto SET, auto HALF) {
     constexpr int set = decltype(SET)::value, half = decltype(HALF)::value;
@@ -180,40 +223,49 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_f64_kernel(
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-
-  sa.load(0, klen);
-  sb.load(0, klen);
-  sa.store(sAbuf, 0, klen);
-  sb.store(sBbuf, 0, klen);
-  if (nk > 1) {
-    sa.load(1, klen);
-    sb.load(1, klen);
-  }
-  __syncthreads();
-  read_frags(0, 0, I0{});
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  // only the last tile of a split can be ragged; the choice is block-uniform (a scalar branch)
+  const int edge_kt = (klen & 15) ? nk - 1 : -1;
+  auto load_tile = [&](int kt) {
+    if (kt == edge_kt) {
+      sa.load_edge(kt, klen);
+      sb.load_edge(kt, klen);
+    } else {
+      sa.load(kt);
+      sb.load(kt);
+    }
+  };
+  auto store_tile = [&](auto BUF, int kt) {
+    constexpr int buf = decltype(BUF)::value;
+    if (kt == edge_kt) {
+      sa.store_edge(sAbuf + buf * SA::LDS_ELEMS, kt, klen);
+      sb.store_edge(sBbuf + buf * SB::LDS_ELEMS, kt, klen);
+    } else {
+      sa.store(sAbuf + buf * SA::LDS_ELEMS);
+      sb.store(sBbuf + buf * SB::LDS_ELEMS);
+    }
+  };
+  // same pipeline as the forward kernel (kernels_gemm.hip tile_body): [half the MFMAs][LDS / global traffic][other half]
+  auto tile_body = [&](auto BUF, auto NBUF, int kt) {
     mfma_half(I0{}, I0{});
     __builtin_amdgcn_sched_barrier(0);
-    read_frags(buf, 1, I1{});
+    read_frags(BUF, I1{}, I1{});
     __builtin_amdgcn_sched_barrier(0);
     mfma_half(I0{}, I1{});
     __builtin_amdgcn_sched_barrier(0);
 
     mfma_half(I1{}, I0{});
     __builtin_amdgcn_sched_barrier(0);
-    read_frags(buf, 2, I0{});
-    if (kt + 1 < nk) {
-      sa.store(sAbuf + (buf ^ 1) * SA::LDS_ELEMS, kt + 1, klen);
-      sb.store(sBbuf + (buf ^ 1) * SB::LDS_ELEMS, kt + 1, klen);
-    }
+    read_frags(BUF, I2{}, I0{});
+    if (kt + 1 < nk) store_tile(NBUF, kt + 1);
     __builtin_amdgcn_sched_barrier(0);
     mfma_half(I1{}, I1{});
     __builtin_amdgcn_sched_barrier(0);
 
     mfma_half(I0{}, I0{});
     __builtin_amdgcn_sched_barrier(0);
-    read_frags(buf, 3, I1{});
+    read_frags(BUF, I3{}, I1{});
     __builtin_amdgcn_sched_barrier(0);
     mfma_half(I0{}, I1{});
     __builtin_amdgcn_sched_barrier(0);
@@ -221,14 +273,21 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_f64_kernel(
     mfma_half(I1{}, I0{});
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    if (kt + 1 < nk) read_frags(buf ^ 1, 0, I0{});
-    if (kt + 2 < nk) {
-      sa.load(kt + 2, klen);
-      sb.load(kt + 2, klen);
-    }
+    if (kt + 1 < nk) read_frags(NBUF, I0{}, I0{});
+    if (kt + 2 < nk && !(dbg & 2)) load_tile(kt + 2);
     __builtin_amdgcn_sched_barrier(0);
     mfma_half(I1{}, I1{});
     __builtin_amdgcn_sched_barrier(0);
+  };
+
+  load_tile(0);
+  store_tile(I0{}, 0);
+  if (nk > 1) load_tile(1);
+  __syncthreads();
+  read_frags(I0{}, I0{}, I0{});
+  for (int kt = 0; kt < nk; kt += 2) {
+    tile_body(I0{}, I1{}, kt);
+    if (kt + 1 < nk) tile_body(I1{}, I0{}, kt + 1);
   }
 
   // epilogue: D[n = q + 4r][m = c] per tile; transposed through LDS for 16-B stores when the shape allows
@@ -236,7 +295,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_f64_kernel(
   constexpr bool WIDE = VEC && (64 % (WI / 2) == 0) && (WM * WN * 16 * WI <= 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS));
   const int mw0 = m0 + wm * WI;
   const int64_t nw0 = n0 + wn * (BN / WN);
-  double* Cout = C + (EPI == EPI_RAW ? (int64_t)blockIdx.y * ldc * Ncols : 0);
+  double* Cout = C + (EPI == EPI_RAW ? split * ldc * Ncols : 0);
   if constexpr (WIDE) {
     constexpr int CH_ROW = WI / 2, NCH = 16 * CH_ROW / 64;
     double* reg = smem + wave * (16 * WI);
@@ -344,25 +403,54 @@ void launch_backward_data(hipStream_t st, const double* W, const double* Delta, 
   }
 }
 
-// partial dW[split][out x in] = Delta[:, split's columns] * Hprev[:, split's columns]';  returns nsplit
-int backward_weight_splits(int32_t out, int32_t in, int64_t B, int num_cu, int64_t* ksplit_out) {
-  const int bm = pick_bm_bwd(out);
-  const int64_t tiles = (int64_t)((out + bm - 1) / bm) * ((in + 127) / 128);
-  // fill the chip's 2 x CU workgroup slots as exactly as the tile count allows (one full round, no ragged second one)
-  int64_t nsplit = (int64_t)num_cu * 2 / tiles;
+// Plan of the split-K weight gradient  dW[out x in] = Delta * Hprev'  (K = B): the row tile and the split count that
+// waste least -- padding of `out` to the tile, and unfilled slots of the ONE round of 2 x CU workgroups (two 8-wave
+// workgroups per CU) the launch is sized for.  cfg2 layer 2: 96-row tiles, 80 tiles x 6 splits = 480 of 512 slots.
+struct DwPlan {
+  int bm;
+  int nsplit;
+  int64_t ks;
+};
+static DwPlan plan_dw(int32_t out, int32_t in, int64_t B, int num_cu) {
+  const int64_t slots = (int64_t)num_cu * 2;
   const int64_t maxsplit = (B + 255) / 256;
-  if (nsplit > maxsplit) nsplit = maxsplit;
-  if (nsplit < 1) nsplit = 1;
-  int64_t ks = ((B + nsplit - 1) / nsplit + 15) / 16 * 16;
-  nsplit = (B + ks - 1) / ks;
-  *ksplit_out = ks;
-  return (int)nsplit;
+  DwPlan best{96, 1, B};
+  double best_score = -1.0;
+  const int bms[3] = {96, 128, 64};
+  for (int bm : bms) {
+    const int64_t pm = (out + bm - 1) / bm, pn = (in + 127) / 128;
+    const int64_t tiles = pm * pn;
+    int64_t ns = slots / tiles;
+    if (ns > maxsplit) ns = maxsplit;
+    if (ns < 1) ns = 1;
+    const double useful = ((double)out * in) / ((double)pm * bm * (double)pn * 128);
+    const double fill = (double)(tiles * ns) / (double)((tiles * ns + slots - 1) / slots * slots);
+    if (useful * fill > best_score * 1.0001) {
+      best_score = useful * fill;
+      best.bm = bm;
+      best.nsplit = (int)ns;
+    }
+  }
+#ifdef SI_BWD_DEBUG_KNOB
+  if (const char* e = getenv("SI_BWD_BM")) best.bm = atoi(e);
+  if (const char* e = getenv("SI_BWD_NSPLIT")) best.nsplit = atoi(e);
+#endif
+  // k-range per split rounded up to whole 16-deep tiles; only splits that hold columns are launched
+  best.ks = ((B + best.nsplit - 1) / best.nsplit + 15) / 16 * 16;
+  best.nsplit = (int)((B + best.ks - 1) / best.ks);
+  return best;
+}
+
+int backward_weight_splits(int32_t out, int32_t in, int64_t B, int num_cu, int64_t* ksplit_out) {
+  const DwPlan p = plan_dw(out, in, B, num_cu);
+  *ksplit_out = p.ks;
+  return p.nsplit;
 }
 
 void launch_backward_weight(hipStream_t st, const double* Delta, const double* Hprev, double* part, int32_t out,
-                            int32_t in, int64_t B, int nsplit, int64_t ksplit) {
+                            int32_t in, int64_t B, int nsplit, int64_t ksplit, int num_cu) {
   // A(m = out idx, k = b) = Delta[m + out*k]: row-fast;  B(k = b, n = in idx) = Hprev[n + in*k]: row-fast
-  switch (pick_bm_bwd(out)) {
+  switch (plan_dw(out, in, B, num_cu).bm) {
     case 96: launch_gemm<96, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0); break;
     case 128: launch_gemm<128, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0); break;
     default: launch_gemm<64, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0); break;

@@ -199,7 +199,7 @@ void launch_backward_data(hipStream_t st, const double* W, const double* Delta, 
                           int32_t out, int32_t in, int64_t B, int32_t act_prev);
 int backward_weight_splits(int32_t out, int32_t in, int64_t B, int num_cu, int64_t* ksplit_out);
 void launch_backward_weight(hipStream_t st, const double* Delta, const double* Hprev, double* part, int32_t out,
-                            int32_t in, int64_t B, int nsplit, int64_t ksplit);
+                            int32_t in, int64_t B, int nsplit, int64_t ksplit, int num_cu);
 void launch_split_reduce(hipStream_t st, const double* part, int nsplit, int64_t elems, double* dst);
 void launch_delta_out(hipStream_t st, const double* Y, const double* Yhat, int64_t d, double scale, int act, double* delta);
 void launch_rowsum(hipStream_t st, const double* D, int32_t out, int64_t B, double* part, double* db);
