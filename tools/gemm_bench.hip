@@ -23,6 +23,7 @@ int main(int argc, char** argv) {
   const int dbg = argc > 5 ? atoi(argv[5]) : 0;
   hipMemcpyToSymbol(HIP_SYMBOL(si::si_gemm_dbg), &dbg, sizeof(int));
   si::si_gemm_lds_floor = argc > 6 ? (size_t)atol(argv[6]) : 0;
+
   printf("debug knob %d lds floor %zu\n", dbg, si::si_gemm_lds_floor);
   const unsigned long mask = argc > 4 ? strtoul(argv[4], nullptr, 0) : ~0ul;  // bit v selects variant v (0 always runs)
   std::vector<double> hW((size_t)out * in), hb(out), hX((size_t)in * B);
@@ -58,6 +59,9 @@ int main(int argc, char** argv) {
     {"96x256 2x4 w2 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<96, 256, 2, 4, 2>(st, W, b, X, Y, o, i, B, a); }},
     {"192x128 4x2 w3 (8 waves)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<192, 128, 4, 2, 3>(st, W, b, X, Y, o, i, B, a); }},
     {"64x64 2x2 w4", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<64, 64, 2, 2, 4>(st, W, b, X, Y, o, i, B, a); }},
+    {"64x64 2x4 w6 (8 waves, 3 WG/CU)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<64, 64, 2, 4, 6>(st, W, b, X, Y, o, i, B, a); }},
+    {"96x64 2x4 w6 (8 waves, 3 WG/CU)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<96, 64, 2, 4, 6>(st, W, b, X, Y, o, i, B, a); }},
+    {"64x64 2x4 w8 (8 waves, 4 WG/CU)", [](hipStream_t st, const double* W, const double* b, const double* X, double* Y, int32_t o, int32_t i, int64_t B, int32_t a) { launch_dense_cfg<64, 64, 2, 4, 8>(st, W, b, X, Y, o, i, B, a); }},
   };
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   std::vector<double> ref((size_t)out * 4096), got((size_t)out * 4096);
