@@ -229,6 +229,21 @@ def test_chain_batched_density_is_bit_identical(gpu_ctx, dims, acts, b, m):
         assert np.array_equal(z5[:, :, j], z1[:, :, 0]) and np.array_equal(lp5[:, j], lp1[:, 0]) and acc5[j] == acc1[0]
 
 
+def test_chain_batching_respects_the_workspace_cap(gpu_ctx):
+    """A model whose forward workspace is ~0.5 GB per chain gets 4 slots under the 2 GiB cap (capi.hip batch_width):
+    6 chains run as a batch of 4 and a batch of 2, with the bits of one-at-a-time evaluation."""
+    dims, acts, b, m = [16, 256, 256, 1], [1, 1, 0], 120000, 3
+    table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=77)
+    gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=1.3)
+    zs = np.asfortranarray(np.random.default_rng(2).standard_normal((m, 6)))
+    lp_single = np.array([gpu_ctx.logdensity(np.asfortranarray(zs[:, j:j + 1]))[0] for j in range(6)])
+    assert np.array_equal(gpu_ctx.logdensity(zs), lp_single)
+    assert np.isclose(lp_single[5], so.logdensity(table, w_swa, p, x, y, 1.3, zs[:, 5]), rtol=1e-11)
+    z6, lp6, _ = gpu_ctx.sample_rwmh(4, 0.02, seed=1, chain_id0=0, nchains=6)
+    z1, lp1, _ = gpu_ctx.sample_rwmh(4, 0.02, seed=1, chain_id0=5, nchains=1)
+    assert np.array_equal(z6[:, :, 5], z1[:, :, 0]) and np.array_equal(lp6[:, 5], lp1[:, 0])
+
+
 @pytest.mark.parametrize("dims,acts", [([10, 20, 20, 2], [0, 0, 0]), ([6, 40, 8], [1, 0]), ([4, 50, 1], [2, 0])])
 def test_predict_new_inputs(gpu_ctx, dims, acts):
     table, n, w_swa, p, x, y = _random_problem(dims, acts, 64, 3, seed=21)
