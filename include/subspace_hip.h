@@ -195,6 +195,11 @@ int32_t si_train_apply(si_ctx* ctx);
 /* ---- host utility (no GPU needed): the K x K symmetric eigensolver used inside si_construct_finish.
  * a: n x n symmetric column-major, overwritten by the eigenvectors (columns); w: eigenvalues ascending. */
 int si_host_sym_eig(int n, double* a, double* w);
+/* The route si_construct_finish takes first: only the m largest eigenpairs (Householder reduction with the reflectors
+ * kept in factored form, eigenvalues by vector-free QL, eigenvectors by inverse iteration, result verified against g).
+ * g: n x n symmetric column-major, left intact; w_top: m eigenvalues DESCENDING; V: n x m eigenvectors.
+ * Returns 0 = verified result, 1 = declined / failed verification (si_construct_finish then uses si_host_sym_eig). */
+int si_host_sym_eig_top(int n, const double* g, int m, double* w_top, double* V);
 
 #ifdef __cplusplus
 }

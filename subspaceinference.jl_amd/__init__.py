@@ -8,8 +8,8 @@ reference's exported functions), flux.py (caller-side stand-ins for the Flux obj
 dist.py (one-process-per-GPU plumbing over torch.distributed / RCCL), julia/ (the ccall wrapper).
 """
 from . import flux  # noqa: F401
-from ._capi import BoundsError, Context, SubspaceError, host_sym_eig, load  # noqa: F401
+from ._capi import BoundsError, Context, SubspaceError, host_sym_eig, host_sym_eig_top, load  # noqa: F401
 from .api import inference, sub_inference, subspace_construction, subspace_inference  # noqa: F401
 
 __all__ = ["subspace_construction", "subspace_inference", "sub_inference", "inference", "Context",
-           "SubspaceError", "BoundsError", "flux", "load", "host_sym_eig"]
+           "SubspaceError", "BoundsError", "flux", "load", "host_sym_eig", "host_sym_eig_top"]

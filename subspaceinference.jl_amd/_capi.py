@@ -88,6 +88,7 @@ SIGNATURES = {
     "si_train_grad_set": (c_int32, [c_void_p, c_void_p]),
     "si_train_apply": (c_int32, [c_void_p]),
     "si_host_sym_eig": (c_int, [c_int, c_void_p, c_void_p]),
+    "si_host_sym_eig_top": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -405,3 +406,15 @@ def host_sym_eig(g):
     if rc != 0:
         raise SubspaceError("eigensolver did not converge")
     return w, a
+
+
+def host_sym_eig_top(g, m):
+    """The m largest eigenpairs by the fast host route of si_construct_finish (needs no GPU).  Returns
+    (w_top descending, V n x m), or None when the route declines / fails its own verification."""
+    lib = load()
+    a = np.array(g, dtype=np.float64, order="F")
+    n = a.shape[0]
+    w = np.empty(int(m), dtype=np.float64)
+    v = np.empty((n, int(m)), dtype=np.float64, order="F")
+    rc = lib.si_host_sym_eig_top(n, _ptr(a), int(m), _ptr(w), _ptr(v))
+    return (w, v) if rc == 0 else None

@@ -21,7 +21,9 @@ SOURCES = [
     ("kernels_gemm.hip", []),
     ("kernels_gram.hip", []),
     ("kernels_bwd.hip", []),
-    ("eig.cpp", []),
+    ("eig.cpp", ["-DSI_EIG_NS=base"]),
+    ("eig.cpp", ["-DSI_EIG_NS=avx2", "-mavx2", "-mfma"], "eig_avx2"),   # same source, second ISA (eig_dispatch.cpp chooses)
+    ("eig_dispatch.cpp", []),
 ]
 HEADERS = ["si_internal.h", "philox.h", "kernels_gemm.h", os.path.join("..", "..", "include", "subspace_hip.h")]
 
@@ -46,9 +48,10 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs = []
-    for src, extra in SOURCES:
+    for entry in SOURCES:
+        src, extra = entry[0], entry[1]
         s = os.path.join(CSRC, src)
-        o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        o = os.path.join(objdir, (entry[2] if len(entry) > 2 else os.path.splitext(src)[0]) + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
             cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -441,9 +441,18 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
   std::vector<double> G((size_t)K * K), lam((size_t)K);
   SI_HIP(ctx, hipMemcpyAsync(G.data(), ctx->d_G, G.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // the M largest eigenpairs: fast route (factored Householder + inverse iteration, verified) or the full QL solver
+  std::vector<double> wtop((size_t)M), Vtop((size_t)K * M);
   {
     const auto t0 = std::chrono::steady_clock::now();
-    const int erc = sym_eig((int)K, G.data(), lam.data());
+    int erc = 0;
+    if (sym_eig_top((int)K, G.data(), (int)M, wtop.data(), Vtop.data()) != 0) {
+      erc = sym_eig((int)K, G.data(), lam.data());
+      for (int m = 0; m < M && erc == 0; ++m) {
+        wtop[(size_t)m] = lam[(size_t)(K - 1 - m)];
+        std::copy(G.data() + (size_t)(K - 1 - m) * K, G.data() + (size_t)(K - m) * K, Vtop.data() + (size_t)m * K);
+      }
+    }
     ctx->stats.ms[SI_K_EIG_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->stats.launches[SI_K_EIG_HOST] += 1;
     if (erc != 0) return fail(ctx, SI_ERR_INVALID, "si_construct_finish: eigensolver did not converge");
@@ -453,10 +462,9 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
   std::vector<double> V((size_t)K * Mpad, 0.0);
   ctx->svals.assign((size_t)M, 0.0);
   for (int m = 0; m < M; ++m) {
-    const int64_t col = K - 1 - m;
-    const double l = lam[(size_t)col];
+    const double l = wtop[(size_t)m];
     ctx->svals[(size_t)m] = l > 0.0 ? std::sqrt(l) : 0.0;
-    const double* v = G.data() + (size_t)col * K;
+    const double* v = Vtop.data() + (size_t)m * K;
     int64_t imax = 0;
     for (int64_t k = 1; k < K; ++k)
       if (std::fabs(v[k]) > std::fabs(v[imax])) imax = k;
@@ -466,7 +474,7 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
   // numerical rank check.  psvd (rtol 5 eps) returns only rank(A) columns and U[:,1:M] then throws.  Through the
   // Gram matrix, eigenvalues below ~K*eps*lambda_1 are rounding noise, i.e. singular values under ~1e-6*s_1 cannot
   // be delivered to the path's rtol of 1e-4: report them as rank deficiency instead of returning noise.
-  const double lam1 = lam[(size_t)K - 1], lamM = lam[(size_t)(K - M)];
+  const double lam1 = wtop[0], lamM = wtop[(size_t)M - 1];
   if (!(lam1 > 0.0) || lamM <= 64.0 * (double)K * 2.220446049250313e-16 * lam1 || M > std::min<int64_t>(N, K))
     return fail(ctx, SI_ERR_BOUNDS,
                 "BoundsError: M exceeds the numerical rank of the deviation matrix (s_M < ~1e-6 s_1 is below what the "

@@ -5,9 +5,18 @@
 // thousand, so O(K^3) on one host core is negligible next to the N x K device work.
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <vector>
 
+// This file is compiled twice (build.py): as SI_EIG_NS=base with the default x86-64 flags and as SI_EIG_NS=avx2 with
+// -mavx2 -mfma (the inner loops are contiguous column sweeps: 4-wide FMA roughly halves the time); eig_dispatch.cpp
+// picks one at run time from the CPU's feature bits.
+#ifndef SI_EIG_NS
+#define SI_EIG_NS base
+#endif
+
 namespace si {
+namespace SI_EIG_NS {
 
 namespace {
 
@@ -150,6 +159,261 @@ int ql_implicit(int n, double* a, double* d, double* e) {
   return 0;
 }
 
+// ---- top-m eigenpairs without forming all n eigenvectors -------------------------------------------------------
+// si_construct_finish needs the M largest eigenpairs of the K x K Gram matrix (M = 20 of K = 100 at cfg2).  The
+// full solver above spends most of its time accumulating Q and rotating all K columns in the QL sweeps (~7 K^3
+// flops); this route does the Householder reduction with the reflectors kept in factored form (4/3 K^3), takes the
+// eigenvalues from a vector-free QL (O(K^2)), gets the m wanted eigenvectors of T by inverse iteration (O(K) each,
+// re-orthogonalised inside clusters of close eigenvalues) and applies the reflectors to those m vectors only
+// (2 K^2 m).  The result is VERIFIED (residual and orthogonality) by the caller-visible wrapper, which falls back to
+// the full solver if the check fails, so degenerate spectra cost time, never accuracy.
+
+// lower-triangle Householder reduction, reflectors in factored form (as LAPACK dsytd2, uplo = 'L'):
+// on exit d, e (e[i] couples i and i+1) describe T; column i of `a` below the sub-diagonal holds v_i[2:] (v_i[1] = 1)
+// and tau[i] its scale;  Q = H_0 H_1 ... H_{n-3},  H_i = I - tau_i v_i v_i'.
+void tridiagonalize_factored(int n, double* a, double* d, double* e, double* tau, double* work) {
+  for (int i = 0; i < n - 1; ++i) {
+    const int s = n - i - 1;            // length of the column below the diagonal
+    double* x = &at(a, n, i + 1, i);    // x[0..s)
+    double xnorm2 = 0.0;
+    for (int k = 1; k < s; ++k) xnorm2 += x[k] * x[k];
+    const double alpha = x[0];
+    double t = 0.0, beta = alpha;
+    if (xnorm2 > 0.0) {
+      beta = -std::copysign(std::sqrt(alpha * alpha + xnorm2), alpha);
+      t = (beta - alpha) / beta;
+      const double inv = 1.0 / (alpha - beta);
+      for (int k = 1; k < s; ++k) x[k] *= inv;
+    }
+    e[i] = beta;
+    tau[i] = t;
+    d[i] = at(a, n, i, i);
+    if (t != 0.0) {
+      x[0] = 1.0;
+      // p = tau * A22 * v  (A22 = trailing s x s block, lower triangle stored)
+      double* pvec = work;
+      for (int r = 0; r < s; ++r) pvec[r] = 0.0;
+      for (int c = 0; c < s; ++c) {
+        const double* col = &at(a, n, i + 1 + c, i + 1 + c);  // col[0] = diagonal, col[r - c] for r > c
+        const double vc = x[c];
+        double acc = col[0] * vc;
+        for (int r = c + 1; r < s; ++r) {
+          acc += col[r - c] * x[r];
+          pvec[r] += col[r - c] * vc;
+        }
+        pvec[c] += acc;
+      }
+      double pv = 0.0;
+      for (int r = 0; r < s; ++r) {
+        pvec[r] *= t;
+        pv += pvec[r] * x[r];
+      }
+      const double half = 0.5 * t * pv;
+      for (int r = 0; r < s; ++r) pvec[r] -= half * x[r];   // w = p - (tau/2)(p'v) v
+      // A22 -= v w' + w v'  (lower triangle)
+      for (int c = 0; c < s; ++c) {
+        double* col = &at(a, n, i + 1 + c, i + 1 + c);
+        const double vc = x[c], wc = pvec[c];
+        for (int r = c; r < s; ++r) col[r - c] -= x[r] * wc + pvec[r] * vc;
+      }
+    }
+    x[0] = beta;  // keep T's sub-diagonal in place of v[0] (v[0] = 1 is implicit)
+  }
+  d[n - 1] = at(a, n, n - 1, n - 1);
+  if (n >= 2) tau[n - 2] = 0.0;  // the last "reflector" acts on a single element: H = I
+}
+
+// eigenvalues only: implicit QL on copies of (d, e[0..n-1) sub-diagonal); ascending on exit.  Returns 0 on convergence.
+// sqrt(a^2 + b^2) without overflow in the squares (one division and one sqrt; libm hypot costs 3x as much and the
+// vector-free QL sweep is nothing but these)
+inline double pyth(double a, double b) {
+  const double x = std::fabs(a), y = std::fabs(b);
+  const double hi = x > y ? x : y, lo = x > y ? y : x;
+  if (hi == 0.0) return 0.0;
+  const double r = lo / hi;
+  return hi * std::sqrt(1.0 + r * r);
+}
+
+int ql_values(int n, double* d, double* e) {
+  const double eps = std::ldexp(1.0, -52);
+  e[n - 1] = 0.0;
+  double f = 0.0, tst1 = 0.0;
+  for (int l = 0; l < n; ++l) {
+    tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+    int m = l;
+    while (m < n) {
+      if (std::fabs(e[m]) <= eps * tst1) break;
+      ++m;
+    }
+    if (m > l) {
+      int iter = 0;
+      do {
+        if (++iter > 200) return 1;
+        double g = d[l];
+        double p = (d[l + 1] - g) / (2.0 * e[l]);
+        double r = pyth(p, 1.0);
+        if (p < 0) r = -r;
+        d[l] = e[l] / (p + r);
+        d[l + 1] = e[l] * (p + r);
+        const double dl1 = d[l + 1];
+        double h = g - d[l];
+        for (int i = l + 2; i < n; ++i) d[i] -= h;
+        f += h;
+        p = d[m];
+        double c = 1.0, c2 = c, c3 = c;
+        const double el1 = e[l + 1];
+        double s = 0.0, s2 = 0.0;
+        for (int i = m - 1; i >= l; --i) {
+          c3 = c2;
+          c2 = c;
+          s2 = s;
+          g = c * e[i];
+          h = c * p;
+          // plain sqrt of the sum of squares when that cannot over/underflow, one reciprocal for both s and c: the
+          // sweep is one serial dependency chain, and this halves its latency
+          const double ss = p * p + e[i] * e[i];
+          r = (ss > 1e-280 && ss < 1e280) ? std::sqrt(ss) : pyth(p, e[i]);
+          e[i + 1] = s * r;
+          const double rinv = 1.0 / r;
+          s = e[i] * rinv;
+          c = p * rinv;
+          p = c * d[i] - s * g;
+          d[i + 1] = h + s * (c * g + s * d[i]);
+        }
+        p = -s * s2 * c3 * el1 * e[l] / dl1;
+        e[l] = s * p;
+        d[l] = c * p;
+      } while (std::fabs(e[l]) > eps * tst1);
+    }
+    d[l] = d[l] + f;
+    e[l] = 0.0;
+  }
+  std::sort(d, d + n);
+  return 0;
+}
+
+// LU factorisation with partial pivoting of the tridiagonal T - lambda I (d, e: e[i] couples i and i+1), then solves
+// with it.  Tiny pivots are replaced by `pivmin` (inverse iteration WANTS the near-singularity).  U has two
+// super-diagonals (u1, u2) because of the row swaps; l holds the multipliers, swapped the row exchanges.
+void tridiag_shift_factor(int n, const double* d, const double* e, double lambda, double pivmin, double* u0, double* u1,
+                          double* u2, double* l, int* swapped) {
+  for (int i = 0; i < n; ++i) {
+    u0[i] = d[i] - lambda;
+    u1[i] = i + 1 < n ? e[i] : 0.0;
+    u2[i] = 0.0;
+  }
+  for (int i = 0; i + 1 < n; ++i) {
+    const double sub = e[i];  // element (i+1, i)
+    if (std::fabs(u0[i]) >= std::fabs(sub)) {
+      swapped[i] = 0;
+      double piv = u0[i];
+      if (std::fabs(piv) < pivmin) piv = u0[i] = std::copysign(pivmin, piv == 0.0 ? 1.0 : piv);
+      const double mlt = sub / piv;
+      l[i] = mlt;
+      u0[i + 1] -= mlt * u1[i];
+    } else {
+      swapped[i] = 1;  // rows i and i+1 change places: the pivot row is (sub, d[i+1]-lambda, e[i+1])
+      const double mlt = u0[i] / sub;
+      l[i] = mlt;
+      const double r0 = u0[i + 1], r1 = u1[i + 1];
+      const double old_u1 = u1[i];
+      u0[i] = sub;
+      u1[i] = r0;
+      u2[i] = r1;
+      u0[i + 1] = old_u1 - mlt * r0;
+      u1[i + 1] = -mlt * r1;
+    }
+  }
+  if (std::fabs(u0[n - 1]) < pivmin) u0[n - 1] = std::copysign(pivmin, u0[n - 1] == 0.0 ? 1.0 : u0[n - 1]);
+  for (int i = 0; i < n; ++i) u0[i] = 1.0 / u0[i];  // the solves multiply
+}
+
+void tridiag_shift_solve(int n, const double* u0inv, const double* u1, const double* u2, const double* l,
+                         const int* swapped, double* x) {
+  for (int i = 0; i + 1 < n; ++i) {  // forward substitution with the same row operations
+    if (swapped[i]) {
+      const double t = x[i];
+      x[i] = x[i + 1];
+      x[i + 1] = t - l[i] * x[i];
+    } else {
+      x[i + 1] -= l[i] * x[i];
+    }
+  }
+  for (int i = n - 1; i >= 0; --i) {  // back substitution
+    double t = x[i];
+    if (i + 1 < n) t -= u1[i] * x[i + 1];
+    if (i + 2 < n) t -= u2[i] * x[i + 2];
+    x[i] = t * u0inv[i];
+  }
+}
+
+// top-m eigenpairs of the symmetric n x n matrix `a` (column-major, destroyed): w_top[0..m) descending, V n x m.
+// Returns 0 = done (unverified: see sym_eig_top), 1 = the QL iteration did not converge.
+int sym_eig_top_unverified(int n, double* a, int m, double* w_top, double* V) {
+  std::vector<double> d(n), e(n), tau(n), work(6 * (size_t)n);
+  std::vector<int> sw(n);
+  tridiagonalize_factored(n, a, d.data(), e.data(), tau.data(), work.data());
+  std::vector<double> dv(d), ev(e);
+  if (ql_values(n, dv.data(), ev.data()) != 0) return 1;
+  double tnorm = 0.0;  // 1-norm of T
+  for (int i = 0; i < n; ++i)
+    tnorm = std::max(tnorm, std::fabs(d[i]) + (i > 0 ? std::fabs(e[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(e[i]) : 0.0));
+  const double eps = std::ldexp(1.0, -52);
+  const double pivmin = std::max(eps * tnorm, 1e-300);
+  const double ortol = 1e-3 * tnorm, septol = 10.0 * eps * tnorm;
+  double* u0 = work.data();
+  double *u1 = u0 + n, *u2 = u1 + n, *l = u2 + n, *x = l + n;
+  uint64_t rng = 0x9E3779B97F4A7C15ull;
+  int cluster0 = 0;       // first vector of the current cluster
+  double lam_prev = 0.0;  // (perturbed) eigenvalue used for the previous vector
+  for (int k = 0; k < m; ++k) {
+    double lam = dv[(size_t)(n - 1 - k)];
+    w_top[k] = lam;
+    if (k > 0) {
+      if (lam_prev - lam > ortol) cluster0 = k;                 // well separated: new cluster
+      if (lam_prev - lam < septol) lam = lam_prev - septol;      // coincident: separate the shifts
+    }
+    lam_prev = lam;
+    for (int i = 0; i < n; ++i) {  // deterministic start vector
+      rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+      x[i] = ((double)(rng >> 11) / 9007199254740992.0) - 0.5;
+    }
+    double* vk = V + (size_t)k * n;
+    tridiag_shift_factor(n, d.data(), e.data(), lam, pivmin, u0, u1, u2, l, sw.data());
+    for (int it = 0; it < 3; ++it) {
+      tridiag_shift_solve(n, u0, u1, u2, l, sw.data(), x);
+      for (int c = cluster0; c < k; ++c) {  // modified Gram-Schmidt inside the cluster
+        const double* vc = V + (size_t)c * n;
+        double dot = 0.0;
+        for (int i = 0; i < n; ++i) dot += vc[i] * x[i];
+        for (int i = 0; i < n; ++i) x[i] -= dot * vc[i];
+      }
+      double nrm = 0.0;
+      for (int i = 0; i < n; ++i) nrm += x[i] * x[i];
+      nrm = std::sqrt(nrm);
+      if (!(nrm > 0.0) || !std::isfinite(nrm)) return 1;
+      for (int i = 0; i < n; ++i) x[i] /= nrm;
+    }
+    for (int i = 0; i < n; ++i) vk[i] = x[i];   // eigenvector of T (kept for the cluster orthogonalisation)
+  }
+  // back-transform  V <- Q V,  Q = H_0 ... H_{n-3}:  apply H_i for i = n-3 .. 0 to rows i+1 .. n-1
+  for (int i = n - 3; i >= 0; --i) {
+    const double t = tau[i];
+    if (t == 0.0) continue;
+    const double* v = &at(a, n, i + 1, i);  // v[0] = 1 implicit, v[1..] stored
+    const int s = n - i - 1;
+    for (int c = 0; c < m; ++c) {
+      double* z = V + (size_t)c * n + i + 1;
+      double dot = z[0];
+      for (int r = 1; r < s; ++r) dot += v[r] * z[r];
+      dot *= t;
+      z[0] -= dot;
+      for (int r = 1; r < s; ++r) z[r] -= dot * v[r];
+    }
+  }
+  return 0;
+}
+
 }  // namespace
 
 // a: n x n symmetric, column-major; overwritten with eigenvectors (columns); w: eigenvalues ascending.
@@ -181,6 +445,38 @@ int sym_eig(int n, double* a, double* w) {
   return 0;
 }
 
-}  // namespace si
+// Top-m eigenpairs of the symmetric n x n matrix g (column-major, left intact): w_top descending, V n x m, lam_min_out
+// unused (<0) ... verified: every returned pair satisfies ||g v - w v|| <= 1e-12 ||g||_F and the vectors are orthonormal
+// to 1e-10; returns 0 ok, 1 = failed (the caller uses the full solver).
+int sym_eig_top(int n, const double* g, int m, double* w_top, double* V) {
+  if (n <= 0 || m <= 0 || m > n) return 1;
+  if (n < 8 || 3 * m > n) return 1;  // no advantage over the full solver
+  std::vector<double> a(g, g + (size_t)n * n);
+  if (sym_eig_top_unverified(n, a.data(), m, w_top, V) != 0) return 1;
+  double fro = 0.0;
+  for (size_t i = 0; i < (size_t)n * n; ++i) fro += g[i] * g[i];
+  fro = std::sqrt(fro);
+  std::vector<double> r(n);
+  for (int k = 0; k < m; ++k) {
+    const double* v = V + (size_t)k * n;
+    for (int i = 0; i < n; ++i) r[i] = -w_top[k] * v[i];
+    for (int j = 0; j < n; ++j) {
+      const double vj = v[j];
+      const double* col = g + (size_t)j * n;
+      for (int i = 0; i < n; ++i) r[i] += col[i] * vj;
+    }
+    double res = 0.0;
+    for (int i = 0; i < n; ++i) res += r[i] * r[i];
+    if (!(std::sqrt(res) <= 1e-12 * fro)) return 1;
+    for (int c = 0; c <= k; ++c) {
+      const double* vc = V + (size_t)c * n;
+      double dot = 0.0;
+      for (int i = 0; i < n; ++i) dot += vc[i] * v[i];
+      if (!(std::fabs(dot - (c == k ? 1.0 : 0.0)) <= 1e-10)) return 1;
+    }
+  }
+  return 0;
+}
 
-extern "C" int si_host_sym_eig(int n, double* a, double* w) { return si::sym_eig(n, a, w); }
+}  // namespace SI_EIG_NS
+}  // namespace si

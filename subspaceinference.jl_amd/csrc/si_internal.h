@@ -218,6 +218,9 @@ void launch_rwmh_accept(hipStream_t st, double* zcur, const double* zprop, doubl
 // host symmetric eigensolver (eig.cpp): a is n x n symmetric col-major, overwritten by eigenvectors
 // (columns), w gets eigenvalues ascending.  Returns 0 on success.
 int sym_eig(int n, double* a, double* w);
+// M largest eigenpairs without the full eigenvector matrix (eig.cpp); g is left intact; w_top descending, V n x m.
+// Verified (residual, orthogonality); returns non-zero when the caller should use sym_eig instead.
+int sym_eig_top(int n, const double* g, int m, double* w_top, double* V);
 
 }  // namespace si
 

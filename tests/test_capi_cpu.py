@@ -66,6 +66,51 @@ def test_host_eigensolver(si):
     assert np.allclose(w, [0, 1, 3, 3])
 
 
+def test_host_top_eigenpairs(si):
+    """The route si_construct_finish takes first (eig.cpp sym_eig_top): M largest eigenpairs by factored Householder +
+    vector-free QL + inverse iteration; self-verifying, declines when it has no advantage."""
+    rng = np.random.default_rng(3)
+    cases = []
+    for n, m in ((100, 20), (64, 3), (200, 20), (31, 10)):
+        cases.append(("walk", np.cumsum(rng.standard_normal((3 * n, n)), axis=1), m))
+        cases.append(("gauss", rng.standard_normal((3 * n, n)), m))
+    a = rng.standard_normal((400, 100))
+    a[:, 1] = a[:, 0]                       # duplicated column: a zero eigenvalue at the BOTTOM of the spectrum
+    cases.append(("dup", a, 20))
+    cases.append(("lowrank", rng.standard_normal((400, 25)) @ rng.standard_normal((25, 100)), 20))
+    b = rng.standard_normal((300, 60))
+    b[:, 5] = b[:, 4] * (1 + 1e-9)          # a nearly repeated direction
+    cases.append(("near-dup", b, 12))
+    for name, a, m in cases:
+        g = a.T @ a
+        r = si.host_sym_eig_top(g, m)
+        assert r is not None, name
+        w, v = r
+        ref = np.linalg.eigvalsh(g)[::-1][:m]
+        assert np.allclose(w, ref, rtol=1e-11, atol=1e-12 * ref[0]), name
+        assert np.linalg.norm(g @ v - v * w[None, :]) <= 1e-11 * np.linalg.norm(g), name
+        assert np.abs(v.T @ v - np.eye(m)).max() < 1e-9, name
+        wf, vf = si.host_sym_eig(g)          # same subspace as the full solver
+        top = vf[:, ::-1][:, :m]
+        gap_ok = ref[m - 1] - np.linalg.eigvalsh(g)[::-1][m] > 1e-8 * ref[0] if m < g.shape[0] else True
+        if gap_ok:
+            assert np.abs(np.abs(np.linalg.svd(top.T @ v, compute_uv=False)) - 1).max() < 1e-7, name
+    # exactly repeated TOP eigenvalues: any orthonormal basis of the eigenspace is right; the verification must hold
+    q, _ = np.linalg.qr(rng.standard_normal((40, 40)))
+    lam = np.r_[np.full(4, 7.0), np.linspace(3, 0.1, 36)]
+    g = (q * lam) @ q.T
+    g = 0.5 * (g + g.T)
+    r = si.host_sym_eig_top(g, 6)
+    if r is not None:                        # (may also decline: then si_construct_finish uses the full solver)
+        w, v = r
+        assert np.allclose(w[:4], 7.0, rtol=1e-12) and np.linalg.norm(g @ v - v * w) <= 1e-11 * np.linalg.norm(g)
+        assert np.abs(v.T @ v - np.eye(6)).max() < 1e-9
+    # declines when it has no advantage / arguments make no sense
+    assert si.host_sym_eig_top(np.eye(6), 2) is None          # tiny
+    assert si.host_sym_eig_top(g, 30) is None                 # 3 m > n
+    assert si.host_sym_eig_top(np.zeros((50, 50)), 5) is not None or True   # must not crash on the zero matrix
+
+
 def test_flux_standins_match_reference_semantics():
     from subspaceinference_jl_amd import flux
     rng = np.random.default_rng(1)
