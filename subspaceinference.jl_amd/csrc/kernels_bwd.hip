@@ -15,6 +15,7 @@
 // generic over the two storage orders an operand can have:
 //   layout 0 "row-fast": X[r + ld*k]  -> LDS [k][R+16]      layout 1 "k-fast": X[k + ld*r] -> LDS [r][18]
 // Both LDS images give conflict-free ds_read_b64 operand reads (same bank arithmetic as the forward kernel).
+#include <algorithm>
 #include <type_traits>
 
 #include "kernels_gemm.h"
@@ -454,6 +455,20 @@ void launch_backward_weight(hipStream_t st, const double* Delta, const double* H
     case 96: launch_gemm<96, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0); break;
     case 128: launch_gemm<128, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0); break;
     default: launch_gemm<64, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0); break;
+  }
+}
+
+// K3 for wide subspaces (M > 32), on the matrix cores:  P[N x M] = A[N x K] * V[K x M]  with  A(m = row, k) = A[m + ldA*k]
+// (row-fast) and B(k, n) = V[n + Mpad*k] (row-fast), no split.  The VALU kernel of kernels_gram.hip holds M accumulators
+// per row in registers, needs one pass over A per 32 columns and runs at 2 waves per SIMD: at cfg5 (K = 128, M = 64,
+// 6.4 M rows per GPU) it took 25 ms; this is the same 105 GFLOP as MFMA work on one pass over A.
+void launch_project_mfma(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, const double* V, int32_t M,
+                         int32_t Mpad, double* P, int64_t ldP) {
+  const int64_t ks = (K + 15) / 16 * 16;
+  for (int32_t m0 = 0; m0 < M; m0 += 64) {   // 64-column panels of P (one panel up to M = 64)
+    const int32_t mc = M - m0 < 64 ? M - m0 : 64;
+    launch_gemm<128, 64, 0, 0, EPI_RAW>(st, A, ldA, V + m0, Mpad, P + (int64_t)m0 * ldP, ldP, (int)std::min<int64_t>(N, 0x7fffffff),
+                                        mc, K, 1, ks, nullptr, 0);
   }
 }
 

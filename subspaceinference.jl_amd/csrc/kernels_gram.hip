@@ -430,6 +430,10 @@ int project_mpad(int M) {
 
 void launch_project(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, const double* V,
                     int32_t M, int32_t Mpad, double* P, int64_t ldP, int num_cu) {
+  if (M > 32 && N < 0x7fffffff) {  // wide subspace: one pass over A on the matrix cores instead of ceil(M/32) VALU passes
+    launch_project_mfma(st, A, ldA, N, K, V, M, Mpad, P, ldP);
+    return;
+  }
   int64_t blocks = (((N + 1) >> 1) + 255) / 256;
   if (blocks > (int64_t)num_cu * 8) blocks = (int64_t)num_cu * 8;
   if (blocks < 1) blocks = 1;

@@ -84,7 +84,9 @@ def test_push_state_errors(si, gpu_ctx):
 
 # ----------------------------------------------------------------------------------------------- K2 / H1 / K3
 @pytest.mark.parametrize("n,k,m", [(682, 12, 3), (5000, 64, 8), (4097, 65, 20), (100003, 100, 20), (682, 200, 5),
-                                   (50, 130, 4)])
+                                   (50, 130, 4),
+                                   # M > 32: projection on the matrix cores (kernels_bwd.hip launch_project_mfma)
+                                   (20000, 128, 64), (4097, 100, 33), (3001, 80, 70), (130, 40, 36)])
 def test_gram_and_projection(gpu_ctx, n, k, m):
     snaps = _snap_stream(n, k, seed=7 * n + k, dtype=np.float32)
     ns = [float(1 + i // 4) for i in range(k)]
