@@ -785,6 +785,7 @@ static int32_t ensure_grad(si_ctx* ctx) {
     maxpart = std::max(maxpart, (size_t)ns * ly.out * ly.in);
     ok = dev_alloc(&ctx->d_hs[l], (size_t)ly.out * B) == hipSuccess;
   }
+  if (ctx->fuse_tail) maxpart = std::max(maxpart, tail_bwd_part_elems(ctx->layers.back().out, ctx->layers.back().in));
   ok = ok && dev_alloc(&ctx->d_delta[0], (size_t)maxw * B) == hipSuccess &&
        dev_alloc(&ctx->d_delta[1], (size_t)maxw * B) == hipSuccess &&
        dev_alloc(&ctx->d_gw, (size_t)pad_ld(ctx->iN)) == hipSuccess && dev_alloc(&ctx->d_bwpart, maxpart) == hipSuccess &&
@@ -818,9 +819,11 @@ int32_t si_logdensity_grad(si_ctx* ctx, const double* z, double* lp_out, double*
     ProfScope ps(ctx, SI_K_RECON, 2.0 * (double)N * M, (double)N * (M + 2) * 8.0);
     launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, ctx->d_zprop, 1, ctx->d_w, pad_ld(N), ctx->num_cu);
   }
-  // forward with every layer's output kept (the fused tail is not used here: the backward sweep needs them all)
+  // forward with every layer's output kept for the reverse sweep.  With a narrow head (fuse_tail) the layer in front
+  // of it stores its output AND feeds the head from its epilogue, so the head costs no pass over that activation.
   const double* h = ctx->d_X;
-  for (size_t l = 0; l < nl; ++l) {
+  const size_t nplain = ctx->fuse_tail ? nl - 2 : nl;
+  for (size_t l = 0; l < nplain; ++l) {
     const si_layer& ly = ctx->layers[l];
     ProfScope ps(ctx, SI_K_DENSE, 2.0 * (double)ly.in * ly.out * (double)B,
                  ((double)ly.in * ly.out + ly.out + (double)(ly.in + ly.out) * (double)B) * 8.0);
@@ -828,7 +831,21 @@ int32_t si_logdensity_grad(si_ctx* ctx, const double* z, double* lp_out, double*
     h = ctx->d_hs[l];
   }
   const int64_t d = (int64_t)ctx->out_dim * B;
-  {
+  if (ctx->fuse_tail) {
+    const si_layer& ly = ctx->layers[nl - 2];
+    const si_layer& ll = ctx->layers[nl - 1];
+    {
+      ProfScope ps(ctx, SI_K_DENSE, 2.0 * ((double)ly.in * ly.out + (double)ll.in * ll.out) * (double)B,
+                   ((double)ly.in * ly.out + ly.out + (double)(ly.in + ly.out) * (double)B) * 8.0);
+      launch_dense_f64_fused(ctx->stream, ctx->d_w + ly.w_off, ctx->d_w + ly.b_off, h, ly.out, ly.in, B, ly.act,
+                             ctx->d_w + ll.w_off, ll.out, ctx->d_part, ChainBatch(), ctx->d_hs[nl - 2]);
+    }
+    ProfScope ps(ctx, SI_K_SSE, (3.0 + ctx->fuse_slots) * (double)d, (16.0 + 8.0 * ctx->fuse_slots) * (double)d);
+    launch_tail_sse(ctx->stream, ctx->d_part, ctx->fuse_slots, ll.out, B, ctx->d_w + ll.b_off, ll.act, ctx->d_Y,
+                    ctx->d_hs[nl - 1], ctx->d_ssepart, ctx->sse_blocks);
+    launch_sse_final(ctx->stream, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse);
+    h = ctx->d_hs[nl - 1];
+  } else {
     ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d, 16.0 * (double)d);
     launch_sse(ctx->stream, h, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse);
   }
@@ -840,10 +857,23 @@ int32_t si_logdensity_grad(si_ctx* ctx, const double* z, double* lp_out, double*
     int cur = 0;
     // d lp / d yhat = (y - yhat) / sigma^2
     launch_delta_out(ctx->stream, ctx->d_Y, h, d, 1.0 / s2, ctx->layers[nl - 1].act, ctx->d_delta[cur]);
-    for (size_t li = nl; li-- > 0;) {
+    size_t top = nl;          // layers [0, top) still go through the generic sweep
+    bool have_db = false;     // db of layer top-1 already produced by the fused tail
+    if (ctx->fuse_tail) {
+      // narrow head: Delta_{L-1}, dW_L and db_{L-1} in one pass over H_{L-1}
+      const si_layer& ll = ctx->layers[nl - 1];
+      const si_layer& lp = ctx->layers[nl - 2];
+      launch_rowsum(ctx->stream, ctx->d_delta[cur], ll.out, B, ctx->d_rspart, ctx->d_gw + ll.b_off);
+      launch_tail_bwd(ctx->stream, ctx->d_w + ll.w_off, ctx->d_delta[cur], ctx->d_hs[nl - 2], ll.out, ll.in, B, lp.act,
+                      ctx->d_delta[cur ^ 1], ctx->d_bwpart, ctx->d_gw + ll.w_off, ctx->d_gw + lp.b_off);
+      cur ^= 1;
+      top = nl - 1;
+      have_db = true;
+    }
+    for (size_t li = top; li-- > 0;) {
       const si_layer& ly = ctx->layers[li];
       const double* hprev = li > 0 ? ctx->d_hs[li - 1] : ctx->d_X;
-      launch_rowsum(ctx->stream, ctx->d_delta[cur], ly.out, B, ctx->d_rspart, ctx->d_gw + ly.b_off);
+      if (!(have_db && li + 1 == top)) launch_rowsum(ctx->stream, ctx->d_delta[cur], ly.out, B, ctx->d_rspart, ctx->d_gw + ly.b_off);
       int64_t ks;
       const int ns = backward_weight_splits(ly.out, ly.in, B, ctx->num_cu, &ks);
       launch_backward_weight(ctx->stream, ctx->d_delta[cur], hprev, ctx->d_bwpart, ly.out, ly.in, B, ns, ks, ctx->num_cu);

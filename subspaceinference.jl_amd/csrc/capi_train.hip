@@ -76,7 +76,7 @@ void free_train(Ctx* c) {
   if (!t) return;
   release(t->X); release(t->Y); release(t->Xb); release(t->Yb); release(t->idx); release(t->w32); release(t->m32);
   release(t->v32); release(t->w64); release(t->gw); release(t->delta[0]); release(t->delta[1]); release(t->bwpart);
-  release(t->rspart); release(t->ssepart); release(t->sse);
+  release(t->rspart); release(t->ssepart); release(t->sse); release(t->part);
   for (auto& h : t->hs) release(h);
   delete t;
   c->train = nullptr;
@@ -110,6 +110,8 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
     maxpart = std::max(maxpart, (size_t)ns * ly.out * ly.in);
   }
   if (width != out_dim) return fail(ctx, SI_ERR_INVALID, "si_train_setup: last layer width != out_dim");
+  const bool fuse_tail = (L >= 2) && layers[L - 1].out <= SI_FUSE_MAX_OUT;
+  if (fuse_tail) maxpart = std::max(maxpart, tail_bwd_part_elems(layers[L - 1].out, layers[L - 1].in));
   SI_HIP(ctx, hipSetDevice(ctx->device));
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   free_train(ctx);
@@ -119,6 +121,8 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
   t->N = N; t->Btot = B_total; t->Bmax = batch_max; t->in_dim = in_dim; t->out_dim = out_dim;
   t->opt = opt_kind; t->eta = eta; t->p1 = p1; t->p2 = p2; t->bp1 = p1; t->bp2 = p2;  // ADAM: beta powers start at beta
   t->sse_blocks = sse_num_blocks((int64_t)out_dim * batch_max, ctx->num_cu);
+  t->fuse_tail = fuse_tail;
+  t->fuse_slots = fuse_tail ? dense_fused_slots(layers[L - 2].out) : 0;
   t->hs.assign((size_t)L, nullptr);
   bool ok = alloc(&t->X, (size_t)in_dim * B_total) && alloc(&t->Y, (size_t)out_dim * B_total) &&
             alloc(&t->Xb, (size_t)in_dim * batch_max) && alloc(&t->Yb, (size_t)out_dim * batch_max) &&
@@ -126,7 +130,8 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
             alloc(&t->v32, (size_t)N) && alloc(&t->w64, (size_t)pad_ld(N)) && alloc(&t->gw, (size_t)pad_ld(N)) &&
             alloc(&t->delta[0], (size_t)maxw * batch_max) && alloc(&t->delta[1], (size_t)maxw * batch_max) &&
             alloc(&t->bwpart, maxpart) && alloc(&t->rspart, (size_t)rowsum_chunks() * maxw) &&
-            alloc(&t->ssepart, (size_t)t->sse_blocks) && alloc(&t->sse, 1);
+            alloc(&t->ssepart, (size_t)t->sse_blocks) && alloc(&t->sse, 1) &&
+            (!fuse_tail || alloc(&t->part, (size_t)t->fuse_slots * out_dim * batch_max));
   for (int l = 0; l < L && ok; ++l) ok = alloc(&t->hs[(size_t)l], (size_t)layers[l].out * batch_max);
   if (!ok) {
     free_train(ctx);
@@ -163,15 +168,32 @@ static int32_t train_gradient(si_ctx* ctx, const char* who, const int64_t* idx, 
   hipLaunchKernelGGL(gather_cols_kernel, dim3(grid_for((int64_t)t->out_dim * nb, ctx->num_cu)), dim3(256), 0, st, t->Y,
                      t->out_dim, t->idx, nb, t->Yb);
   hipLaunchKernelGGL(widen_kernel, dim3(grid_for(N, ctx->num_cu)), dim3(256), 0, st, t->w32, N, t->w64);
+  // forward with every layer's output kept; a narrow head is fed from the epilogue of the layer in front of it
   const double* h = t->Xb;
-  for (size_t l = 0; l < nl; ++l) {
+  const size_t nplain = t->fuse_tail ? nl - 2 : nl;
+  for (size_t l = 0; l < nplain; ++l) {
     const si_layer& ly = t->layers[l];
     ProfScope ps(ctx, SI_K_DENSE, 2.0 * (double)ly.in * ly.out * (double)nb, 0.0);
     launch_dense_f64(st, t->w64 + ly.w_off, t->w64 + ly.b_off, h, t->hs[l], ly.out, ly.in, nb, ly.act);
     h = t->hs[l];
   }
   const int64_t d = (int64_t)t->out_dim * nb;
-  launch_sse(st, h, t->Yb, d, t->ssepart, sse_num_blocks(d, ctx->num_cu), t->sse);
+  const int sse_blocks = sse_num_blocks(d, ctx->num_cu);
+  if (t->fuse_tail) {
+    const si_layer& ly = t->layers[nl - 2];
+    const si_layer& ll = t->layers[nl - 1];
+    {
+      ProfScope ps(ctx, SI_K_DENSE, 2.0 * ((double)ly.in * ly.out + (double)ll.in * ll.out) * (double)nb, 0.0);
+      launch_dense_f64_fused(st, t->w64 + ly.w_off, t->w64 + ly.b_off, h, ly.out, ly.in, nb, ly.act, t->w64 + ll.w_off, ll.out,
+                             t->part, ChainBatch(), t->hs[nl - 2]);
+    }
+    launch_tail_sse(st, t->part, t->fuse_slots, ll.out, nb, t->w64 + ll.b_off, ll.act, t->Yb, t->hs[nl - 1], t->ssepart,
+                    sse_blocks);
+    launch_sse_final(st, t->ssepart, sse_blocks, t->sse);
+    h = t->hs[nl - 1];
+  } else {
+    launch_sse(st, h, t->Yb, d, t->ssepart, sse_blocks, t->sse);
+  }
   {
     double bflops = 0.0;
     for (const auto& ly : t->layers) bflops += 4.0 * (double)ly.in * ly.out * (double)nb;
@@ -180,10 +202,22 @@ static int32_t train_gradient(si_ctx* ctx, const char* who, const int64_t* idx, 
     int cur = 0;
     // d mse / d yhat = 2 (yhat - y) / d
     launch_delta_out(st, t->Yb, h, d, -2.0 / d_total, t->layers[nl - 1].act, t->delta[cur]);
-    for (size_t li = nl; li-- > 0;) {
+    size_t top = nl;
+    bool have_db = false;
+    if (t->fuse_tail) {  // narrow head: Delta_{L-1}, dW_L and db_{L-1} in one pass over H_{L-1}
+      const si_layer& ll = t->layers[nl - 1];
+      const si_layer& lp = t->layers[nl - 2];
+      launch_rowsum(st, t->delta[cur], ll.out, nb, t->rspart, t->gw + ll.b_off);
+      launch_tail_bwd(st, t->w64 + ll.w_off, t->delta[cur], t->hs[nl - 2], ll.out, ll.in, nb, lp.act, t->delta[cur ^ 1],
+                      t->bwpart, t->gw + ll.w_off, t->gw + lp.b_off);
+      cur ^= 1;
+      top = nl - 1;
+      have_db = true;
+    }
+    for (size_t li = top; li-- > 0;) {
       const si_layer& ly = t->layers[li];
       const double* hprev = li > 0 ? t->hs[li - 1] : t->Xb;
-      launch_rowsum(st, t->delta[cur], ly.out, nb, t->rspart, t->gw + ly.b_off);
+      if (!(have_db && li + 1 == top)) launch_rowsum(st, t->delta[cur], ly.out, nb, t->rspart, t->gw + ly.b_off);
       int64_t ks;
       const int ns = backward_weight_splits(ly.out, ly.in, nb, ctx->num_cu, &ks);
       launch_backward_weight(st, t->delta[cur], hprev, t->bwpart, ly.out, ly.in, nb, ns, ks, ctx->num_cu);

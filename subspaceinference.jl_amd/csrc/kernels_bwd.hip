@@ -541,6 +541,128 @@ void launch_rowsum(hipStream_t st, const double* D, int32_t out, int64_t B, doub
 }
 int rowsum_chunks() { return RS_CHUNKS; }
 
+// Reverse sweep through a NARROW last layer (out_last <= 4: regression heads) in ONE pass over its input H (F x B):
+//   Delta_prev[i,b] = (sum_o W[o,i] Delta[o,b]) * act_prev'(H[i,b])      (written, F x B)
+//   dW[o,i]         = sum_b Delta[o,b] H[i,b]                            (chunk partials, summed in fixed order)
+//   db_prev[i]      = sum_b Delta_prev[i,b]                              (chunk partials, summed in fixed order)
+// The generic route runs three GEMM-shaped launches with a degenerate dimension plus a row-sum pass, each reading or
+// writing the 768 MB activation again (cfg2: 0.95 ms); this kernel is bound by one read of H and one write of
+// Delta_prev.  A thread owns E consecutive features (16-B accesses when F is even) and walks its chunk of columns;
+// Delta[:, b] is block-uniform.
+constexpr int TAILB_CHUNKS = 512;
+template <int OL, int E>
+__global__ __launch_bounds__(256) void tail_bwd_kernel(const double* __restrict__ W, const double* __restrict__ Delta,
+                                                       const double* __restrict__ H, int F, int64_t B, int act_prev,
+                                                       double* __restrict__ DeltaPrev, double* __restrict__ part,
+                                                       int64_t cols) {
+  const int i = (blockIdx.x * 256 + threadIdx.x) * E;
+  if (i >= F) return;
+  const int64_t b0 = (int64_t)blockIdx.y * cols;
+  int64_t b1 = b0 + cols;
+  if (b1 > B) b1 = B;
+  double w[OL][E], dw[OL][E], db[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    db[e] = 0.0;
+#pragma unroll
+    for (int o = 0; o < OL; ++o) {
+      w[o][e] = (i + e < F) ? W[o + (int64_t)OL * (i + e)] : 0.0;
+      dw[o][e] = 0.0;
+    }
+  }
+#pragma unroll 4
+  for (int64_t b = b0; b < b1; ++b) {
+    double h[E];
+    if constexpr (E == 2) {
+      const double2 v = *reinterpret_cast<const double2*>(H + i + (int64_t)F * b);
+      h[0] = v.x;
+      h[1] = v.y;
+    } else {
+      h[0] = H[i + (int64_t)F * b];
+    }
+    double dl[OL];
+#pragma unroll
+    for (int o = 0; o < OL; ++o) dl[o] = Delta[o + (int64_t)OL * b];
+    double d[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      double t = 0.0;
+#pragma unroll
+      for (int o = 0; o < OL; ++o) {
+        t = fma(w[o][e], dl[o], t);
+        dw[o][e] = fma(dl[o], h[e], dw[o][e]);
+      }
+      d[e] = t * dact_from_output(h[e], act_prev);
+      db[e] += d[e];
+    }
+    if constexpr (E == 2)
+      *reinterpret_cast<double2*>(DeltaPrev + i + (int64_t)F * b) = make_double2(d[0], d[1]);
+    else
+      DeltaPrev[i + (int64_t)F * b] = d[0];
+  }
+  double* pp = part + (int64_t)blockIdx.y * (OL + 1) * F;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if (i + e >= F) continue;
+#pragma unroll
+    for (int o = 0; o < OL; ++o) pp[(int64_t)o * F + i + e] = dw[o][e];
+    pp[(int64_t)OL * F + i + e] = db[e];
+  }
+}
+
+// dW[o + OL*i] = sum_chunks part[c][o][i];  db_prev[i] = sum_chunks part[c][OL][i].  Block = 32 entries x 8 chunk lanes:
+// lane j adds chunks j, j+8, ... in order, the eight lane sums are added in a fixed tree => deterministic.
+__global__ __launch_bounds__(256) void tail_bwd_reduce_kernel(const double* __restrict__ part, int chunks, int OL, int F,
+                                                              double* __restrict__ dW, double* __restrict__ dbprev) {
+  __shared__ double red[8][33];
+  const int il = threadIdx.x & 31, cl = threadIdx.x >> 5;
+  const int total = (OL + 1) * F;
+  const int idx = blockIdx.x * 32 + il;
+  double s = 0.0;
+  if (idx < total)
+    for (int c = cl; c < chunks; c += 8) s += part[(int64_t)c * total + idx];
+  red[cl][il] = s;
+  __syncthreads();
+  if (cl == 0 && idx < total) {
+    const double t = ((red[0][il] + red[1][il]) + (red[2][il] + red[3][il])) + ((red[4][il] + red[5][il]) + (red[6][il] + red[7][il]));
+    const int o = idx / F, i = idx - o * F;
+    if (o < OL)
+      dW[o + (int64_t)OL * i] = t;
+    else
+      dbprev[i] = t;
+  }
+}
+
+size_t tail_bwd_part_elems(int32_t out_last, int32_t F) { return (size_t)TAILB_CHUNKS * (out_last + 1) * F; }
+
+void launch_tail_bwd(hipStream_t st, const double* W, const double* Delta, const double* H, int32_t out_last, int32_t F,
+                     int64_t B, int32_t act_prev, double* DeltaPrev, double* part, double* dW, double* dbprev) {
+  int chunks = TAILB_CHUNKS;
+  if (chunks > B) chunks = (int)B;
+  const int64_t cols = (B + chunks - 1) / chunks;
+  chunks = (int)((B + cols - 1) / cols);
+  const bool vec = (F % 2 == 0) && ((reinterpret_cast<uintptr_t>(H) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(DeltaPrev) & 15u) == 0);
+  const int per = 256 * (vec ? 2 : 1);
+  const dim3 grid((F + per - 1) / per, chunks);
+#define SI_TAILB(OLV)                                                                                                  \
+  if (vec)                                                                                                             \
+    hipLaunchKernelGGL((tail_bwd_kernel<OLV, 2>), grid, dim3(256), 0, st, W, Delta, H, (int)F, B, (int)act_prev,       \
+                       DeltaPrev, part, cols);                                                                         \
+  else                                                                                                                 \
+    hipLaunchKernelGGL((tail_bwd_kernel<OLV, 1>), grid, dim3(256), 0, st, W, Delta, H, (int)F, B, (int)act_prev,       \
+                       DeltaPrev, part, cols)
+  switch (out_last) {
+    case 1: SI_TAILB(1); break;
+    case 2: SI_TAILB(2); break;
+    case 3: SI_TAILB(3); break;
+    default: SI_TAILB(4); break;
+  }
+#undef SI_TAILB
+  const int total = (out_last + 1) * F;
+  hipLaunchKernelGGL(tail_bwd_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, st, part, chunks, (int)out_last,
+                     (int)F, dW, dbprev);
+}
+
 // grad_z[m] = sum_r P[r + ldP*m] * g[r]   (HBM-bound: P is read once, N*M*8 bytes)
 constexpr int PTG_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void ptg_partial_kernel(const double* __restrict__ P, int64_t ldP, int64_t N, int M,

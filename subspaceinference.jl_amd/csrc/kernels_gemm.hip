@@ -60,6 +60,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f64_kernel(
     if constexpr (FUSE) {
       Wlast += ch * cb.w;
       part += ch * cb.part;
+      if (Hout != nullptr) Hout += ch * cb.hout;
     } else {
       Hout += ch * cb.hout;
     }
@@ -318,6 +319,17 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f64_kernel(
       for (int b = 0; b < TN; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[a][b][r] = finish(acc[a][b][r] + bv[a]);
+    if (Hout != nullptr) {  // block-uniform: the gradient / training forward keeps this layer's output for the reverse sweep
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t gb = bw0 + b * 16 + q + 4 * r;
+            if (gi[a] < out && gb < B) Hout[gi[a] + (int64_t)out * gb] = acc[a][b][r];
+          }
+    }
     const int64_t slot = (int64_t)mt * WM + wm;
     for (int o = 0; o < out_last; ++o) {
       double wl[TM];
@@ -471,17 +483,17 @@ int dense_fused_slots(int32_t out) {
 
 void launch_dense_f64_fused(hipStream_t st, const double* W, const double* bias, const double* Hin, int32_t out,
                             int32_t in, int64_t B, int32_t act, const double* Wlast, int32_t out_last, double* part,
-                            const ChainBatch& cb) {
+                            const ChainBatch& cb, double* Hkeep) {
   FuseArgs fa;
   fa.Wlast = Wlast;
   fa.out_last = out_last;
   fa.part = part;
   fa.cb = cb;
   switch (pick_bm(out)) {
-    case 32: launch_dense_cfg<32, 128, 1, 4, 2, true>(st, W, bias, Hin, nullptr, out, in, B, act, fa); break;
-    case 96: launch_dense_cfg<96, 128, 2, 4, 4, true>(st, W, bias, Hin, nullptr, out, in, B, act, fa); break;
-    case 128: launch_dense_cfg<128, 128, 2, 4, 4, true>(st, W, bias, Hin, nullptr, out, in, B, act, fa); break;
-    default: launch_dense_cfg<64, 128, 2, 4, 4, true>(st, W, bias, Hin, nullptr, out, in, B, act, fa); break;
+    case 32: launch_dense_cfg<32, 128, 1, 4, 2, true>(st, W, bias, Hin, Hkeep, out, in, B, act, fa); break;
+    case 96: launch_dense_cfg<96, 128, 2, 4, 4, true>(st, W, bias, Hin, Hkeep, out, in, B, act, fa); break;
+    case 128: launch_dense_cfg<128, 128, 2, 4, 4, true>(st, W, bias, Hin, Hkeep, out, in, B, act, fa); break;
+    default: launch_dense_cfg<64, 128, 2, 4, 4, true>(st, W, bias, Hin, Hkeep, out, in, B, act, fa); break;
   }
 }
 

@@ -37,6 +37,9 @@ struct TrainState {
   int opt = 0;
   double eta = 0.0, p1 = 0.0, p2 = 0.0, bp1 = 0.0, bp2 = 0.0;
   bool grad_ready = false;  // gw holds a gradient that has not been applied yet
+  bool fuse_tail = false;   // narrow head: folded into the epilogue of the layer in front of it (forward and reverse)
+  int fuse_slots = 0;
+  double* part = nullptr;   // [fuse_slots][out_last][Bmax] partial head products
 };
 
 struct Ctx {
@@ -186,7 +189,7 @@ constexpr int SI_FUSE_MAX_OUT = 4;
 int dense_fused_slots(int32_t out);
 void launch_dense_f64_fused(hipStream_t st, const double* W, const double* bias, const double* Hin, int32_t out,
                             int32_t in, int64_t B, int32_t act, const double* Wlast, int32_t out_last, double* part,
-                            const ChainBatch& cb = ChainBatch());
+                            const ChainBatch& cb = ChainBatch(), double* Hkeep = nullptr /* also store the layer's output */);
 void launch_tail_sse(hipStream_t st, const double* part, int slots, int out_last, int64_t B, const double* bias_last,
                      int act_last, const double* Y, double* yhat, double* blockpart, int nblocks,
                      const ChainBatch& cb = ChainBatch());
@@ -206,6 +209,11 @@ void launch_backward_weight(hipStream_t st, const double* Delta, const double* H
 void launch_split_reduce(hipStream_t st, const double* part, int nsplit, int64_t elems, double* dst);
 void launch_delta_out(hipStream_t st, const double* Y, const double* Yhat, int64_t d, double scale, int act, double* delta);
 void launch_rowsum(hipStream_t st, const double* D, int32_t out, int64_t B, double* part, double* db);
+// reverse sweep through a narrow last layer (out_last <= SI_FUSE_MAX_OUT) in one pass over its input H (F x B):
+// DeltaPrev = (W' Delta) .* act_prev'(H), dW = Delta H', dbprev = rowsum(DeltaPrev); part: tail_bwd_part_elems doubles
+size_t tail_bwd_part_elems(int32_t out_last, int32_t F);
+void launch_tail_bwd(hipStream_t st, const double* W, const double* Delta, const double* H, int32_t out_last, int32_t F,
+                     int64_t B, int32_t act_prev, double* DeltaPrev, double* part, double* dW, double* dbprev);
 int rowsum_chunks();
 void launch_ptg(hipStream_t st, const double* P, int64_t ldP, int64_t N, int M, const double* g, double* part, double* gz);
 int ptg_blocks();
