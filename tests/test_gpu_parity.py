@@ -818,3 +818,37 @@ def test_api_multi_chain(si, gpu_ctx):
     assert len(chn) == 4 and len(chn[0]) == 12 and np.allclose(chn[2][5], w_swa + p @ z[:, 5, 2], rtol=1e-13)
     with pytest.raises(si.SubspaceError):
         si.sub_inference(model, data, w_swa, p, itr=5, M=3, ctx=gpu_ctx, alg="hmc", nchains=2)
+
+
+def test_nn_example_flow(si, gpu_ctx):
+    """docs/src/nn_example.md:181-217 end to end: MLP 2-200-50-50-50-1, `subspace_inference(m, L1, data, opt, σ_z=0.1,
+    itr=100, T=10, c=1, M=3, alg=:rwmh)`, then the predictive trajectories `re(all_chain[i])(inp)` on new inputs --
+    here from `Context.predict` (no weight vector materialised) and checked against the oracle forward on the returned
+    weight samples."""
+    from subspaceinference_jl_amd import flux
+    rng = np.random.default_rng(0)
+    zdata = rng.uniform(-3, 3, 400)
+    x = np.asfortranarray(np.stack([zdata / 10.0, (zdata / 10.0) ** 2]))     # features(z)
+    y = np.asfortranarray((np.sin(zdata) + 0.1 * rng.standard_normal(400))[None, :])
+    wr = np.random.default_rng(1)
+    m = flux.Chain(flux.Dense(2, 200, flux.relu, rng=wr), flux.Dense(200, 50, flux.relu, rng=wr),
+                   flux.Dense(50, 50, flux.relu, rng=wr), flux.Dense(50, 50, flux.relu, rng=wr), flux.Dense(50, 1, rng=wr))
+    data = flux.DataLoader(x, y, batchsize=100, shuffle=True, rng=np.random.default_rng(2))
+    itr, mm = 100, 3
+    chn, lp, w_swa = si.subspace_inference(m, flux.mse, data, flux.ADAM(0.01), σ_z=0.1, itr=itr, T=10, c=1, M=mm,
+                                           print_freq=10, alg=":rwmh", ctx=gpu_ctx, seed=3, verbose=False)
+    table, n = flux.layer_table(m)
+    assert len(chn) == itr and chn[0].shape == (n,) and lp.shape == (itr,) and w_swa.shape == (n,)
+    assert np.all(np.isfinite(lp)) and len(set(np.round(lp, 9))) > 3        # the chain moves (doc: constant lp = all rejected)
+    # same call with return_z: the chain in subspace coordinates; weights = W_swa + P z (the context still holds P)
+    z, lp2, _ = gpu_ctx.sample_rwmh(itr, 0.1, seed=3, chain_id0=0, nchains=1)
+    assert np.array_equal(lp2[:, 0], lp)
+    w = gpu_ctx.reconstruct(z[:, :, 0])
+    assert all(np.array_equal(w[:, t], chn[t]) for t in (0, 17, itr - 1))
+    zin = np.linspace(-10.0, 10.0, 100)
+    inp = np.asfortranarray(np.stack([zin / 10.0, (zin / 10.0) ** 2]))
+    traj = gpu_ctx.predict(z[:, :, 0], inp)                                 # 1 x 100 x itr
+    for t in (0, 50, itr - 1):
+        ref = so.forward(table, chn[t], inp)
+        assert np.allclose(traj[:, :, t], ref, rtol=1e-9, atol=1e-10)
+    assert traj[0].std(axis=1).max() > 0.0                                  # a predictive band, not a single curve
