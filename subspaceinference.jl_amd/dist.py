@@ -85,6 +85,30 @@ def allreduce_sum(a):
     return t.cpu().numpy().reshape(np.shape(a))
 
 
+def broadcast(a, src=0, shape=None, dtype=np.float64):
+    """Replicate an array from rank `src` on every rank (independent chains: W_swa / P / X / Y are broadcast
+    ONCE at setup -- 168 MB of P at cfg2 -- and nothing is exchanged per step).  Non-source ranks pass a=None and the
+    `shape` to receive into."""
+    d = _dist()
+    if d is None:
+        return np.array(a, dtype=dtype)
+    if d.get_rank() == src:
+        buf = np.ascontiguousarray(np.asfortranarray(a, dtype=dtype).ravel(order="F"))
+        shape = np.shape(a)
+    else:
+        if shape is None:
+            raise ValueError("broadcast: receiving ranks need the shape")
+        buf = np.empty(int(np.prod(shape)), dtype=dtype)
+    t = _tensor(buf)
+    d.broadcast(t, src=src)
+    return np.asfortranarray(t.cpu().numpy().reshape(shape, order="F"))
+
+
+def replicate_subspace(w_swa, p, n, m, src=0):
+    """(W_swa, P) constructed on rank `src` -> every rank (what the chains of cfg3 start from)."""
+    return broadcast(w_swa, src, (n,)), broadcast(p, src, (n, m))
+
+
 def allgather_rows(local, n_total):
     """Concatenate row blocks (row_shard order) of a vector / matrix held one block per rank."""
     d = _dist()

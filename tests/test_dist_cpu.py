@@ -139,6 +139,9 @@ def _worker(rank, world, port, q):
         zfull, lpfull, _, naccfull = so.sub_inference(table, x2, y2, ws2, p2, 0.1, 0.9, 25, seed=5)
         ok = ok and np.allclose(zsh[:, :, 0], zfull, rtol=1e-10, atol=1e-13) and np.allclose(lpsh[:, 0], lpfull, rtol=1e-11)
         ok = ok and abs(accsh[0] - naccfull / 24) < 1e-12
+        # one-off broadcast of the subspace from the constructing rank
+        wb, pb = sd.replicate_subspace(w_swa if rank == 0 else None, p_ref if rank == 0 else None, n, m, src=0)
+        ok = ok and np.array_equal(wb, w_swa) and np.array_equal(pb, p_ref) and pb.flags.f_contiguous
         # data-parallel training: each rank takes its share of every batch; one gradient all-reduce per step
         r3 = np.random.default_rng(2)
         xl, yl, w0 = r3.standard_normal((4, 30)), r3.standard_normal((2, 30)), r3.standard_normal((2, 4))
