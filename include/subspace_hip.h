@@ -89,6 +89,10 @@ const char* si_last_error(si_ctx* ctx); /* ctx may be NULL: message of the last 
 int32_t si_set_stream(si_ctx* ctx, void* hip_stream);
 int32_t si_synchronize(si_ctx* ctx);
 int32_t si_set_profiling(si_ctx* ctx, int32_t on); /* hipEvent pair around every kernel launch */
+/* restrict the event pairs to the classes whose bit (1u << SI_K_*) is set (default: all); launches / flops / bytes are
+ * counted for every class regardless.  An event pair costs ~5 us of stream time: a timed region that wants the duration
+ * of one kernel class only should say so. */
+int32_t si_set_profiling_classes(si_ctx* ctx, uint32_t class_mask);
 int32_t si_get_stats(si_ctx* ctx, si_stats* out);  /* synchronizes; resolves pending events   */
 int32_t si_reset_stats(si_ctx* ctx);
 int32_t si_device_name(si_ctx* ctx, char* buf, int32_t buflen);

@@ -52,6 +52,7 @@ SIGNATURES = {
     "si_set_stream": (c_int32, [c_void_p, c_void_p]),
     "si_synchronize": (c_int32, [c_void_p]),
     "si_set_profiling": (c_int32, [c_void_p, c_int32]),
+    "si_set_profiling_classes": (c_int32, [c_void_p, ctypes.c_uint32]),
     "si_get_stats": (c_int32, [c_void_p, POINTER(SiStats)]),
     "si_reset_stats": (c_int32, [c_void_p]),
     "si_device_name": (c_int32, [c_void_p, c_char_p, c_int32]),
@@ -177,8 +178,11 @@ class Context:
     def synchronize(self):
         self._check(self.lib.si_synchronize(self.h))
 
-    def set_profiling(self, on):
+    def set_profiling(self, on, classes=None):
+        """classes: iterable of class names (K_NAMES) that get event pairs; None = all."""
         self._check(self.lib.si_set_profiling(self.h, 1 if on else 0))
+        mask = 0xFFFFFFFF if classes is None else sum(1 << K_NAMES.index(k) for k in classes)
+        self._check(self.lib.si_set_profiling_classes(self.h, mask))
 
     def reset_stats(self):
         self._check(self.lib.si_reset_stats(self.h))

@@ -39,7 +39,7 @@ ProfScope::ProfScope(Ctx* c_, int cls_, double flops, double bytes) : c(c_), cls
   c->stats.launches[cls] += 1;
   c->stats.flops[cls] += flops;
   c->stats.bytes[cls] += bytes;
-  if (!c->profiling || c->pending.size() >= (1u << 20)) return;
+  if (!c->profiling || !((c->prof_mask >> cls) & 1u) || c->pending.size() >= (1u << 20)) return;
   a = get_event(c);
   b = get_event(c);
   if (a && b) (void)hipEventRecord(a, c->stream);
@@ -208,6 +208,12 @@ int32_t si_synchronize(si_ctx* ctx) {
   CHECK_CTX(ctx);
   BIND(ctx);
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+int32_t si_set_profiling_classes(si_ctx* ctx, uint32_t class_mask) {
+  CHECK_CTX(ctx);
+  ctx->prof_mask = class_mask;
   return SI_OK;
 }
 

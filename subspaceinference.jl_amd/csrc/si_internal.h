@@ -53,6 +53,7 @@ struct Ctx {
 
   // profiling
   bool profiling = false;
+  uint32_t prof_mask = 0xffffffffu;  // classes that get event pairs while profiling is on
   std::vector<EventPair> pending;
   std::vector<hipEvent_t> event_pool;
   si_stats stats{};
