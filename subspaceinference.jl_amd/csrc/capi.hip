@@ -191,6 +191,7 @@ int32_t si_destroy(si_ctx* ctx) {
   free_infer(ctx);
   dev_free(ctx->d_wstage);
   dev_free(ctx->d_nvals);
+  if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return SI_OK;
@@ -443,20 +444,33 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
     int32_t rc = si_construct_gram(ctx);
     if (rc != SI_OK) return rc;
   }
-  // H1: eigen-decomposition of G on the host (K x K)
-  std::vector<double> G((size_t)K * K), lam((size_t)K);
-  SI_HIP(ctx, hipMemcpyAsync(G.data(), ctx->d_G, G.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  // H1: eigen-decomposition of G on the host (K x K); G comes down into, and V goes up from, pinned memory
+  const int Mpad = project_mpad(M);
+  const size_t g_elems = (size_t)K * K, v_elems = (size_t)K * Mpad;
+  if (ctx->h_pin_cap < g_elems + v_elems) {
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    ctx->h_pin = nullptr;
+    ctx->h_pin_cap = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), (g_elems + v_elems) * sizeof(double), hipHostMallocDefault) != hipSuccess)
+      return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: pinned staging allocation failed");
+    ctx->h_pin_cap = g_elems + v_elems;
+  }
+  double* const G = ctx->h_pin;
+  double* const V = ctx->h_pin + g_elems;
+  std::vector<double> lam((size_t)K);
+  SI_HIP(ctx, hipMemcpyAsync(G, ctx->d_G, g_elems * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // the M largest eigenpairs: fast route (factored Householder + inverse iteration, verified) or the full QL solver
   std::vector<double> wtop((size_t)M), Vtop((size_t)K * M);
   {
     const auto t0 = std::chrono::steady_clock::now();
     int erc = 0;
-    if (sym_eig_top((int)K, G.data(), (int)M, wtop.data(), Vtop.data()) != 0) {
-      erc = sym_eig((int)K, G.data(), lam.data());
+    if (sym_eig_top((int)K, G, (int)M, wtop.data(), Vtop.data()) != 0) {
+      erc = sym_eig((int)K, G, lam.data());
       for (int m = 0; m < M && erc == 0; ++m) {
         wtop[(size_t)m] = lam[(size_t)(K - 1 - m)];
-        std::copy(G.data() + (size_t)(K - 1 - m) * K, G.data() + (size_t)(K - m) * K, Vtop.data() + (size_t)m * K);
+        std::copy(G + (size_t)(K - 1 - m) * K, G + (size_t)(K - m) * K, Vtop.data() + (size_t)m * K);
       }
     }
     ctx->stats.ms[SI_K_EIG_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -464,8 +478,7 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
     if (erc != 0) return fail(ctx, SI_ERR_INVALID, "si_construct_finish: eigensolver did not converge");
   }
   // descending singular values; V_M with a deterministic sign (largest-magnitude entry positive)
-  const int Mpad = project_mpad(M);
-  std::vector<double> V((size_t)K * Mpad, 0.0);
+  std::fill(V, V + v_elems, 0.0);
   ctx->svals.assign((size_t)M, 0.0);
   for (int m = 0; m < M; ++m) {
     const double l = wtop[(size_t)m];
@@ -493,23 +506,24 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
     ctx->M_built = 0;
     if (dev_alloc(&ctx->d_P, (size_t)ctx->ldA * M) != hipSuccess)
       return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: allocation of P failed");
+    // zeroed once, for the padding rows [N, ldA): the projection writes every row < N of every column on each finish
+    SI_HIP(ctx, hipMemsetAsync(ctx->d_P, 0, (size_t)ctx->ldA * M * sizeof(double), ctx->stream));
   }
-  if (ctx->v_cap < (int64_t)V.size()) {
+  if (ctx->v_cap < (int64_t)v_elems) {
     SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     dev_free(ctx->d_V);
     ctx->v_cap = 0;
-    if (dev_alloc(&ctx->d_V, V.size()) != hipSuccess)
+    if (dev_alloc(&ctx->d_V, v_elems) != hipSuccess)
       return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: allocation of V failed");
-    ctx->v_cap = (int64_t)V.size();
+    ctx->v_cap = (int64_t)v_elems;
   }
-  SI_HIP(ctx, hipMemcpyAsync(ctx->d_V, V.data(), V.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  SI_HIP(ctx, hipMemsetAsync(ctx->d_P, 0, (size_t)ctx->ldA * M * sizeof(double), ctx->stream));
+  SI_HIP(ctx, hipMemcpyAsync(ctx->d_V, V, v_elems * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   {
     ProfScope ps(ctx, SI_K_PROJECT, 2.0 * (double)N * (double)K * (double)M, (double)N * (double)(K + M) * 8.0);
     launch_project(ctx->stream, ctx->d_A, ctx->ldA, N, K, ctx->d_V, M, Mpad, ctx->d_P, ctx->ldA, ctx->num_cu);
   }
   SI_HIP(ctx, hipGetLastError());
-  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));  // V (host vector) must outlive the async copy
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the pinned V may be rewritten by the next finish
   ctx->M_built = M;
   ctx->c_finished = true;
   if (s_out) std::copy(ctx->svals.begin(), ctx->svals.end(), s_out);

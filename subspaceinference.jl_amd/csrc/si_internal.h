@@ -52,6 +52,9 @@ struct Ctx {
   int num_cu = 256;
 
   // profiling
+  // pinned host staging for the small construct-time transfers (G down, V up): pageable copies cost tens of us each
+  double* h_pin = nullptr;
+  size_t h_pin_cap = 0;
   bool profiling = false;
   uint32_t prof_mask = 0xffffffffu;  // classes that get event pairs while profiling is on
   std::vector<EventPair> pending;
