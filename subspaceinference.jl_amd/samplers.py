@@ -8,13 +8,16 @@ vendored.  What is restated [upstream, unverifiable offline]:
     is z' ~ N(z + (σ_z²/2)·∇lp(z), σ_z² I), accepted with the Metropolis–Hastings ratio including the asymmetric
     proposal densities; `itr` samples INCLUDING the initial state.
   * HMC: `StaticTrajectory(Leapfrog(ε), 1)` -- ONE leapfrog step per sample, `DiagEuclideanMetric(M)`, ε from
-    `find_good_stepsize`, adapted for `n_adapts = round(itr/2)` iterations by dual averaging to an acceptance of 0.8.
-    AdvancedHMC's windowed mass-matrix adaptation (StanHMCAdaptor) is NOT restated: the metric stays the identity
-    (documented deviation).
+    `find_good_stepsize`, adapted for `n_adapts = round(itr/2)` iterations by `StanHMCAdaptor(MassMatrixAdaptor(metric),
+    StepSizeAdaptor(0.8, integrator))`: Nesterov dual averaging of log ε to an acceptance of 0.8 on every adaptation
+    step, plus Stan's WINDOWED diagonal mass-matrix adaptation (class StanAdaptor below: init buffer 75, terminal
+    buffer 50, doubling windows from 25; Welford variance of the draws inside a window, regularised
+    (n/(n+5))·var + 1e-3·5/(n+5), installed as M⁻¹ at the window's end together with a restart of the dual averaging
+    at the current ε).  With the reference's default `itr` the windows only open when n_adapts > 125.
   * NUTS: `NUTS{MultinomialTS, GeneralisedNoUTurn}(Leapfrog(ε))` -- multinomial trajectory sampling with the
     generalised (momentum-sum) no-U-turn criterion, biased progressive sub-tree sampling, max depth 10, divergence
     threshold ΔH > 1000 (the published algorithm of Betancourt 2017 / Stan that AdvancedHMC implements); same step-size
-    search and dual averaging as above, identity metric.
+    search and adaptor as above.
 The random stream is NumPy's PCG64 seeded by the caller (the reference uses Julia's global MersenneTwister).
 """
 import math
@@ -45,16 +48,22 @@ def mala(logdensity_grad, m, itr, sigma_z, rng):
     return zs, lps, nacc / max(1, itr - 1)
 
 
-def _leapfrog(logdensity_grad, z, r, g, eps):
+def _leapfrog(logdensity_grad, z, r, g, eps, minv=1.0):
+    """One leapfrog step of H(z, r) = -lp(z) + r' M⁻¹ r / 2 with the diagonal M⁻¹ = minv."""
     r = r + 0.5 * eps * g
-    z = z + eps * r
+    z = z + eps * (minv * r)
     lp, g = logdensity_grad(z)
     r = r + 0.5 * eps * g
     return z, r, lp, g
 
 
+def _kinetic(r, minv):
+    return 0.5 * float(np.sum(minv * r * r))
+
+
 def find_good_stepsize(logdensity_grad, z, lp, g, rng, eps=0.1, max_iter=100):
-    """Hoffman & Gelman (2014) Algorithm 4, the heuristic AdvancedHMC's `find_good_stepsize` implements."""
+    """Hoffman & Gelman (2014) Algorithm 4, the heuristic AdvancedHMC's `find_good_stepsize` implements (identity
+    metric: it runs before any adaptation)."""
     r = rng.standard_normal(z.size)
     h0 = lp - 0.5 * float(r @ r)
     _, rp, lpp, _ = _leapfrog(logdensity_grad, z, r, g, eps)
@@ -71,70 +80,131 @@ def find_good_stepsize(logdensity_grad, z, lp, g, rng, eps=0.1, max_iter=100):
     return eps
 
 
+class StanAdaptor:
+    """`StanHMCAdaptor(MassMatrixAdaptor(DiagEuclideanMetric), StepSizeAdaptor(δ, integrator))` restated from the
+    published algorithm (Stan reference manual, "Automatic Parameter Tuning"; stan/mcmc/windowed_adaptation.hpp and
+    var_adaptation.hpp, which AdvancedHMC's stan_adaptor.jl cites) [upstream, unverifiable offline].
+
+    Step size: Nesterov dual averaging (γ = 0.05, t0 = 10, κ = 0.75, μ = log 10ε) on every adaptation step, restarted at
+    the current ε whenever the metric changes, frozen to exp(x̄) after the last step.  Metric: the draws of a window feed
+    a Welford variance; at the window's end M⁻¹ <- (n/(n+5))·var + 1e-3·5/(n+5) and the estimator is reset.  Windows:
+    the first opens after `init_buffer` steps, the last closes `term_buffer` steps before the end, sizes double
+    (25, 50, 100, ...) and the last one is stretched to the end of the slow phase.  When the three phases do not fit
+    (n_adapts < 150) Stan rescales them to 15 % / 75 % / 10 % if n_adapts >= 20, otherwise there is no metric window.
+    """
+
+    def __init__(self, m, n_adapts, eps, delta=0.8, init_buffer=75, term_buffer=50, window_size=25):
+        self.m, self.n_adapts, self.delta = m, int(n_adapts), delta
+        if init_buffer + window_size + term_buffer > self.n_adapts:
+            if self.n_adapts >= 20:
+                init_buffer = int(0.15 * self.n_adapts)
+                term_buffer = int(0.1 * self.n_adapts)
+                window_size = self.n_adapts - init_buffer - term_buffer
+            else:
+                init_buffer, term_buffer, window_size = self.n_adapts + 1, 0, 1   # never inside a window
+        self.window_start = init_buffer + 1
+        self.window_end = self.n_adapts - term_buffer
+        self.window_splits = []
+        nxt = init_buffer + window_size
+        while nxt <= self.window_end:
+            if nxt + 2 * window_size > self.window_end:
+                nxt = self.window_end
+            self.window_splits.append(nxt)
+            window_size *= 2
+            nxt += window_size
+        self.i = 0
+        self.minv = np.ones(m)
+        self.eps = eps
+        self._restart_da(eps)
+        self._wn, self._wmean, self._wm2 = 0, np.zeros(m), np.zeros(m)
+
+    def _restart_da(self, eps):
+        self.mu, self.hbar, self.log_eps_bar, self.t = math.log(10.0 * eps), 0.0, 0.0, 0
+
+    def adapt(self, z, accept):
+        """After adaptation step i (1-based): returns True when the metric changed."""
+        if self.i >= self.n_adapts:
+            return False
+        self.i += 1
+        gamma, t0, kappa = 0.05, 10.0, 0.75
+        self.t += 1
+        a = min(1.0, accept)
+        self.hbar = (1.0 - 1.0 / (self.t + t0)) * self.hbar + (self.delta - a) / (self.t + t0)
+        log_eps = self.mu - math.sqrt(self.t) / gamma * self.hbar
+        eta = self.t ** (-kappa)
+        self.log_eps_bar = eta * log_eps + (1.0 - eta) * self.log_eps_bar
+        self.eps = math.exp(log_eps)
+        changed = False
+        if self.window_start <= self.i <= self.window_end:
+            self._wn += 1
+            dlt = z - self._wmean
+            self._wmean = self._wmean + dlt / self._wn
+            self._wm2 = self._wm2 + dlt * (z - self._wmean)
+            if self.i in self.window_splits:
+                n = self._wn
+                if n >= 2:
+                    var = self._wm2 / (n - 1)
+                    self.minv = (n / (n + 5.0)) * var + 1e-3 * (5.0 / (n + 5.0))
+                    changed = True
+                self._wn, self._wmean, self._wm2 = 0, np.zeros(self.m), np.zeros(self.m)
+                self._restart_da(self.eps)
+        if self.i == self.n_adapts:
+            if self.t > 0:
+                self.eps = math.exp(self.log_eps_bar)
+        return changed
+
+
 def hmc(logdensity_grad, m, itr, sigma_z, rng, delta=0.8):
     z = sigma_z * rng.standard_normal(m)  # initial_theta = rand(MvNormal(zeros(M), sigma_z)), space_inference.jl:140
     lp, g = logdensity_grad(z)
-    eps = find_good_stepsize(logdensity_grad, z, lp, g, rng)
-    n_adapts = int(round(itr / 2))
-    # dual averaging (Nesterov), Stan's constants
-    mu, gamma, t0, kappa = math.log(10.0 * eps), 0.05, 10.0, 0.75
-    hbar, log_eps_bar = 0.0, 0.0
+    ad = StanAdaptor(m, int(round(itr / 2)), find_good_stepsize(logdensity_grad, z, lp, g, rng), delta)
     zs = np.empty((m, itr), order="F")
     lps = np.empty(itr)
     acc = np.empty(itr)
     for t in range(itr):
-        r = rng.standard_normal(m)
-        h0 = lp - 0.5 * float(r @ r)
-        zp, rp, lpp, gp = _leapfrog(logdensity_grad, z, r, g, eps)
-        h1 = lpp - 0.5 * float(rp @ rp)
+        minv, eps = ad.minv, ad.eps
+        r = rng.standard_normal(m) / np.sqrt(minv)          # r ~ N(0, M)
+        h0 = lp - _kinetic(r, minv)
+        zp, rp, lpp, gp = _leapfrog(logdensity_grad, z, r, g, eps, minv)
+        h1 = lpp - _kinetic(rp, minv)
         a = min(1.0, math.exp(h1 - h0)) if np.isfinite(h1) else 0.0
         if rng.random() < a:
             z, lp, g = zp, lpp, gp
         zs[:, t], lps[t], acc[t] = z, lp, a
-        if t < n_adapts:
-            it = t + 1
-            hbar = (1.0 - 1.0 / (it + t0)) * hbar + (delta - a) / (it + t0)
-            log_eps = mu - math.sqrt(it) / gamma * hbar
-            eta = it ** (-kappa)
-            log_eps_bar = eta * log_eps + (1.0 - eta) * log_eps_bar
-            eps = math.exp(log_eps)
-            if it == n_adapts:
-                eps = math.exp(log_eps_bar)
+        ad.adapt(z, a)
     return zs, lps, float(acc.mean())
 
 
-def _uturn(rho, r_minus, r_plus):
-    return float(rho @ r_minus) <= 0.0 or float(rho @ r_plus) <= 0.0
+def _uturn(rho, v_minus, v_plus):
+    """Generalised no-U-turn criterion (Betancourt 2017): rho = sum of momenta, v = M⁻¹ r at the two ends."""
+    return float(rho @ v_minus) <= 0.0 or float(rho @ v_plus) <= 0.0
 
 
 def nuts(logdensity_grad, m, itr, sigma_z, rng, delta=0.8, max_depth=10, max_dh=1000.0):
     z = sigma_z * rng.standard_normal(m)
     lp, g = logdensity_grad(z)
-    eps = find_good_stepsize(logdensity_grad, z, lp, g, rng)
-    n_adapts = int(round(itr / 2))
-    mu, gamma, t0, kappa = math.log(10.0 * eps), 0.05, 10.0, 0.75
-    hbar, log_eps_bar = 0.0, 0.0
+    ad = StanAdaptor(m, int(round(itr / 2)), find_good_stepsize(logdensity_grad, z, lp, g, rng), delta)
     zs = np.empty((m, itr), order="F")
     lps = np.empty(itr)
     acc = np.empty(itr)
 
-    def build(zc, rc, gc, v, depth, h0):
+    def build(zc, rc, gc, v, depth, h0, eps, minv):
         """2**depth leapfrog steps from (zc, rc) in direction v.  Returns the sub-tree summary."""
         if depth == 0:
-            z1, r1, lp1, g1 = _leapfrog(logdensity_grad, zc, rc, gc, v * eps)
-            h1 = lp1 - 0.5 * float(r1 @ r1)
+            z1, r1, lp1, g1 = _leapfrog(logdensity_grad, zc, rc, gc, v * eps, minv)
+            h1 = lp1 - _kinetic(r1, minv)
             if not np.isfinite(h1):
                 h1 = -np.inf
             dh = h1 - h0
             return dict(zm=z1, rm=r1, gm=g1, zp=z1, rp=r1, gp=g1, zprop=z1, lpprop=lp1, gprop=g1, logw=dh, rho=r1.copy(),
                         alpha=min(1.0, math.exp(dh)) if dh < 0 else 1.0, n=1, stop=(-dh) > max_dh)
-        a = build(zc, rc, gc, v, depth - 1, h0)
+        a = build(zc, rc, gc, v, depth - 1, h0, eps, minv)
         if a["stop"]:
             return a
         if v > 0:
-            b = build(a["zp"], a["rp"], a["gp"], v, depth - 1, h0)
+            b = build(a["zp"], a["rp"], a["gp"], v, depth - 1, h0, eps, minv)
         else:
-            b = build(a["zm"], a["rm"], a["gm"], v, depth - 1, h0)
+            b = build(a["zm"], a["rm"], a["gm"], v, depth - 1, h0, eps, minv)
         logw = np.logaddexp(a["logw"], b["logw"])
         out = dict(a)
         if v > 0:
@@ -147,21 +217,22 @@ def nuts(logdensity_grad, m, itr, sigma_z, rng, delta=0.8, max_depth=10, max_dh=
         out["logw"] = logw
         out["alpha"] = a["alpha"] + b["alpha"]
         out["n"] = a["n"] + b["n"]
-        out["stop"] = b["stop"] or _uturn(out["rho"], out["rm"], out["rp"])
+        out["stop"] = b["stop"] or _uturn(out["rho"], minv * out["rm"], minv * out["rp"])
         return out
 
     for t in range(itr):
-        r0 = rng.standard_normal(m)
-        h0 = lp - 0.5 * float(r0 @ r0)
+        minv, eps = ad.minv, ad.eps
+        r0 = rng.standard_normal(m) / np.sqrt(minv)
+        h0 = lp - _kinetic(r0, minv)
         tree = dict(zm=z, rm=r0, gm=g, zp=z, rp=r0, gp=g, rho=r0.copy(), logw=0.0)
         zn, lpn, gn = z, lp, g
         alpha_sum, n_alpha = 0.0, 0
         for depth in range(max_depth):
             v = 1.0 if rng.random() < 0.5 else -1.0
             if v > 0:
-                sub = build(tree["zp"], tree["rp"], tree["gp"], v, depth, h0)
+                sub = build(tree["zp"], tree["rp"], tree["gp"], v, depth, h0, eps, minv)
             else:
-                sub = build(tree["zm"], tree["rm"], tree["gm"], v, depth, h0)
+                sub = build(tree["zm"], tree["rm"], tree["gm"], v, depth, h0, eps, minv)
             alpha_sum += sub["alpha"]
             n_alpha += sub["n"]
             if sub["stop"]:
@@ -174,18 +245,10 @@ def nuts(logdensity_grad, m, itr, sigma_z, rng, delta=0.8, max_depth=10, max_dh=
                 tree.update(zm=sub["zm"], rm=sub["rm"], gm=sub["gm"])
             tree["rho"] = tree["rho"] + sub["rho"]
             tree["logw"] = np.logaddexp(tree["logw"], sub["logw"])
-            if _uturn(tree["rho"], tree["rm"], tree["rp"]):
+            if _uturn(tree["rho"], minv * tree["rm"], minv * tree["rp"]):
                 break
         z, lp, g = zn, lpn, gn
         a = alpha_sum / max(1, n_alpha)
         zs[:, t], lps[t], acc[t] = z, lp, a
-        if t < n_adapts:
-            it = t + 1
-            hbar = (1.0 - 1.0 / (it + t0)) * hbar + (delta - a) / (it + t0)
-            log_eps = mu - math.sqrt(it) / gamma * hbar
-            eta = it ** (-kappa)
-            log_eps_bar = eta * log_eps + (1.0 - eta) * log_eps_bar
-            eps = math.exp(log_eps)
-            if it == n_adapts:
-                eps = math.exp(log_eps_bar)
+        ad.adapt(z, a)
     return zs, lps, float(acc.mean())
