@@ -364,20 +364,14 @@ static void launch_gemm(hipStream_t st, const double* A, int64_t lda, const doub
                    (BLAY == 0 ? Ncols % 2 == 0 : Kdim % 2 == 0) && ksplit % 2 == 0;
   if (vec) {
     auto kern = gemm_f64_kernel<BM, BN, WM, WN, 4, ALAY, BLAY, true, EPI>;
-    static bool set = false;
-    if (!set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      set = true;
-    }
+    static LdsOptIn optin;
+    optin.ensure(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)nsplit), dim3(NT), lds, st, A, lda, Bm, ldb, C, ldc, Mrows,
                        Ncols, Kdim, ksplit, aux, act, nMt, nNt);
   } else {
     auto kern = gemm_f64_kernel<BM, BN, WM, WN, 4, ALAY, BLAY, false, EPI>;
-    static bool set = false;
-    if (!set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      set = true;
-    }
+    static LdsOptIn optin;
+    optin.ensure(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)nsplit), dim3(NT), lds, st, A, lda, Bm, ldb, C, ldc, Mrows,
                        Ncols, Kdim, ksplit, aux, act, nMt, nNt);
   }

@@ -420,11 +420,8 @@ static void launch_dense_inst(hipStream_t st, const double* W, const double* bia
   const int64_t groups = (nNt + 7) / 8;  // batch panels per XCD lane
   const int64_t grid = groups * nMt * 8;
   auto kern = dense_f64_kernel<BM, BN, WM, WN, MINW, VEC, KEDGE, FUSE>;
-  static size_t attr_lds = 0;
-  if (attr_lds < lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_lds = lds;
-  }
+  static LdsOptIn optin;
+  optin.ensure(reinterpret_cast<const void*>(kern), lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)fa.cb.n), dim3(NT), lds, st, W, bias, Hin, Hout, (int)out,
                      (int)in, B, (int)act, nMt, nNt, fa.Wlast, fa.out_last, fa.part, fa.cb);
 }

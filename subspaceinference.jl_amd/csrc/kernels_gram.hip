@@ -195,12 +195,8 @@ template <int NT>
 static void launch_gram_small(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, int col0, double* Gpart,
                               double* G, int nblocks, Ctx* prof, double flops, double bytes) {
   constexpr size_t lds = (size_t)NT * 16 * GRP * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_small_kernel<NT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static LdsOptIn optin;
+  optin.ensure(reinterpret_cast<const void*>(gram_small_kernel<NT>), lds);
   {
     ProfScope ps(prof, SI_K_GRAM, flops, bytes);
     hipLaunchKernelGGL(gram_small_kernel<NT>, dim3(nblocks), dim3(512), lds, st, A, ldA, N, K, col0, Gpart);
@@ -313,12 +309,8 @@ template <int NTJ>
 static void launch_gram_off(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, int ci0, int cj0, double* Gpart,
                             double* G, int nblocks, Ctx* prof, double flops, double bytes) {
   constexpr size_t lds = (size_t)(8 + NTJ) * 16 * GRP2 * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_off_kernel<NTJ>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static LdsOptIn optin;
+  optin.ensure(reinterpret_cast<const void*>(gram_off_kernel<NTJ>), lds);
   {
     ProfScope ps(prof, SI_K_GRAM, flops, bytes);
     hipLaunchKernelGGL(gram_off_kernel<NTJ>, dim3(nblocks), dim3(512), lds, st, A, ldA, N, K, ci0, cj0, Gpart);

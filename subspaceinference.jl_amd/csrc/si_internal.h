@@ -146,6 +146,19 @@ int32_t fail(Ctx* c, int32_t code, const std::string& msg);
       return si::fail((c), SI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// Dynamic-LDS opt-in of a kernel (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-DEVICE property of the loaded code
+// object: a process may hold contexts on several GPUs, so the "already set" note is kept per device.
+struct LdsOptIn {
+  size_t done[64] = {0};
+  void ensure(const void* kern, size_t lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev >= 0 && done[dev] >= lds) return;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (dev >= 0) done[dev] = lds;
+  }
+};
+
 // profiling scope: records an event pair around kernel launches of one class
 struct ProfScope {
   Ctx* c;
