@@ -852,3 +852,60 @@ def test_nn_example_flow(si, gpu_ctx):
         ref = so.forward(table, chn[t], inp)
         assert np.allclose(traj[:, :, t], ref, rtol=1e-9, atol=1e-10)
     assert traj[0].std(axis=1).max() > 0.0                                  # a predictive band, not a single curve
+
+
+def test_random_shape_sweep_forward_density_gradient(gpu_ctx):
+    """Seeded sweep over random Dense chains (1-4 layers, widths 1..210, every activation, heads of width 1..9 so both
+    the fused narrow-head path and the generic one run, ragged and odd sizes, B from 1 to ~700): forward, log-density
+    (several chains per call) and the reverse-sweep gradient against the oracle."""
+    rng = np.random.default_rng(20240229)
+    for case in range(28):
+        nl = int(rng.integers(1, 5))
+        dims = [int(rng.integers(1, 40))] + [int(rng.choice([1, 2, 3, 7, 16, 33, 64, 97, 130, 210])) for _ in range(nl - 1)] \
+            + [int(rng.integers(1, 10))]
+        acts = [int(rng.integers(0, 4)) for _ in range(nl)]
+        b = int(rng.choice([1, 2, 17, 128, 129, 300, 701]))
+        m = int(rng.integers(1, 9))
+        table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=1000 + case)
+        gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=0.8)
+        zs = np.asfortranarray(0.5 * rng.standard_normal((m, 3)))
+        tag = "case %d dims %s acts %s B %d M %d" % (case, dims, acts, b, m)
+        yref = so.forward(table, so.reconstruct(w_swa, p, zs[:, 0]), x)
+        assert np.allclose(gpu_ctx.forward(zs[:, 0]), yref, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(yref).max())), tag
+        lp_ref = np.array([so.logdensity(table, w_swa, p, x, y, 0.8, zs[:, j]) for j in range(3)])
+        assert np.allclose(gpu_ctx.logdensity(zs), lp_ref, rtol=1e-10), tag
+        lp, g = gpu_ctx.logdensity_grad(zs[:, 1])
+        lpr, gr, _ = so.logdensity_grad(table, w_swa, p, x, y, 0.8, zs[:, 1])
+        assert np.isclose(lp, lpr, rtol=1e-10), tag
+        assert np.allclose(g, gr, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(gr).max())), tag
+
+
+def test_random_shape_sweep_training_gradient(si, gpu_ctx):
+    """si_train_grad (forward + reverse sweep of the mse cost, with the fused narrow-head path for heads of width <= 4 and
+    the generic one above) against the host stand-in of Zygote's gradient on random Dense chains and batches."""
+    from subspaceinference_jl_amd import flux
+    rng = np.random.default_rng(77)
+    act_names = [flux.identity, flux.relu, flux.tanh, flux.sigmoid]
+    for case in range(14):
+        nl = int(rng.integers(1, 5))
+        dims = [int(rng.integers(1, 30))] + [int(rng.choice([1, 2, 5, 16, 33, 64, 97, 130])) for _ in range(nl - 1)] \
+            + [int(rng.integers(1, 8))]
+        acts = [act_names[int(rng.integers(0, 4))] for _ in range(nl)]
+        btot = int(rng.choice([5, 64, 129, 400]))
+        nb = int(rng.integers(1, btot + 1))
+        wr = np.random.default_rng(500 + case)
+        model = flux.Chain(*[flux.Dense(dims[i], dims[i + 1], acts[i], rng=wr) for i in range(nl)])
+        for l in model.layers:                                 # non-zero biases
+            l.b[...] = (0.1 * wr.standard_normal(l.b.shape)).astype(np.float32)
+        x, y = rng.standard_normal((dims[0], btot)), rng.standard_normal((dims[-1], btot))
+        table, n = flux.layer_table(model)
+        gpu_ctx.train_setup(table, n, flux.extract_params(flux.params(model)), x, y, btot, 0, 0.1)
+        ids = rng.permutation(btot)[:nb]
+        sse = gpu_ctx.train_grad(ids, nb)
+        g = gpu_ctx.train_grad_get()
+        loss, gs = flux.mse.value_and_grad(model, x[:, ids], y[:, ids])
+        gref = np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1, order="F") for a in gs])
+        tag = "case %d dims %s nb %d/%d" % (case, dims, nb, btot)
+        assert np.isclose(sse / (dims[-1] * nb), loss, rtol=1e-10), tag
+        assert np.allclose(g, gref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(gref).max())), tag
+        gpu_ctx.train_apply()
