@@ -909,3 +909,39 @@ def test_random_shape_sweep_training_gradient(si, gpu_ctx):
         assert np.isclose(sse / (dims[-1] * nb), loss, rtol=1e-10), tag
         assert np.allclose(g, gref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(gref).max())), tag
         gpu_ctx.train_apply()
+
+
+def test_random_shape_sweep_construction(gpu_ctx):
+    """Seeded sweep of the construction path: N from 1 to ~30 000 (odd, below / across the 64-row slab and tile sizes),
+    K from 1 to 300 (one, two and three 128-column Gram panels), fp32 / fp64 snapshots, M up to 70 (VALU and MFMA
+    projection, fast and full eigen route): W_swa bit-exact, Gram, singular values and P against the oracle."""
+    rng = np.random.default_rng(4242)
+    for case in range(16):
+        n = int(rng.choice([1, 2, 63, 65, 257, 1000, 4097, 12345, 30011]))
+        k = int(rng.choice([1, 2, 15, 16, 17, 100, 128, 129, 200, 257, 300]))
+        k = min(k, 60) if n > 20000 else k
+        dtype = np.float32 if rng.random() < 0.6 else np.float64
+        snaps = _snap_stream(n, k, seed=10 * case + 3, dtype=dtype)
+        ns = [float(1 + i // int(rng.integers(1, 5))) for i in range(k)]
+        w_ref, a_ref = so.construct_stream(snaps, ns)
+        sv = np.linalg.svd(a_ref, compute_uv=False)
+        rank = int(np.sum(sv > 1e-5 * sv[0])) if sv[0] > 0 else 0      # well inside what the Gram route resolves
+        tag = "case %d N %d K %d %s" % (case, n, k, dtype.__name__)
+        gpu_ctx.construct_begin(n, k)
+        for w, nn in zip(snaps, ns):
+            gpu_ctx.construct_push(w, nn)
+        gpu_ctx.construct_gram()
+        g = gpu_ctx.construct_gram_get()
+        g_ref = a_ref.T @ a_ref
+        assert np.array_equal(g, g.T) and np.allclose(g, g_ref, rtol=1e-11, atol=1e-11 * max(np.abs(g_ref).max(), 1e-300)), tag
+        if rank == 0:
+            continue
+        m = int(min(rank, rng.choice([1, 3, 20, 33, 70])))
+        w_swa, p, s, kk = gpu_ctx.construct_finish(m)
+        p_ref, s_ref = so.projection_from_A(a_ref, m)
+        assert kk == k and np.array_equal(w_swa, w_ref), tag
+        assert np.allclose(s, s_ref[:m], rtol=1e-7), tag
+        assert np.allclose(p.T @ p, np.diag(s ** 2), atol=1e-8 * s[0] ** 2), tag
+        gaps = np.abs(np.diff(np.r_[s_ref[:m], sv[m] if m < sv.size else 0.0])) / s_ref[0]
+        if gaps.min() > 1e-6:                                          # individual vectors are defined only away from ties
+            assert np.allclose(_align_signs(p, p_ref), p_ref, rtol=1e-5, atol=1e-7 * np.abs(p_ref).max()), tag
