@@ -58,11 +58,24 @@ def glorot_flat(seed):
 def cpu_baseline(table, w_swa, p, x, y, z0, budget_s):
     """The NumPy/OpenBLAS restatement (oracle) timed on the host: bounded sample of the same workload."""
     from oracle import subspace_oracle as so
+    blas = "unknown"
     try:
         from threadpoolctl import threadpool_info
-        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [os.cpu_count() or 1])
+        info = threadpool_info()
+        cores = max([i.get("num_threads", 1) for i in info] or [os.cpu_count() or 1])
+        blas = ", ".join(sorted({"%s %s" % (i.get("internal_api", "?"), i.get("version", "?")) for i in info
+                                 if i.get("user_api") == "blas"})) or blas
     except Exception:
         cores = os.cpu_count() or 1
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     t0 = time.perf_counter()
     lp0 = so.logdensity(table, w_swa, p, x, y, SIGMA_M, z0)
     t1 = time.perf_counter() - t0
@@ -72,7 +85,8 @@ def cpu_baseline(table, w_swa, p, x, y, z0, budget_s):
     for _ in range(n):
         so.logdensity(table, w_swa, p, x, y, SIGMA_M, z0 + SIGMA_Z * rng.standard_normal(M))
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
+    return {"value": n / dt, "unit": "samples/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model,
+            "host_cpus": os.cpu_count(), "blas": blas,
             "sample": "%d density evaluations (W_swa+P*z, fp64 forward over X 128x%d, SSE) of the cfg2 workload with "
                       "NumPy+OpenBLAS (oracle/subspace_oracle.py), %.1f s" % (n, B, dt)}, lp0
 
