@@ -85,7 +85,16 @@ def cpu_baseline(table, w_swa, p, x, y, z0, budget_s):
     for _ in range(n):
         so.logdensity(table, w_swa, p, x, y, SIGMA_M, z0 + SIGMA_Z * rng.standard_normal(M))
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "samples/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model,
+    single = None
+    try:  # the same evaluation on ONE host thread (BASELINE.md asks for both figures); one evaluation, ~5-10 s
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            t0 = time.perf_counter()
+            so.logdensity(table, w_swa, p, x, y, SIGMA_M, z0)
+            single = 1.0 / (time.perf_counter() - t0)
+    except Exception:
+        pass
+    return {"value": n / dt, "unit": "samples/s", "cores": int(cores), "kind": "port", "single_core_value": single, "cpu_model": cpu_model,
             "host_cpus": os.cpu_count(), "blas": blas,
             "sample": "%d density evaluations (W_swa+P*z, fp64 forward over X 128x%d, SSE) of the cfg2 workload with "
                       "NumPy+OpenBLAS (oracle/subspace_oracle.py), %.1f s" % (n, B, dt)}, lp0
