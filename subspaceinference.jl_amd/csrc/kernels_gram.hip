@@ -12,16 +12,20 @@ namespace si {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int GR = 64;   // slab rows
-constexpr int GRP = 66;  // padded row stride in LDS: operand reads (lane l -> column l&15, row 4s + (l>>4)) touch dword
-                         // banks 4*col + 2*row (mod 64): 32 distinct bank pairs per 32-lane half, conflict-free
+constexpr int GR = 32;   // slab rows
+constexpr int GRP = 34;  // padded row stride in LDS (68 dwords per column): operand reads (lane l -> column l&15, row
+                         // 4s + (l>>4)) touch dword banks 4*col + 2*row (mod 64): 32 distinct bank pairs per 32-lane
+                         // half, conflict-free
 
 // ------------------------------------------------------------------------------------------------
-// K2, K <= 128 (the usual case: K = snapshots collected, 100 at cfg2).  A 64-row slab of ALL columns fits in LDS
-// (NT*16 columns x 66 doubles), so A is read exactly once and the NT(NT+1)/2 upper-triangular 16x16 tiles are dealt
-// round-robin to the 8 waves of a 512-thread workgroup: every wave runs a STATIC list of at most 5 MFMAs per k step
-// (compile-time tile pairs => accumulators stay in fixed registers).  Two workgroups per CU (4 waves per SIMD); the
-// next slab is prefetched into registers under the MFMAs.  Partial tiles go to Gpart[block][pair][256].
+// K2, K <= 128 (the usual case: K = snapshots collected, 100 at cfg2).  A 32-row slab of ALL columns fits in LDS twice
+// (2 x NT*16 columns x 34 doubles: 61 KB at K = 100), so A is read exactly once and the NT(NT+1)/2 upper-triangular
+// 16x16 tiles are dealt round-robin to the 8 waves of a 512-thread workgroup: every wave runs a STATIC list of at most
+// 5 MFMAs per k step (compile-time tile pairs => accumulators stay in fixed registers).  Two workgroups per CU (4 waves
+// per SIMD).  Pipeline per slab, ONE barrier: [k steps 0-3] [ds_write slab s+1 -> other buffer; global loads of slab
+// s+2 -> registers] [k steps 4-7] barrier -- the LDS stores and the HBM loads issue under the wave's own MFMAs.  (A
+// single-buffered 64-row slab needed two barriers with an exposed store phase between them: the matrix pipe sat at
+// 68 %.)  Partial tiles go to Gpart[block][pair][256].
 // ------------------------------------------------------------------------------------------------
 constexpr int GS_WAVES = 8;
 
@@ -63,20 +67,26 @@ struct GramWave {
       mfma_slots<SL + 1>(f, acc);
     }
   }
-  template <int T>
-  static __device__ __forceinline__ void load_frags(const double* base, int s, double (&f)[NT]) {
+  // fb[s] = element index of (column c, row 4s + q) in buffer 0; OFF = element offset of the buffer in use (compile
+  // time, so every read is base register + immediate).  The eight indices are OPAQUE to the compiler (see gram_small_body): reads
+  // of neighbouring k steps are 32 B apart and would otherwise be fused into ds_read2_b64, which is banked mod 32 in
+  // 16-lane groups -- 2-way conflicts on this column-strided image and a quarter of ds_read_b64's bandwidth
+  // (SQ_LDS_BANK_CONFLICT was 46 % of SQ_LDS_IDX_ACTIVE).
+  template <int T, int OFF>
+  static __device__ __forceinline__ void load_frags(const double* sA, int b, double (&f)[NT]) {
     if constexpr (T < NT) {
       constexpr unsigned M = mask();
-      if constexpr ((M >> T) & 1u) f[T] = base[T * 16 * GRP + 4 * s];
-      load_frags<T + 1>(base, s, f);
+      if constexpr ((M >> T) & 1u) f[T] = sA[b + (OFF + T * 16 * GRP)];
+      load_frags<T + 1, OFF>(sA, b, f);
     }
   }
-  // one 64-row slab: 16 k steps; f[t] = operand of column tile t (same register image serves as A and as B operand)
-  static __device__ __forceinline__ void steps(const double* base, d4 (&acc)[5]) {
-#pragma unroll 2
-    for (int s = 0; s < GR / 4; ++s) {
+  // k steps [S0, S1) of one slab; f[t] = operand of column tile t (same register image serves as A and as B operand)
+  template <int S0, int S1, int OFF>
+  static __device__ __forceinline__ void steps(const double* sA, const int (&fb)[GR / 4], d4 (&acc)[5]) {
+#pragma unroll
+    for (int s = S0; s < S1; ++s) {
       double f[NT];
-      load_frags<0>(base, s, f);
+      load_frags<0, OFF>(sA, fb[s], f);
       mfma_slots<0>(f, acc);
     }
   }
@@ -100,44 +110,70 @@ template <int NT, int W>
 __device__ __forceinline__ void gram_small_body(const double* __restrict__ A, int64_t ldA, int64_t N, int K,
                                                 int col0, double* __restrict__ Gpart, double* sA) {
   constexpr int NC = NT * 16;
-  constexpr int NLD = (NC + 15) / 16;  // staging passes: 512 threads cover 16 columns x 64 rows with 16 B per lane
+  constexpr int NLD = (NC + 31) / 32;  // staging passes: 512 threads cover 32 columns x 32 rows with 16 B per lane
+  constexpr int BUF = NC * GRP;        // doubles per LDS buffer
   const int tid = threadIdx.x, lane = tid & 63;
   const int q = lane >> 4, c = lane & 15;
-  const int srow = (lane & 31) * 2;
-  const int scol0 = W * 2 + (lane >> 5);
+  const int srow = (lane & 15) * 2;            // 16 lanes x 2 rows = one 32-row column
+  const int scol0 = W * 4 + (lane >> 4);       // 4 columns per wave per pass
   const double* Arow = A + srow;
   double2 rg[NLD];
   auto load_slab = [&](int64_t slab) {
     const double* base = Arow + slab * GR;
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
-      const int g = col0 + scol0 + p * 16;
+      const int g = col0 + scol0 + p * 32;
       rg[p] = *reinterpret_cast<const double2*>(base + (int64_t)(g < K ? g : K - 1) * ldA);
     }
   };
-  auto store_slab = [&]() {
+  auto store_slab = [&](double* dst) {
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
-      const int lc = scol0 + p * 16;
-      if (lc < NC) *reinterpret_cast<double2*>(sA + lc * GRP + srow) = col0 + lc < K ? rg[p] : make_double2(0.0, 0.0);
+      const int lc = scol0 + p * 32;
+      if (lc < NC) *reinterpret_cast<double2*>(dst + lc * GRP + srow) = col0 + lc < K ? rg[p] : make_double2(0.0, 0.0);
     }
   };
   d4 acc[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
-  const double* fbase = sA + c * GRP + q;
+  int fb[GR / 4];
+#pragma unroll
+  for (int s = 0; s < GR / 4; ++s) {
+    fb[s] = c * GRP + q + 4 * s;
+    asm volatile("" : "+v"(fb[s]));  // keep the eight indices unrelated for the load/store optimiser (no ds_read2_b64)
+  }
   const int64_t nslab = (N + GR - 1) / GR;
+  const int64_t stride = gridDim.x;
   int64_t slab = blockIdx.x;
-  if (slab < nslab) load_slab(slab);
-  for (; slab < nslab; slab += gridDim.x) {
-    store_slab();
-    __syncthreads();
-    const int64_t next = slab + gridDim.x;
-    if (next < nslab) load_slab(next);
+  if (slab >= nslab) {  // (the launcher never starts more blocks than slabs; keep the partial defined anyway)
+    GramWave<NT, W>::store(Gpart + (int64_t)blockIdx.x * (NT * (NT + 1) / 2) * 256, acc, q, c);
+    return;
+  }
+  load_slab(slab);
+  store_slab(sA);
+  if (slab + stride < nslab) load_slab(slab + stride);
+  __syncthreads();
+  // one slab from buffer BUFI; the other buffer receives slab s+1 in the middle of it
+  auto one_slab = [&](auto BUFI) {
+    constexpr int bi = decltype(BUFI)::value;
     __builtin_amdgcn_s_setprio(1);
-    GramWave<NT, W>::steps(fbase, acc);
+    GramWave<NT, W>::template steps<0, GR / 8, bi * BUF>(sA, fb, acc);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (slab + stride < nslab) {
+      store_slab(sA + (bi ^ 1) * BUF);                          // free since the barrier of the last iteration
+      if (slab + 2 * stride < nslab) load_slab(slab + 2 * stride);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    GramWave<NT, W>::template steps<GR / 8, GR / 4, bi * BUF>(sA, fb, acc);
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();
+    slab += stride;
+  };
+  while (slab < nslab) {
+    one_slab(std::integral_constant<int, 0>{});
+    if (slab < nslab) one_slab(std::integral_constant<int, 1>{});
   }
   GramWave<NT, W>::store(Gpart + (int64_t)blockIdx.x * (NT * (NT + 1) / 2) * 256, acc, q, c);
 }
@@ -148,7 +184,7 @@ template <int NT>
 #endif
 __global__ __launch_bounds__(512, GS_MINW) void gram_small_kernel(const double* __restrict__ A, int64_t ldA, int64_t N,
                                                                   int K, int col0, double* __restrict__ Gpart) {
-  extern __shared__ double sA[];  // [NT*16][GRP]
+  extern __shared__ double sA[];  // [2][NT*16][GRP]
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
     case 0: gram_small_body<NT, 0>(A, ldA, N, K, col0, Gpart, sA); break;
     case 1: gram_small_body<NT, 1>(A, ldA, N, K, col0, Gpart, sA); break;
@@ -161,26 +197,31 @@ __global__ __launch_bounds__(512, GS_MINW) void gram_small_kernel(const double* 
   }
 }
 
-// sums the per-block partial tiles in block order (bit-reproducible), writes both triangles of G
-__global__ __launch_bounds__(256) void gram_small_reduce_kernel(const double* __restrict__ Gpart, int nblocks, int nt,
-                                                                int K, int col0, double* __restrict__ G) {
+// sums the per-block partial tiles in a fixed order (bit-reproducible), writes both triangles of G.  1024 threads:
+// element e of the tile x 4 lanes; lane j adds partials j, j+4, ... in order, the four lane sums are added in a fixed tree.
+__global__ __launch_bounds__(1024) void gram_small_reduce_kernel(const double* __restrict__ Gpart, int nblocks, int nt,
+                                                                 int K, int col0, double* __restrict__ G) {
+  __shared__ double red[4][256];
   const int p = blockIdx.x;  // tile pair
   const int a = tri_a(p, nt), b = tri_b(p, nt);
-  const int e = threadIdx.x, i = e & 15, j = e >> 4;
+  const int e = threadIdx.x & 255, ln = threadIdx.x >> 8, i = e & 15, j = e >> 4;
   const int gi = col0 + a * 16 + i, gj = col0 + b * 16 + j;
   const int64_t stride = (int64_t)(nt * (nt + 1) / 2) * 256;
   const double* src = Gpart + (int64_t)p * 256 + e;
   double s = 0.0;
-  int sp = 0;
-  for (; sp + 8 <= nblocks; sp += 8) {
+  int sp = ln;
+  for (; sp + 28 < nblocks; sp += 32) {
     double v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(sp + u) * stride];
+    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(sp + 4 * u) * stride];
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += v[u];
   }
-  for (; sp < nblocks; ++sp) s += src[(int64_t)sp * stride];
-  if (gi < K && gj < K) {
+  for (; sp < nblocks; sp += 4) s += src[(int64_t)sp * stride];
+  red[ln][e] = s;
+  __syncthreads();
+  if (ln == 0 && gi < K && gj < K) {
+    s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     if (a != b) {
       G[gi + (int64_t)K * gj] = s;
       G[gj + (int64_t)K * gi] = s;
@@ -194,7 +235,7 @@ __global__ __launch_bounds__(256) void gram_small_reduce_kernel(const double* __
 template <int NT>
 static void launch_gram_small(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, int col0, double* Gpart,
                               double* G, int nblocks, Ctx* prof, double flops, double bytes) {
-  constexpr size_t lds = (size_t)NT * 16 * GRP * sizeof(double);
+  constexpr size_t lds = (size_t)2 * NT * 16 * GRP * sizeof(double);
   static LdsOptIn optin;
   optin.ensure(reinterpret_cast<const void*>(gram_small_kernel<NT>), lds);
   {
@@ -203,7 +244,7 @@ static void launch_gram_small(hipStream_t st, const double* A, int64_t ldA, int6
   }
   {
     ProfScope ps(prof, SI_K_GRAM_RED, 0.0, (double)nblocks * NT * (NT + 1) / 2 * 256 * 8.0);
-    hipLaunchKernelGGL(gram_small_reduce_kernel, dim3(NT * (NT + 1) / 2), dim3(256), 0, st, Gpart, nblocks, NT, K, col0, G);
+    hipLaunchKernelGGL(gram_small_reduce_kernel, dim3(NT * (NT + 1) / 2), dim3(1024), 0, st, Gpart, nblocks, NT, K, col0, G);
   }
 }
 
@@ -352,9 +393,9 @@ static void gram_off_dispatch(hipStream_t st, const double* A, int64_t ldA, int6
 size_t launch_gram(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, double* Gpart,
                    double* G, int num_cu, Ctx* prof) {
   // workspace: the largest single launch (an off-diagonal pair of full panels: 64 tiles per block)
-  const int64_t nslab64 = (N + GR - 1) / GR, nslab32 = (N + GR2 - 1) / GR2;
-  int64_t nb_diag = std::min<int64_t>((int64_t)num_cu * 2, nslab64);
-  int64_t nb_off = std::min<int64_t>((int64_t)num_cu * 2, nslab32);
+  const int64_t nslab_d = (N + GR - 1) / GR, nslab_o = (N + GR2 - 1) / GR2;
+  int64_t nb_diag = std::min<int64_t>((int64_t)num_cu * 2, nslab_d);
+  int64_t nb_off = std::min<int64_t>((int64_t)num_cu * 2, nslab_o);
   const int npan = (int)((K + 127) / 128);
   const size_t need = (size_t)std::max<int64_t>(nb_diag * 36, npan > 1 ? nb_off * 64 : 0) * 256 * sizeof(double);
   if (Gpart == nullptr) return need;
