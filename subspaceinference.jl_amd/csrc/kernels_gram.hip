@@ -13,9 +13,10 @@ namespace si {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int GR = 32;   // slab rows
-constexpr int GRP = 34;  // padded row stride in LDS (68 dwords per column): operand reads (lane l -> column l&15, row
-                         // 4s + (l>>4)) touch dword banks 4*col + 2*row (mod 64): 32 distinct bank pairs per 32-lane
-                         // half, conflict-free
+constexpr int GRP = 34;  // padded column stride in LDS (68 dwords): lane l reads column l&15, row 4s + (l>>4), i.e. dword
+                         // banks 4*col + 2*row (mod 64) -- distinct inside each 32-lane half for ds_read_b64.  Measured
+                         // (SQ_LDS_BANK_CONFLICT): strides 34 / 38 / 42 / 46 all leave the same 19 M conflict cycles of
+                         // 59 M active, 36 and 40 are 7-15x worse.
 
 // ------------------------------------------------------------------------------------------------
 // K2, K <= 128 (the usual case: K = snapshots collected, 100 at cfg2).  A 32-row slab of ALL columns fits in LDS twice
