@@ -22,7 +22,8 @@ SOURCES = [
     ("kernels_gram.hip", []),
     ("kernels_bwd.hip", []),
     ("eig.cpp", ["-DSI_EIG_NS=base"]),
-    ("eig.cpp", ["-DSI_EIG_NS=avx2", "-mavx2", "-mfma"], "eig_avx2"),   # same source, second ISA (eig_dispatch.cpp chooses)
+    ("eig.cpp", ["-DSI_EIG_NS=avx2", "-mavx2", "-mfma"], "eig_avx2"),   # same source, other ISAs (eig_dispatch.cpp chooses)
+    ("eig.cpp", ["-DSI_EIG_NS=avx512", "-mavx512f", "-mavx512vl", "-mavx512dq", "-mfma"], "eig_avx512"),
     ("eig_dispatch.cpp", []),
 ]
 HEADERS = ["si_internal.h", "philox.h", "kernels_gemm.h", os.path.join("..", "..", "include", "subspace_hip.h")]

@@ -8,9 +8,10 @@
 #include <cstdint>
 #include <vector>
 
-// This file is compiled twice (build.py): as SI_EIG_NS=base with the default x86-64 flags and as SI_EIG_NS=avx2 with
-// -mavx2 -mfma (the inner loops are contiguous column sweeps: 4-wide FMA roughly halves the time); eig_dispatch.cpp
-// picks one at run time from the CPU's feature bits.
+// This file is compiled three times (build.py): as SI_EIG_NS=base with the default x86-64 flags, as SI_EIG_NS=avx2 with
+// -mavx2 -mfma and as SI_EIG_NS=avx512 with -mavx512f -mfma (the inner loops are contiguous column sweeps and the
+// lane-parallel bisection: wider vectors cut the time); eig_dispatch.cpp picks one at run time from the CPU's feature
+// bits.
 #ifndef SI_EIG_NS
 #define SI_EIG_NS base
 #endif
@@ -163,7 +164,8 @@ int ql_implicit(int n, double* a, double* d, double* e) {
 // si_construct_finish needs the M largest eigenpairs of the K x K Gram matrix (M = 20 of K = 100 at cfg2).  The
 // full solver above spends most of its time accumulating Q and rotating all K columns in the QL sweeps (~7 K^3
 // flops); this route does the Householder reduction with the reflectors kept in factored form (4/3 K^3), takes the
-// eigenvalues from a vector-free QL (O(K^2)), gets the m wanted eigenvectors of T by inverse iteration (O(K) each,
+// eigenvalues by bisection on the Sturm count with all m targets in flight (vectorised), gets the m wanted
+// eigenvectors of T by inverse iteration (O(K) each,
 // re-orthogonalised inside clusters of close eigenvalues) and applies the reflectors to those m vectors only
 // (2 K^2 m).  The result is VERIFIED (residual and orthogonality) by the caller-visible wrapper, which falls back to
 // the full solver if the check fails, so degenerate spectra cost time, never accuracy.
@@ -224,72 +226,56 @@ void tridiagonalize_factored(int n, double* a, double* d, double* e, double* tau
 }
 
 // eigenvalues only: implicit QL on copies of (d, e[0..n-1) sub-diagonal); ascending on exit.  Returns 0 on convergence.
-// sqrt(a^2 + b^2) without overflow in the squares (one division and one sqrt; libm hypot costs 3x as much and the
-// vector-free QL sweep is nothing but these)
-inline double pyth(double a, double b) {
-  const double x = std::fabs(a), y = std::fabs(b);
-  const double hi = x > y ? x : y, lo = x > y ? y : x;
-  if (hi == 0.0) return 0.0;
-  const double r = lo / hi;
-  return hi * std::sqrt(1.0 + r * r);
-}
-
-int ql_values(int n, double* d, double* e) {
-  const double eps = std::ldexp(1.0, -52);
-  e[n - 1] = 0.0;
-  double f = 0.0, tst1 = 0.0;
-  for (int l = 0; l < n; ++l) {
-    tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
-    int m = l;
-    while (m < n) {
-      if (std::fabs(e[m]) <= eps * tst1) break;
-      ++m;
-    }
-    if (m > l) {
-      int iter = 0;
-      do {
-        if (++iter > 200) return 1;
-        double g = d[l];
-        double p = (d[l + 1] - g) / (2.0 * e[l]);
-        double r = pyth(p, 1.0);
-        if (p < 0) r = -r;
-        d[l] = e[l] / (p + r);
-        d[l + 1] = e[l] * (p + r);
-        const double dl1 = d[l + 1];
-        double h = g - d[l];
-        for (int i = l + 2; i < n; ++i) d[i] -= h;
-        f += h;
-        p = d[m];
-        double c = 1.0, c2 = c, c3 = c;
-        const double el1 = e[l + 1];
-        double s = 0.0, s2 = 0.0;
-        for (int i = m - 1; i >= l; --i) {
-          c3 = c2;
-          c2 = c;
-          s2 = s;
-          g = c * e[i];
-          h = c * p;
-          // plain sqrt of the sum of squares when that cannot over/underflow, one reciprocal for both s and c: the
-          // sweep is one serial dependency chain, and this halves its latency
-          const double ss = p * p + e[i] * e[i];
-          r = (ss > 1e-280 && ss < 1e280) ? std::sqrt(ss) : pyth(p, e[i]);
-          e[i + 1] = s * r;
-          const double rinv = 1.0 / r;
-          s = e[i] * rinv;
-          c = p * rinv;
-          p = c * d[i] - s * g;
-          d[i + 1] = h + s * (c * g + s * d[i]);
-        }
-        p = -s * s2 * c3 * el1 * e[l] / dl1;
-        e[l] = s * p;
-        d[l] = c * p;
-      } while (std::fabs(e[l]) > eps * tst1);
-    }
-    d[l] = d[l] + f;
-    e[l] = 0.0;
+// The m largest eigenvalues of the symmetric tridiagonal T (d, e: e[i] couples i and i+1) by bisection on the Sturm
+// count, ALL m targets advanced together: the inner loop over the targets has no dependency between its lanes (one
+// division each) and vectorises, where a vector-free QL sweep is one serial chain of sqrt and divisions (it took 40 %
+// of the whole top-m route).  w[k] = k-th largest, to the precision of the count (a few ulp of ||T||).
+void bisect_top(int n, const double* d, const double* e, int m, double* w, double* work /* 5 * mp doubles */) {
+  const int mp = (m + 7) / 8 * 8;
+  double *lo = work, *hi = lo + mp, *sig = hi + mp, *q = sig + mp, *cnt = q + mp;
+  double gl = d[0], gu = d[0], tnorm = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double r = (i > 0 ? std::fabs(e[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(e[i]) : 0.0);
+    gl = std::min(gl, d[i] - r);
+    gu = std::max(gu, d[i] + r);
+    tnorm = std::max(tnorm, std::fabs(d[i]) + r);
   }
-  std::sort(d, d + n);
-  return 0;
+  const double eps = std::ldexp(1.0, -52);
+  const double pivmin = std::max(eps * eps * tnorm * tnorm, 1e-300);  // floor for |q| (a square: q carries e^2 / q)
+  const double pad = 2.0 * eps * tnorm * n + 1e-300;
+  for (int k = 0; k < mp; ++k) {
+    lo[k] = gl - pad;
+    hi[k] = gu + pad;
+  }
+  std::vector<double> e2(n, 0.0);
+  for (int i = 0; i + 1 < n; ++i) e2[i] = e[i] * e[i];
+  for (int round = 0; round < 58; ++round) {  // the interval starts ~2 ||T|| wide: 58 halvings reach 1e-17 ||T||
+    for (int k = 0; k < mp; ++k) {
+      sig[k] = 0.5 * (lo[k] + hi[k]);
+      double t = d[0] - sig[k];
+      t = std::fabs(t) < pivmin ? -pivmin : t;
+      q[k] = t;
+      cnt[k] = t < 0.0 ? 1.0 : 0.0;
+    }
+    for (int i = 1; i < n; ++i) {
+      const double di = d[i], ei2 = e2[i - 1];
+      for (int k = 0; k < mp; ++k) {  // independent lanes: vectorised
+        double t = di - sig[k] - ei2 / q[k];
+        t = std::fabs(t) < pivmin ? -pivmin : t;
+        q[k] = t;
+        cnt[k] += t < 0.0 ? 1.0 : 0.0;
+      }
+    }
+    // target k is the (n-1-k)-th eigenvalue in ascending order: the smallest sigma with count(sigma) >= n - k
+    for (int k = 0; k < mp; ++k) {
+      const double need = (double)(n - (k < m ? k : m - 1));
+      if (cnt[k] >= need)
+        hi[k] = sig[k];
+      else
+        lo[k] = sig[k];
+    }
+  }
+  for (int k = 0; k < m; ++k) w[k] = 0.5 * (lo[k] + hi[k]);
 }
 
 // LU factorisation with partial pivoting of the tridiagonal T - lambda I (d, e: e[i] couples i and i+1), then solves
@@ -348,13 +334,13 @@ void tridiag_shift_solve(int n, const double* u0inv, const double* u1, const dou
 }
 
 // top-m eigenpairs of the symmetric n x n matrix `a` (column-major, destroyed): w_top[0..m) descending, V n x m.
-// Returns 0 = done (unverified: see sym_eig_top), 1 = the QL iteration did not converge.
+// Returns 0 = done (unverified: see sym_eig_top), 1 = inverse iteration broke down.
 int sym_eig_top_unverified(int n, double* a, int m, double* w_top, double* V) {
   std::vector<double> d(n), e(n), tau(n), work(6 * (size_t)n);
   std::vector<int> sw(n);
   tridiagonalize_factored(n, a, d.data(), e.data(), tau.data(), work.data());
-  std::vector<double> dv(d), ev(e);
-  if (ql_values(n, dv.data(), ev.data()) != 0) return 1;
+  std::vector<double> wtop_t((size_t)m), bwork(5 * ((size_t)m + 8));
+  bisect_top(n, d.data(), e.data(), m, wtop_t.data(), bwork.data());
   double tnorm = 0.0;  // 1-norm of T
   for (int i = 0; i < n; ++i)
     tnorm = std::max(tnorm, std::fabs(d[i]) + (i > 0 ? std::fabs(e[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(e[i]) : 0.0));
@@ -367,7 +353,7 @@ int sym_eig_top_unverified(int n, double* a, int m, double* w_top, double* V) {
   int cluster0 = 0;       // first vector of the current cluster
   double lam_prev = 0.0;  // (perturbed) eigenvalue used for the previous vector
   for (int k = 0; k < m; ++k) {
-    double lam = dv[(size_t)(n - 1 - k)];
+    double lam = wtop_t[(size_t)k];
     w_top[k] = lam;
     if (k > 0) {
       if (lam_prev - lam > ortol) cluster0 = k;                 // well separated: new cluster
