@@ -97,7 +97,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f64_kernel(
   SI_STAMP(0);
   if ((dbg & 32) && bid < 512) {  // harness: stagger the first round of workgroups over ~one block time
     const int n = (int)((bid * 2654435761u) >> 24) & 31;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    const int unit = (dbg >> 8) ? (dbg >> 8) : 127;  // sleep quantum in 64-cycle units (dbg bits 8..)
+    for (int i = 0; i < n * unit; ++i) __builtin_amdgcn_s_sleep(1);
   }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
