@@ -84,6 +84,13 @@ int main(int argc, char** argv) {
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); best = fminf(best, ms);
     }
+    {  // ten launches back to back under ONE event pair: is the per-launch cost paid again without a host gap?
+      hipEventRecord(e0, 0);
+      for (int rep = 0; rep < 10; ++rep) vs[v].fn(0, dW, db, dX, dY, out, in, B, SI_ACT_RELU);
+      hipEventRecord(e1, 0); hipEventSynchronize(e1);
+      float ms10; hipEventElapsedTime(&ms10, e0, e1);
+      printf("[10 back-to-back: %.3f ms each] ", ms10 / 10);
+    }
     printf("%-28s %8.3f ms  %6.2f TFLOP/s  maxdiff-vs-baseline %.3e", vs[v].name, best, flops / (best * 1e-3) / 1e12, maxd);
     {
       std::vector<long long> st(4 * 16384);
