@@ -696,7 +696,8 @@ static int32_t ensure_chains(si_ctx* ctx, int32_t C) {
 }
 
 // density evaluations for chain slots [c0, c0 + nc), nc <= fw_slots, in ONE pass of launches:
-// d_zprop[:, c] -> d_sse[c]; with nc == 1 optionally leaves the model output in *yhat
+// d_zprop[:, c] -> d_sse[c]; optionally leaves the model outputs at *yhat_out (slot j at + j * out_dim*B after the fused
+// tail, at + j * act_elems otherwise)
 static int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out) {
   const int64_t N = ctx->iN, B = ctx->B, ldw = pad_ld(N);
   const int32_t M = ctx->iM;
@@ -938,7 +939,8 @@ int32_t si_predict(si_ctx* ctx, const double* Z, int32_t C, const double* Xnew, 
   int32_t rc = ensure_chains(ctx, C);
   if (rc != SI_OK) return rc;
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  // run the ordinary forward path on temporary data buffers sized for Bn (the density's own X, Y stay untouched)
+  // run the ordinary forward path on temporary data buffers sized for Bn (the density's own X, Y stay untouched);
+  // like the density, up to `wb` samples share one pass of launches (grid.y), within the same workspace cap
   struct Saved {
     double *X, *Y, *act0, *act1, *ssepart, *part, *yhat;
     int64_t B, act_elems;
@@ -947,27 +949,34 @@ int32_t si_predict(si_ctx* ctx, const double* Z, int32_t C, const double* Xnew, 
        ctx->B, ctx->act_elems, ctx->sse_blocks};
   const int64_t act_elems = pad_ld(ctx->max_stored * Bn);
   const int sse_blocks = sse_num_blocks((int64_t)ctx->out_dim * Bn, ctx->num_cu);
+  const size_t dB = (size_t)ctx->out_dim * (size_t)Bn;
+  const double per = 8.0 * (2.0 * (double)act_elems + ((double)ctx->fuse_slots + 1.0) * (double)dB + (double)sse_blocks);
+  const size_t wb = (size_t)std::max(1.0, std::min({(double)C, (double)ctx->fw_slots, std::floor(SI_BATCH_BYTES / per)}));
   double *tX = nullptr, *tY = nullptr, *tA0 = nullptr, *tA1 = nullptr, *tS = nullptr, *tP = nullptr, *tYh = nullptr;
-  bool ok = dev_alloc(&tX, (size_t)ctx->in_dim * Bn) == hipSuccess && dev_alloc(&tY, (size_t)ctx->out_dim * Bn) == hipSuccess &&
-            dev_alloc(&tA0, (size_t)act_elems) == hipSuccess && dev_alloc(&tA1, (size_t)act_elems) == hipSuccess &&
-            dev_alloc(&tS, (size_t)sse_blocks) == hipSuccess &&
-            (!ctx->fuse_tail || (dev_alloc(&tP, (size_t)ctx->fuse_slots * ctx->out_dim * Bn) == hipSuccess &&
-                                 dev_alloc(&tYh, (size_t)ctx->out_dim * Bn) == hipSuccess));
+  bool ok = dev_alloc(&tX, (size_t)ctx->in_dim * Bn) == hipSuccess && dev_alloc(&tY, dB) == hipSuccess &&
+            dev_alloc(&tA0, wb * (size_t)act_elems) == hipSuccess && dev_alloc(&tA1, wb * (size_t)act_elems) == hipSuccess &&
+            dev_alloc(&tS, wb * (size_t)sse_blocks) == hipSuccess &&
+            (!ctx->fuse_tail || (dev_alloc(&tP, wb * (size_t)ctx->fuse_slots * dB) == hipSuccess &&
+                                 dev_alloc(&tYh, wb * dB) == hipSuccess));
   hipError_t e = hipSuccess;
   if (ok) {
     e = hipMemcpyAsync(tX, Xnew, (size_t)ctx->in_dim * Bn * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(tY, 0, (size_t)ctx->out_dim * Bn * sizeof(double), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(tY, 0, dB * sizeof(double), ctx->stream);
     if (e == hipSuccess)
       e = hipMemcpyAsync(ctx->d_zprop, Z, (size_t)ctx->iM * C * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     ctx->d_X = tX; ctx->d_Y = tY; ctx->d_act[0] = tA0; ctx->d_act[1] = tA1; ctx->d_ssepart = tS; ctx->d_part = tP;
     ctx->d_yhat = tYh; ctx->B = Bn; ctx->act_elems = act_elems; ctx->sse_blocks = sse_blocks;
-    for (int c = 0; c < C && e == hipSuccess && rc == SI_OK; ++c) {
+    for (int c0 = 0; c0 < C && e == hipSuccess && rc == SI_OK; c0 += (int)wb) {
+      const int nc = std::min<int>((int)wb, C - c0);
       const double* yh = nullptr;
-      rc = eval_density(ctx, c, 1, &yh);
-      if (rc == SI_OK)
-        e = hipMemcpyAsync(Yhat_out + (size_t)c * ctx->out_dim * Bn, yh, (size_t)ctx->out_dim * Bn * sizeof(double),
-                           hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // yh is overwritten by the next sample
+      rc = eval_density(ctx, c0, nc, &yh);
+      if (rc == SI_OK) {
+        // sample j of the batch: yh + j * (out_dim*Bn) after the fused tail, yh + j * act_elems otherwise
+        const size_t src_pitch = (ctx->fuse_tail ? dB : (size_t)act_elems) * sizeof(double);
+        e = hipMemcpy2DAsync(Yhat_out + (size_t)c0 * dB, dB * sizeof(double), yh, src_pitch, dB * sizeof(double), (size_t)nc,
+                             hipMemcpyDeviceToHost, ctx->stream);
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the outputs are overwritten by the next batch
     }
     ctx->d_X = sv.X; ctx->d_Y = sv.Y; ctx->d_act[0] = sv.act0; ctx->d_act[1] = sv.act1; ctx->d_ssepart = sv.ssepart;
     ctx->d_part = sv.part; ctx->d_yhat = sv.yhat; ctx->B = sv.B; ctx->act_elems = sv.act_elems; ctx->sse_blocks = sv.sse_blocks;
