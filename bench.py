@@ -1,27 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- the hot path of SubspaceInference.jl on MI355X at BASELINE.json's cfg2.
+"""bench.py -- the hot path of SubspaceInference.jl on MI355X at BASELINE.json's configurations.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--mode chains|construct-sharded|data-sharded]
 
-A "step" is ONE posterior sample: propose z' -> W_swa + P z' -> Dense-chain forward over the full data in fp64
--> Gaussian log-likelihood -> Metropolis accept (reference src/space_inference.jl:90-95,111-116), all on the
-device with inputs resident in HBM.  Each GPU runs its own independent chain (weak scaling, no data-path
-collective); `value` = samples of all ranks / max-over-ranks time.  The subspace-construct wall-clock (the
-metric's second half: K=100 SWA/deviation pushes from device-resident snapshots + Gram + eigensolve +
-projection) is measured before sampling and reported as `construct_wall_ms`.
+With N > 1 and no RANK in the environment the parent process -- BEFORE importing torch or touching HIP -- starts the N
+ranks itself (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), relays
+rank 0's JSON line and exits non-zero when any rank fails.  Started under torchrun (RANK set) it is one rank.
+`n_gpus` in the line is the number of ranks RCCL actually saw (all-reduce of ones); N > visible GPUs is an error.
 
-One JSON line on stdout (rank 0).  `roofline` is computed live from the library's own hipEvent pairs around
-the dominant kernel (the 960x960 Dense layer GEMM on the fp64 matrix cores) inside the timed region;
-`cpu_baseline` times the NumPy/OpenBLAS oracle on the same workload on this box's host cores (bounded sample).
+--mode chains (default; the headline, BASELINE cfg2 / cfg3)
+    A "step" is ONE posterior sample: propose z' -> W_swa + P z' -> Dense-chain forward over the full data in fp64 ->
+    Gaussian log-likelihood -> Metropolis accept (reference src/space_inference.jl:90-95,111-116), all on the device
+    with inputs resident in HBM.  Each GPU runs its own independent chain (weak scaling, no data-path collective);
+    `value` = samples of all ranks / max-over-ranks time.  The subspace-construct wall-clock (the metric's second half)
+    is measured before sampling and reported as `construct_wall_ms`.
+--mode construct-sharded --config cfg4|cfg5
+    Row-sharded construction: every rank holds N/world rows of the snapshots / W_swa / A / P; K1, K2, K3 are
+    row-local, ONE in-place RCCL all-reduce of the K x K Gram matrix.  A step = one whole construction.
+--mode data-sharded
+    cfg5 density with the observations split over the ranks (B_total = 131072 fixed: strong scaling), W_swa / P (26 GB)
+    replicated and device-resident, ONE 8-byte in-place RCCL all-reduce per transition.  A step = one transition.
+
+One JSON line on stdout (rank 0).  `roofline` is computed live from the library's own hipEvent pairs around the
+dominant kernel inside the timed region; `cpu_baseline` (N = 1, chains mode) times the CPU restatement on this box's
+host cores (bounded sample): the C/OpenMP port single-core and all-core, and the NumPy/OpenBLAS port.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -30,111 +41,265 @@ METRIC = "posterior samples/sec (whole node) + subspace-construct wall-clock, 1M
 DIMS, ACTS = [128, 960, 960, 1], [1, 1, 0]  # Chain(Dense(128,960,relu), Dense(960,960,relu), Dense(960,1))
 B, M, K_SNAP = 100000, 20, 100
 SIGMA_Z, SIGMA_M = 0.1, 1.0
-PEAK_F64_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet; the guide's table has no f64 row -- DESIGN.md)
+PEAK_F64_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet; the guide's table has no f64 row -- DESIGN.md section 4)
 PEAK_HBM_GBS = 8000.0
+CFG = {  # construct-only configurations
+    "cfg2": dict(n=1047361, k=100, m=20),
+    "cfg4": dict(n=5200266, k=200, m=20),
+    "cfg5": dict(n=51138049, k=128, m=64),
+}
+DIMS5, ACTS5, B5_TOTAL, M5 = [1024, 6656, 6656, 1], [1, 1, 0], 8 * 16384, 64
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def layer_table():
+# ------------------------------------------------------------------------------------------------ launcher
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--mode", choices=["chains", "construct-sharded", "data-sharded"], default="chains")
+    ap.add_argument("--config", choices=sorted(CFG), default="cfg5", help="construct-sharded: which N / K / M")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run-launcher", action="store_true",
+                    help="ranks join a gloo group, count themselves and print a line with value null: exercises the "
+                         "launch / relay / failure logic on a machine without GPUs (tests/test_bench_launcher.py)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="(dry run) this rank exits non-zero")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    dflt = {"chains": (100, 10), "construct-sharded": (5, 2), "data-sharded": (20, 3)}[args.mode]
+    args.steps = dflt[0] if args.steps is None else args.steps
+    args.warmup = dflt[1] if args.warmup is None else args.warmup
+    return args
+
+
+def launch_ranks(args, argv):
+    """Parent of an N-rank run.  Imports neither torch nor the HIP library: the ranks are CHILD processes (a process
+    that has initialised the GPU must never exec another program), and a failed child is a failed run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    log("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and ln.rstrip().endswith("}")]
+    if r.returncode != 0:
+        log("bench.py: a rank failed (torchrun exit code %d); no result line" % r.returncode)
+        return r.returncode if r.returncode > 0 else 1
+    if len(lines) != 1:
+        log("bench.py: expected exactly one JSON line from rank 0, got %d" % len(lines))
+        return 1
+    try:
+        json.loads(lines[0])
+    except ValueError:
+        log("bench.py: rank 0's line is not valid JSON")
+        return 1
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def layer_table(dims, acts):
     table, off = [], 0
-    for fin, fout, act in zip(DIMS[:-1], DIMS[1:], ACTS):
+    for fin, fout, act in zip(dims[:-1], dims[1:], acts):
         table.append((fin, fout, act, off, off + fin * fout))
         off += fin * fout + fout
     return table, off
 
 
-def glorot_flat(seed):
+def glorot_flat(seed, dims=DIMS):
+    import numpy as np
     rng = np.random.default_rng(seed)
     parts = []
-    for fin, fout in zip(DIMS[:-1], DIMS[1:]):
+    for fin, fout in zip(dims[:-1], dims[1:]):
         w = ((rng.random((fout, fin)) - 0.5) * np.sqrt(24.0 / (fin + fout))).astype(np.float32)
         parts += [w.reshape(-1, order="F"), np.zeros(fout, dtype=np.float32)]
     return np.concatenate(parts)
 
 
-def cpu_baseline(table, w_swa, p, x, y, z0, budget_s):
-    """The NumPy/OpenBLAS restatement (oracle) timed on the host: bounded sample of the same workload."""
-    from oracle import subspace_oracle as so
-    blas = "unknown"
-    try:
-        from threadpoolctl import threadpool_info
-        info = threadpool_info()
-        cores = max([i.get("num_threads", 1) for i in info] or [os.cpu_count() or 1])
-        blas = ", ".join(sorted({"%s %s" % (i.get("internal_api", "?"), i.get("version", "?")) for i in info
-                                 if i.get("user_api") == "blas"})) or blas
-    except Exception:
-        cores = os.cpu_count() or 1
-    cpu_model = "unknown"
+def _sha16(path):
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def pmc_traffic(profile, kernel_sources):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE,
+    separate passes, gfx950 correction applied -- MI355X_MICROARCH.md), valid ONLY while the kernel sources are the ones
+    the profile was taken on: the profile records their sha256; on a mismatch `traffic` is null rather than stale."""
+    path = os.path.join(ROOT, "profiles", profile)
+    if not os.path.exists(path):
+        return None, "no PMC profile committed"
+    rec = json.load(open(path))
+    want = rec.get("kernel_source_sha16", {})
+    have = {s: _sha16(os.path.join(ROOT, "subspaceinference.jl_amd", "csrc", s)) for s in kernel_sources}
+    if not want or any(want.get(s) != have[s] for s in kernel_sources):
+        return None, "profiles/%s was taken on other kernel sources (sha mismatch): re-run tools/pmc_traffic.sh" % profile
+    return rec.get("hbm_bytes_per_launch"), "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same kernel sources by sha256)" % profile
+
+
+def host_info():
+    info = {"host_cpus": os.cpu_count(), "cpu_model": "unknown"}
     try:
         with open("/proc/cpuinfo") as f:
             for line in f:
                 if line.startswith("model name"):
-                    cpu_model = line.split(":", 1)[1].strip()
+                    info["cpu_model"] = line.split(":", 1)[1].strip()
                     break
     except OSError:
         pass
-    t0 = time.perf_counter()
-    lp0 = so.logdensity(table, w_swa, p, x, y, SIGMA_M, z0)
-    t1 = time.perf_counter() - t0
-    n = int(max(1, min(50, (budget_s - t1) // max(t1, 1e-3))))
+    return info
+
+
+def cpu_baseline(table, w_swa, p, x, y, z0, budget_s):
+    """The CPU restatement (oracle) timed on the host, bounded sample of the same workload: (1) the C/OpenMP port
+    (oracle/subspace_oracle_c.c: blocked fp64 GEMM, AVX-512 / AVX2 by run-time dispatch) on ONE core and on ALL cores,
+    (2) the NumPy/OpenBLAS port.  `value` is the fastest all-core figure -- the baseline most favourable to the CPU."""
+    import numpy as np
+    from oracle import subspace_oracle as so
+    out = dict(host_info(), kind="port", unit="samples/s")
     rng = np.random.default_rng(123)
+    legs = {}
+    lp0 = None
+    try:
+        from oracle import c_port
+        cores = c_port.max_threads()
+        lpc = c_port.logdensity(table, w_swa, p, x, y, SIGMA_M, z0, threads=cores)   # warm-up + parity
+        t0 = time.perf_counter()
+        n = 0
+        while n < 200 and time.perf_counter() - t0 < budget_s * 0.4:
+            c_port.logdensity(table, w_swa, p, x, y, SIGMA_M, z0 + SIGMA_Z * rng.standard_normal(M), threads=cores)
+            n += 1
+        dt = time.perf_counter() - t0
+        legs["c_openmp_all_cores"] = {"value": n / dt, "threads": cores, "evaluations": n, "seconds": round(dt, 2),
+                                      "isa": c_port.isa()}
+        t0 = time.perf_counter()
+        c_port.logdensity(table, w_swa, p, x, y, SIGMA_M, z0, threads=1)
+        dt1 = time.perf_counter() - t0
+        legs["c_openmp_single_core"] = {"value": 1.0 / dt1, "threads": 1, "evaluations": 1, "seconds": round(dt1, 2)}
+        lp0 = lpc
+    except Exception as e:  # the C port is optional test infrastructure; its absence is reported, not hidden
+        legs["c_openmp_error"] = repr(e)
+    blas, threads = "unknown", os.cpu_count() or 1
+    try:
+        from threadpoolctl import threadpool_info
+        tinfo = threadpool_info()
+        threads = max([i.get("num_threads", 1) for i in tinfo] or [threads])
+        blas = ", ".join(sorted({"%s %s" % (i.get("internal_api", "?"), i.get("version", "?")) for i in tinfo
+                                 if i.get("user_api") == "blas"})) or blas
+    except Exception:
+        pass
+    t0 = time.perf_counter()
+    lpn = so.logdensity(table, w_swa, p, x, y, SIGMA_M, z0)
+    t1 = time.perf_counter() - t0
+    n = int(max(1, min(30, (budget_s * 0.5 - t1) // max(t1, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(n):
         so.logdensity(table, w_swa, p, x, y, SIGMA_M, z0 + SIGMA_Z * rng.standard_normal(M))
     dt = time.perf_counter() - t0
-    single = None
-    try:  # the same evaluation on ONE host thread (BASELINE.md asks for both figures); one evaluation, ~5-10 s
-        from threadpoolctl import threadpool_limits
-        with threadpool_limits(limits=1):
-            t0 = time.perf_counter()
-            so.logdensity(table, w_swa, p, x, y, SIGMA_M, z0)
-            single = 1.0 / (time.perf_counter() - t0)
-    except Exception:
-        pass
-    return {"value": n / dt, "unit": "samples/s", "cores": int(cores), "kind": "port", "single_core_value": single, "cpu_model": cpu_model,
-            "host_cpus": os.cpu_count(), "blas": blas,
-            "sample": "%d density evaluations (W_swa+P*z, fp64 forward over X 128x%d, SSE) of the cfg2 workload with "
-                      "NumPy+OpenBLAS (oracle/subspace_oracle.py), %.1f s" % (n, B, dt)}, lp0
+    legs["numpy_openblas"] = {"value": n / dt, "threads": int(threads), "evaluations": n, "seconds": round(dt, 2), "blas": blas}
+    if lp0 is None:
+        lp0 = lpn
+    else:
+        legs["c_vs_numpy_lp_rel_diff"] = abs(lp0 - lpn) / abs(lpn)
+    best = max((k for k in legs if isinstance(legs[k], dict) and k != "c_openmp_single_core"), key=lambda k: legs[k]["value"])
+    out.update(value=legs[best]["value"], cores=int(legs[best]["threads"]), best_leg=best, legs=legs,
+               single_core_value=legs.get("c_openmp_single_core", {}).get("value"),
+               sample="%d density evaluations (W_swa+P*z, fp64 forward over X 128x%d, SSE) of the cfg2 workload, %s, %.1f s"
+                      % (legs[best]["evaluations"], B, best, legs[best]["seconds"]))
+    return out, lpn
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (rank 0, N=1)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class Rank:
+    """process-group plumbing of one rank (torch.distributed; backend nccl = RCCL on the GPU node)"""
 
-    # Only the JSON line may reach stdout: RCCL prints a version banner to fd 1 when the communicator is created.
-    # Keep the real stdout aside and point fd 1 at stderr for everything else.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        self.args = args
 
+    def init(self, backend):
+        if self.world > 1 or os.environ.get("SI_BENCH_FORCE_DIST") == "1":  # the env knob rehearses RCCL on one GPU
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            kw = {"device_id": torch.device("cuda", self.local_rank)} if backend == "nccl" else {}
+            dist.init_process_group(backend, **kw)
+            self.dist = dist
+
+    def count_ranks(self, device):
+        """ranks the collective backend actually saw: all-reduce of ones"""
+        if self.dist is None:
+            return 1
+        import torch
+        t = torch.ones(1, dtype=torch.int64, device=device)
+        self.dist.all_reduce(t)
+        return int(t.item())
+
+    def max_over_ranks(self, v, device):
+        if self.dist is None:
+            return v
+        import torch
+        t = torch.tensor([v], device=device, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_floats(self, v, device):
+        if self.dist is None:
+            return [v]
+        import torch
+        t = torch.tensor([v], device=device, dtype=torch.float64)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return [float(o.item()) for o in outs]
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def emit(real_stdout, out):
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+
+# ------------------------------------------------------------------------------------------------ dry run (no GPU)
+def run_dry(args, rk, real_stdout):
+    rk.init("gloo")
+    if rk.rank == args.fail_rank:
+        raise SystemExit(3)
+    n = rk.count_ranks("cpu")
+    if rk.dist is not None:
+        rk.dist.barrier()
+    if rk.rank == 0:
+        emit(real_stdout, {"metric": METRIC, "value": None, "unit": "samples/s", "n_gpus": n, "steps": args.steps,
+                           "warmup": args.warmup, "dry_run": True, "mode": args.mode})
+    rk.finish()
+
+
+# ------------------------------------------------------------------------------------------------ mode: chains
+def run_chains(args, rk, real_stdout):
+    import numpy as np
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or os.environ.get("SI_BENCH_FORCE_DIST") == "1":  # the env knob rehearses the RCCL path on one GPU
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     import subspaceinference_jl_amd as si
-    table, n_par = layer_table()
+    rank, world = rk.rank, rk.world
+    dev = torch.device("cuda", rk.local_rank)
+    n_seen = rk.count_ranks(dev)
+    table, n_par = layer_table(DIMS, ACTS)
     assert n_par == 1047361
 
     # ---- synthetic inputs (deterministic), made resident in HBM before any timed region
@@ -150,13 +315,13 @@ def main():
     del steps
     torch.cuda.synchronize()
 
-    ctx = si.Context(local_rank)
+    ctx = si.Context(rk.local_rank)
 
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        if rk.dist is not None:
+            rk.dist.barrier()
 
     # ---- subspace construction (K pushes + Gram + eig + project), results stay on the device
     def construct():
@@ -174,7 +339,7 @@ def main():
     ctx.set_profiling(False)
     barrier()
     t0 = time.perf_counter()
-    _, _, svals, _ = construct()  # the wall-clock figure, without the event pairs
+    construct()  # the wall-clock figure, without the event pairs
     ctx.synchronize()
     construct_ms = (time.perf_counter() - t0) * 1e3
 
@@ -190,27 +355,36 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     st = ctx.stats()
-    if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    value = world * args.steps / dt
+    dt = rk.max_over_ranks(dt, dev)
+    value = n_seen * args.steps / dt
     bsteps = 20
     ctx.set_profiling(True)
     ctx.reset_stats()
     ctx.sample_rwmh(bsteps, SIGMA_Z, seed=100 + rank, chain_id0=rank, want_z=False)
     ctx.synchronize()
     bst = ctx.stats()
+    ctx.set_profiling(False)
 
-    # ---- extras (outside every timed region above): the "next" rows at the same workload
+    # ---- the reference's output map a13 (src/space_inference.jl:125): W_swa + P*z for every sample, delivered to the
+    # host like the reference's Vector{Vector{Float64}} -- NOT part of `value` (api.sub_inference does it on request)
     extras = {}
     if rank == 0:
+        nmap = min(args.steps, 32)
+        zz = np.asfortranarray(z[:, :nmap, 0])
+        ctx.reconstruct(zz[:, :2])
+        t0 = time.perf_counter()
+        ctx.reconstruct(zz)
+        extras["output_map_ms_per_sample"] = (time.perf_counter() - t0) / nmap * 1e3
+        extras["output_map_note"] = ("a13: one K4 pass + %d-byte D2H per sample into pageable host memory (%d samples timed); "
+                                     "excluded from `value`, which times the chain itself" % (8 * n_par, nmap))
+        # the "next" rows at the same workload (outside every timed region above)
         ctx.reset_stats()
-        zz = np.ascontiguousarray(z[:, 0, 0])
-        ctx.logdensity_grad(zz)  # warm-up (workspace allocation)
+        ctx.set_profiling(True)
+        z1 = np.ascontiguousarray(z[:, 0, 0])
+        ctx.logdensity_grad(z1)  # warm-up (workspace allocation)
         t0 = time.perf_counter()
         for _ in range(5):
-            ctx.logdensity_grad(zz)
+            ctx.logdensity_grad(z1)
         extras["logdensity_grad_ms"] = (time.perf_counter() - t0) / 5 * 1e3
         ctx.train_setup(table, n_par, glorot_flat(1), x, y, B, 2, 1e-3, 0.9, 0.999)  # ADAM, full batch
         ids = np.arange(B)
@@ -222,36 +396,52 @@ def main():
         extras["train_step_full_batch_ms"] = (time.perf_counter() - t0) / 5 * 1e3
         bs = ctx.stats()["backward"]
         extras["backward_sweep_tflops"] = bs["flops"] / max(bs["ms"], 1e-9) / 1e9
+        ctx.set_profiling(False)
 
     if rank == 0:
         dm = st["dense_main"]
         avg_ms = dm["ms"] / max(1, dm["launches"])
         fl = dm["flops"] / max(1, dm["launches"])
         achieved = fl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_dense_main.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        traffic, traffic_src = pmc_traffic("r02_pmc_dense_main.json", ["kernels_gemm.hip"])
+        ms_step = dt / args.steps * 1e3
+        step_flops = 2.0 * B * sum(a * b for a, b in zip(DIMS[:-1], DIMS[1:]))
+        step_tflops = step_flops / (ms_step * 1e-3) / 1e12
+
+        def frac(cls, bound):
+            v = cst[cls]
+            if v["ms"] <= 0:
+                return None
+            if bound == "hbm":
+                a = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+                return {"bound": "hbm", "achieved_GBs": round(a, 1), "frac": round(a / PEAK_HBM_GBS, 4), "ms": round(v["ms"], 4)}
+            a = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            return {"bound": "mfma", "achieved_TFLOPs": round(a, 2), "frac": round(a / PEAK_F64_TFLOPS, 4), "ms": round(v["ms"], 4)}
         out = {
-            "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": n_seen, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cfg2: Chain(Dense(128,960,relu),Dense(960,960,relu),Dense(960,1)) N=1047361, "
                                    "X 128x100000 Y 1x100000 fp64, M=20, K=100 fp32 snapshots, RWMH sigma_z=0.1 sigma_m=1",
-                       "chains_per_gpu": 1, "parallelism": "independent chains x%d (one per GPU), no data-path collective" % world},
+                       "chains_per_gpu": 1, "mode": "chains",
+                       "parallelism": "independent chains x%d (one per GPU), no data-path collective" % n_seen},
             "construct_wall_ms": construct_ms,
             "construct_device_ms": {k: round(cst[k]["ms"], 4) for k in ("push", "gram", "gram_reduce", "project")},
             "construct_host_eig_ms": round(cst["eig_host"]["ms"], 4),
+            "construct_roofline": {"push": frac("push", "hbm"), "gram": frac("gram", "mfma"), "project": frac("project", "hbm")},
             "sample_device_ms_per_step": {k: round(bst[k]["ms"] / bsteps, 4) for k in ("reconstruct", "dense", "sse", "rwmh")},
             "accept_rate": float(acc[0]), "lp_last": float(lp[-1, 0]),
             "roofline": {"kernel": "dense_f64_kernel<96,128> layer 960x960 + fused 960->1 tail (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F64_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_F64_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "flops_per_launch": fl, "launches": dm["launches"]},
+            "step_roofline": {"bound": "mfma", "flops_per_step": step_flops, "achieved": step_tflops, "peak": PEAK_F64_TFLOPS,
+                              "unit": "TFLOP/s", "frac": step_tflops / PEAK_F64_TFLOPS,
+                              "note": "ALL of a transition (propose, reconstruct, 3 layers, SSE, accept) against the fp64 matrix peak"},
             "device": ctx.device_name(),
             "next_rows": extras,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if n_seen == 1 and not args.no_cpu_baseline:
             # W_swa / P of the construction just timed, brought to the host only for the CPU leg (outside all timers)
             w_swa, p, _, _ = ctx.construct_finish(M)
             cb, lp_cpu = cpu_baseline(table, w_swa, p, x, y, z[:, 0, 0], args.cpu_budget)
@@ -259,11 +449,217 @@ def main():
             out["parity_lp_rel_err_vs_oracle"] = abs(lp_cpu - float(lp[0, 0])) / abs(lp_cpu)
         else:
             out["cpu_baseline"] = None
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        emit(real_stdout, out)
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rk.finish()
+
+
+# ------------------------------------------------------------------------------------------------ mode: construct-sharded
+def run_construct_sharded(args, rk, real_stdout):
+    """Row-sharded construction: rank r holds rows row_shard(N, r, world) of every snapshot, of W_swa, A and P."""
+    import numpy as np
+    import torch
+    import subspaceinference_jl_amd as si
+    from subspaceinference_jl_amd import dist as sd
+    rank, world = rk.rank, rk.world
+    dev = torch.device("cuda", rk.local_rank)
+    n_seen = rk.count_ranks(dev)
+    cfg = CFG[args.config]
+    n, k, m = cfg["n"], cfg["k"], cfg["m"]
+    r0, r1 = sd.row_shard(n, rank, world)
+    n_loc = r1 - r0
+    ldw = n_loc + (n_loc & 1)
+    gen = torch.Generator(device="cuda").manual_seed(1000 + rank)
+    snaps = torch.zeros((k, ldw), device="cuda", dtype=torch.float32)
+    cur = 0.02 * torch.randn(n_loc, generator=gen, device="cuda", dtype=torch.float32)
+    for j in range(k):  # random-walk stream of this rank's rows (full-rank A), built row by row to bound memory
+        cur = cur + 0.002 * torch.randn(n_loc, generator=gen, device="cuda", dtype=torch.float32)
+        snaps[j, :n_loc] = cur
+    torch.cuda.synchronize()
+    ctx = si.Context(rk.local_rank)
+    if rk.dist is not None:
+        sd.bind_stream(ctx)
+    ns = np.arange(1, k + 1, dtype=np.float64)
+
+    def construct():
+        ctx.construct_begin(n_loc, k)
+        ctx.construct_push_batch_dev(snaps.data_ptr(), 0, ldw, ns)
+        return _finish()
+
+    def _finish():
+        # K2 local -> ONE in-place RCCL all-reduce of the K x K Gram -> replicated H1 -> K3 local; results stay on device
+        ctx.construct_gram()
+        if rk.dist is not None:
+            ptr, kk = ctx.construct_gram_ptr()
+            sd.allreduce_inplace(ctx, ptr, kk * kk)
+        return ctx.construct_finish(m, want_swa=False, want_p=False)[2]
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if rk.dist is not None:
+            rk.dist.barrier()
+    for _ in range(max(1, args.warmup)):
+        construct()
+    ctx.set_profiling(True)
+    ctx.reset_stats()
+    construct()
+    ctx.synchronize()
+    cst = ctx.stats()
+    ctx.set_profiling(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s = construct()
+    barrier()
+    dt = rk.max_over_ranks(time.perf_counter() - t0, dev)
+    ms = dt / args.steps * 1e3
+    dev_ms = {kk: rk.gather_floats(cst[kk]["ms"], dev) for kk in ("push", "gram", "gram_reduce", "project", "eig_host")}
+    if rank == 0:
+        total_bytes = float(n) * (k * (4 + 8) + 16) + float(n) * k * 8 + float(n) * (k + m) * 8   # K1 + K2 + K3, algorithmic
+        total_flops = float(n) * k * (k + 1) + 2.0 * n * k * m
+
+        def blk(cls, bound):
+            v = cst[cls]
+            if v["ms"] <= 0:
+                return None
+            if bound == "hbm":
+                a = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+                return {"bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a / PEAK_HBM_GBS, "rank0_ms": v["ms"]}
+            a = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            return {"bound": "mfma", "achieved": a, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s", "frac": a / PEAK_F64_TFLOPS, "rank0_ms": v["ms"]}
+        gram = blk("gram", "mfma")
+        emit(real_stdout, {
+            "metric": "subspace-construct wall-clock, row-sharded (%s)" % args.config, "value": ms, "unit": "ms",
+            "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s construct-only: N=%d rows sharded %d-way (%d on rank 0), K=%d fp32 snapshots (device-resident), M=%d"
+                                   % (args.config, n, n_seen, n_loc, k, m), "mode": "construct-sharded",
+                       "parallelism": "row shards; K1/K2/K3 row-local, ONE in-place RCCL all-reduce of the %dx%d fp64 Gram (%d B)"
+                                      % (k, k, 8 * k * k)},
+            "aggregate": {"algorithmic_GBs": total_bytes / (ms * 1e-3) / 1e9, "algorithmic_TFLOPs": total_flops / (ms * 1e-3) / 1e12},
+            "per_rank_device_ms": dev_ms,
+            "roofline": dict(gram or {}, kernel="gram A'A (v_mfma_f64_16x16x4_f64), rank 0", traffic=None),
+            "roofline_push": blk("push", "hbm"), "roofline_project": blk("project", "mfma" if m > 32 else "hbm"),
+            "s1": float(s[0]), "device": ctx.device_name(), "cpu_baseline": None,
+        })
+    ctx.close()
+    rk.finish()
+
+
+# ------------------------------------------------------------------------------------------------ mode: data-sharded
+def run_data_sharded(args, rk, real_stdout):
+    """cfg5 density, observations split over the ranks; W_swa / P device-resident and used in place."""
+    import numpy as np
+    import torch
+    import subspaceinference_jl_amd as si
+    from subspaceinference_jl_amd import dist as sd
+    rank, world = rk.rank, rk.world
+    dev = torch.device("cuda", rk.local_rank)
+    n_seen = rk.count_ranks(dev)
+    table, n = layer_table(DIMS5, ACTS5)
+    b0, b1 = sd.col_shard(B5_TOTAL, rank, world)
+    b_loc = b1 - b0
+    ld = (n + 63) // 64 * 64
+    gen = torch.Generator(device="cuda").manual_seed(7)         # the same W_swa / P on every rank
+    w_t = torch.zeros(ld, device="cuda", dtype=torch.float64)
+    w_t[:n] = torch.from_numpy(glorot_flat(1, DIMS5).astype(np.float64)).cuda()
+    p_t = torch.zeros((M5, ld), device="cuda", dtype=torch.float64)
+    for j in range(M5):
+        p_t[j, :n] = 1e-3 * torch.randn(n, generator=gen, device="cuda", dtype=torch.float64)
+    gx = torch.Generator(device="cuda").manual_seed(11)
+    x_all = torch.randn((B5_TOTAL, DIMS5[0]), generator=gx, device="cuda", dtype=torch.float64)   # [B, in] = in x B col-major
+    y_all = torch.randn((B5_TOTAL, 1), generator=gx, device="cuda", dtype=torch.float64)
+    x_t, y_t = x_all[b0:b1].contiguous(), y_all[b0:b1].contiguous()
+    del x_all, y_all
+    torch.cuda.synchronize()
+    ctx = si.Context(rk.local_rank)
+    if rk.dist is not None:
+        sd.bind_stream(ctx)
+    ctx.infer_setup_dev(table, n, M5, w_t.data_ptr(), p_t.data_ptr(), ld, x_t.data_ptr(), y_t.data_ptr(), DIMS5[0], 1,
+                        b_loc, 1.0, borrow=True)
+    d_total = B5_TOTAL
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if rk.dist is not None:
+            rk.dist.barrier()
+    sd.sample_data_sharded(ctx, max(2, args.warmup), 1e-3, seed=5, d_total=d_total)
+    ctx.set_profiling(True, classes=["dense_main"])
+    barrier()
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    z, lp, acc = sd.sample_data_sharded(ctx, args.steps, 1e-3, seed=5, d_total=d_total)
+    barrier()
+    dt = rk.max_over_ranks(time.perf_counter() - t0, dev)
+    st = ctx.stats()
+    ctx.set_profiling(True)
+    ctx.reset_stats()
+    sd.sample_data_sharded(ctx, 5, 1e-3, seed=5, d_total=d_total)
+    ctx.synchronize()
+    bst = ctx.stats()
+    ms = dt / args.steps * 1e3
+    lps = rk.gather_floats(float(lp[-1, 0]), dev)
+    if rank == 0:
+        dm = st["dense_main"]
+        avg_ms = dm["ms"] / max(1, dm["launches"])
+        fl = dm["flops"] / max(1, dm["launches"])
+        achieved = fl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        rec = bst["reconstruct"]
+        rec_gbs = rec["bytes"] / max(rec["ms"], 1e-9) / 1e6
+        step_flops = 2.0 * B5_TOTAL * sum(a * b for a, b in zip(DIMS5[:-1], DIMS5[1:]))
+        emit(real_stdout, {
+            "metric": "posterior samples/sec, data-sharded density (cfg5 wide MLP, M=64)", "value": args.steps / dt,
+            "unit": "samples/s", "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cfg5: Chain(Dense(1024,6656,relu),Dense(6656,6656,relu),Dense(6656,1)) N=51138049, M=64, "
+                                   "B_total=%d split %d-way (%d on rank 0), W_swa/P (26 GB) replicated, device-resident" % (B5_TOTAL, n_seen, b_loc),
+                       "mode": "data-sharded",
+                       "parallelism": "observations sharded; every rank runs the same Philox stream; ONE 8-byte in-place RCCL all-reduce per transition"},
+            "ranks_agree_on_lp": bool(len(set(lps)) == 1),
+            "per_step_device_ms": {k: round(bst[k]["ms"] / 5, 4) for k in ("reconstruct", "dense", "sse", "rwmh")},
+            "roofline": {"kernel": "dense_f64_kernel layer 6656x6656 + fused 6656->1 tail, rank 0's share", "bound": "mfma",
+                         "achieved": achieved, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F64_TFLOPS,
+                         "traffic": None, "avg_launch_ms": avg_ms, "flops_per_launch": fl, "launches": dm["launches"]},
+            "roofline_reconstruct": {"kernel": "reconstruct_kernel over the 26 GB P (K4)", "bound": "hbm", "achieved": rec_gbs,
+                                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": rec_gbs / PEAK_HBM_GBS},
+            "step_roofline": {"bound": "mfma", "flops_per_step": step_flops, "achieved": step_flops / (ms * 1e-3) / 1e12 / n_seen,
+                              "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s per GPU",
+                              "frac": step_flops / (ms * 1e-3) / 1e12 / n_seen / PEAK_F64_TFLOPS},
+            "lp_last": lps[0], "device": ctx.device_name(), "cpu_baseline": None,
+        })
+    ctx.close()
+    rk.finish()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # N ranks were asked for and nobody started them: do it ourselves, before torch / HIP are touched
+        raise SystemExit(launch_ranks(args, argv))
+
+    # Only the JSON line may reach stdout: RCCL prints a version banner to fd 1 when the communicator is created.
+    # Keep the real stdout aside and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    rk = Rank(args)
+    if rk.world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d (start it as `python bench.py --gpus N` or under "
+                         "torchrun with --nproc-per-node N)" % (rk.world, args.gpus))
+    if args.dry_run_launcher:
+        return run_dry(args, rk, real_stdout)
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    if rk.local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: --gpus %d exceeds the %d visible GPUs" % (args.gpus, torch.cuda.device_count()))
+    torch.cuda.set_device(rk.local_rank)
+    rk.init("nccl")
+    {"chains": run_chains, "construct-sharded": run_construct_sharded, "data-sharded": run_data_sharded}[args.mode](args, rk, real_stdout)
 
 
 if __name__ == "__main__":

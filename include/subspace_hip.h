@@ -118,6 +118,11 @@ int32_t si_construct_push_batch_dev(si_ctx* ctx, const void* w_dev, int32_t w_dt
 int32_t si_construct_gram(si_ctx* ctx);
 int32_t si_construct_gram_get(si_ctx* ctx, double* G_host /* K*K */, int64_t* K_out);
 int32_t si_construct_gram_set(si_ctx* ctx, const double* G_host /* K*K */);
+/* The same hook without the host: device address of G (K x K fp64, contiguous, valid until the next si_construct_gram /
+ * si_construct_begin).  A row-sharded construction all-reduces it IN PLACE over RCCL (stream-ordered after
+ * si_construct_gram when the caller runs the collective on the stream given to si_set_stream) and then calls
+ * si_construct_finish: no D2H / H2D of G, no extra synchronisation.                                                   */
+int32_t si_construct_gram_ptr(si_ctx* ctx, double** G_dev_out, int64_t* K_out);
 /* :61-65  A = reshape(A, N, :); U,s,V = psvd(A); P = U[:,1:M]*Diagonal(s[1:M])  ==  A*V[:,1:M].
  * Outputs may be NULL (results stay on the device for si_infer_setup).  s_out receives the M largest
  * singular values.  Column signs of P are fixed so that the entry of largest magnitude in each column
@@ -126,6 +131,11 @@ int32_t si_construct_gram_set(si_ctx* ctx, const double* G_host /* K*K */);
 int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out /* N */,
                             double* P_out /* N x M col-major */, double* s_out /* M */,
                             int64_t* K_out);
+/* Device addresses of the finished construction's results: W_swa (ld elements, rows [N, ld) zero) and P (ld x M
+ * column-major, ld = N rounded up to 64).  Valid until the next si_construct_begin / si_construct_finish / si_destroy.
+ * For device-to-device hand-over: an RCCL broadcast of (W_swa, P) to the other ranks' si_infer_setup_dev (independent
+ * chains, cfg3), or checks that must not stage 26 GB of P through the host (cfg5).                                  */
+int32_t si_construct_result_ptr(si_ctx* ctx, double** W_swa_dev_out, double** P_dev_out, int64_t* ld_out, int32_t* M_out);
 /* read back deviation columns [k0, k0+nk) (N x nk col-major) -- parity tests of :51-52 */
 int32_t si_construct_get_A(si_ctx* ctx, int64_t k0, int64_t nk, double* A_out);
 
@@ -137,6 +147,15 @@ int32_t si_infer_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
                        const double* W_swa, const double* P, const double* X, const double* Y,
                        int32_t in_dim, int32_t out_dim, int64_t B, double sigma_m,
                        int32_t compute_dtype);
+/* si_infer_setup with every array already on the DEVICE (fp64, column-major; P_dev has leading dimension ldP >= N).
+ * X_dev / Y_dev are copied device-to-device.  W_swa_dev / P_dev: both NULL = the ctx's finished construction;
+ * borrow = 0 copies them; borrow = 1 uses them IN PLACE -- the caller keeps them alive and unchanged until the next
+ * set-up or si_destroy, bases 16-byte aligned, ldP even and >= N + (N mod 2), W_swa_dev readable for N + (N mod 2)
+ * elements (the streaming kernels read rows in 16-byte pairs).  No host staging: at cfg5 P is 26 GB per rank.      */
+int32_t si_infer_setup_dev(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, int32_t M,
+                           const double* W_swa_dev, const double* P_dev, int64_t ldP, int32_t borrow,
+                           const double* X_dev, const double* Y_dev, int32_t in_dim, int32_t out_dim, int64_t B,
+                           double sigma_m, int32_t compute_dtype);
 /* :90-95  lp[c] = logpdf(MvNormal(vec(f_{W_swa+P z_c}(X)), sigma_m), vec(Y)),  Z is M x C          */
 int32_t si_logdensity(si_ctx* ctx, const double* Z, int32_t C, double* lp_out /* C */);
 /* lp and its gradient with respect to z: grad_out[m] = d lp / d z_m = (P' * d lp / d w)[m].
@@ -162,9 +181,15 @@ int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, 
  * ALL ranks (0 = this ctx's own B).  All ranks use the same seed / chain ids, hence take identical decisions.        */
 int32_t si_rwmh_begin(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0, int32_t nchains,
                       int64_t d_total);
-int32_t si_rwmh_step_eval(si_ctx* ctx, double* sse_local_out /* nchains */);
-int32_t si_rwmh_step_accept(si_ctx* ctx, const double* sse_total /* nchains */);
+int32_t si_rwmh_step_eval(si_ctx* ctx, double* sse_local_out /* nchains; NULL = leave them on the device */);
+int32_t si_rwmh_step_accept(si_ctx* ctx, const double* sse_total /* nchains; NULL = the device buffer holds them */);
+/* device address of the nchains partial sums between step_eval(NULL) and step_accept(NULL): the caller all-reduces it
+ * in place over RCCL on the stream given to si_set_stream -- no host round trip, no synchronisation per transition.  */
+int32_t si_rwmh_sse_ptr(si_ctx* ctx, double** sse_dev_out, int32_t* nchains_out);
 int32_t si_rwmh_end(si_ctx* ctx, double* Z_out, double* lp_out, double* accept_rate_out);
+/* drop an open session.  While a session is open, si_logdensity / _grad / si_forward / si_predict / si_sample_rwmh
+ * return SI_ERR_STATE (they share the session's proposal and SSE buffers); si_rwmh_begin restarts it.              */
+int32_t si_rwmh_abort(si_ctx* ctx);
 /* :91 / :125  W_out[:, c] = W_swa + P * Z[:, c]   (N x C col-major)                                  */
 int32_t si_reconstruct(si_ctx* ctx, const double* Z /* M x C */, int64_t C, double* W_out);
 

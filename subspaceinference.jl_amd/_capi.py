@@ -63,10 +63,15 @@ SIGNATURES = {
     "si_construct_gram": (c_int32, [c_void_p]),
     "si_construct_gram_get": (c_int32, [c_void_p, c_void_p, POINTER(c_int64)]),
     "si_construct_gram_set": (c_int32, [c_void_p, c_void_p]),
+    "si_construct_gram_ptr": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
+    "si_construct_result_ptr": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64),
+                                          POINTER(c_int32)]),
     "si_construct_finish": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, POINTER(c_int64)]),
     "si_construct_get_A": (c_int32, [c_void_p, c_int64, c_int64, c_void_p]),
     "si_infer_setup": (c_int32, [c_void_p, POINTER(SiLayer), c_int32, c_int64, c_int32, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_int32, c_int32, c_int64, c_double, c_int32]),
+    "si_infer_setup_dev": (c_int32, [c_void_p, POINTER(SiLayer), c_int32, c_int64, c_int32, c_void_p, c_void_p, c_int64,
+                                     c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_double, c_int32]),
     "si_logdensity": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "si_logdensity_grad": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "si_forward": (c_int32, [c_void_p, c_void_p, c_void_p]),
@@ -76,7 +81,9 @@ SIGNATURES = {
     "si_rwmh_begin": (c_int32, [c_void_p, c_int64, c_double, c_uint64, c_int32, c_int32, c_int64]),
     "si_rwmh_step_eval": (c_int32, [c_void_p, c_void_p]),
     "si_rwmh_step_accept": (c_int32, [c_void_p, c_void_p]),
+    "si_rwmh_sse_ptr": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_int32)]),
     "si_rwmh_end": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "si_rwmh_abort": (c_int32, [c_void_p]),
     "si_reconstruct": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "si_train_setup": (c_int32, [c_void_p, POINTER(SiLayer), c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_int32,
                                  c_int32, c_int64, c_int64, c_int32, c_double, c_double, c_double]),
@@ -122,6 +129,15 @@ def load():
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+def _layer_array(table):
+    """table rows: (in, out, act, w_off, b_off) for Dense, or full 6+-tuples handled by the layer helpers."""
+    arr = (SiLayer * len(table))()
+    for i, row in enumerate(table):
+        fin, fout, act, w_off, b_off = row[:5]
+        arr[i] = SiLayer(0, int(fin), int(fout), int(act), int(w_off), int(b_off))
+    return arr
 
 
 def _f64(a, order="F"):
@@ -232,6 +248,18 @@ class Context:
         g = _f64(g)
         self._check(self.lib.si_construct_gram_set(self.h, _ptr(g)))
 
+    def construct_gram_ptr(self):
+        """(device address, K) of the K x K fp64 Gram matrix, for an in-place RCCL all-reduce."""
+        ptr, k = c_void_p(), c_int64()
+        self._check(self.lib.si_construct_gram_ptr(self.h, byref(ptr), byref(k)))
+        return int(ptr.value), int(k.value)
+
+    def construct_result_ptr(self):
+        """(W_swa device address, P device address, ld, M) of the finished construction."""
+        ws, pp, ld, m = c_void_p(), c_void_p(), c_int64(), c_int32()
+        self._check(self.lib.si_construct_result_ptr(self.h, byref(ws), byref(pp), byref(ld), byref(m)))
+        return int(ws.value), int(pp.value), int(ld.value), int(m.value)
+
     def construct_finish(self, m, want_swa=True, want_p=True):
         k = c_int64()
         w_swa = np.empty(self._n, dtype=np.float64) if want_swa else None
@@ -325,6 +353,15 @@ class Context:
                                             _ptr(y), x.shape[0], y.shape[0], x.shape[1], float(sigma_m), SI_F64))
         self._m, self._in, self._out, self._b, self._ni = int(m), x.shape[0], y.shape[0], x.shape[1], int(n)
 
+    def infer_setup_dev(self, table, n, m, w_swa_ptr, p_ptr, ld_p, x_ptr, y_ptr, in_dim, out_dim, b, sigma_m, borrow=False):
+        """si_infer_setup with device addresses (ints); w_swa_ptr / p_ptr 0 or None => the finished construction."""
+        arr = _layer_array(table)
+        self._check(self.lib.si_infer_setup_dev(
+            self.h, arr, len(table), int(n), int(m), c_void_p(int(w_swa_ptr)) if w_swa_ptr else None,
+            c_void_p(int(p_ptr)) if p_ptr else None, int(ld_p), 1 if borrow else 0, c_void_p(int(x_ptr)), c_void_p(int(y_ptr)),
+            int(in_dim), int(out_dim), int(b), float(sigma_m), SI_F64))
+        self._m, self._in, self._out, self._b, self._ni = int(m), int(in_dim), int(out_dim), int(b), int(n)
+
     def logdensity(self, z):
         z = _f64(z)
         if z.ndim == 1:
@@ -374,14 +411,30 @@ class Context:
                                            int(d_total)))
         self._sw = (int(itr), int(nchains))
 
-    def rwmh_step_eval(self):
+    def rwmh_step_eval(self, on_device=False):
+        """on_device: leave the partial sums in the library's device buffer (rwmh_sse_ptr) -- no copy, no sync."""
+        if on_device:
+            self._check(self.lib.si_rwmh_step_eval(self.h, None))
+            return None
         sse = np.empty(self._sw[1], dtype=np.float64)
         self._check(self.lib.si_rwmh_step_eval(self.h, _ptr(sse)))
         return sse
 
-    def rwmh_step_accept(self, sse_total):
+    def rwmh_step_accept(self, sse_total=None):
+        """sse_total None: the device buffer already holds the totals (all-reduced in place)."""
+        if sse_total is None:
+            self._check(self.lib.si_rwmh_step_accept(self.h, None))
+            return
         sse_total = np.ascontiguousarray(sse_total, dtype=np.float64)
         self._check(self.lib.si_rwmh_step_accept(self.h, _ptr(sse_total)))
+
+    def rwmh_sse_ptr(self):
+        ptr, c = c_void_p(), c_int32()
+        self._check(self.lib.si_rwmh_sse_ptr(self.h, byref(ptr), byref(c)))
+        return int(ptr.value), int(c.value)
+
+    def rwmh_abort(self):
+        self._check(self.lib.si_rwmh_abort(self.h))
 
     def rwmh_end(self):
         itr, c = self._sw

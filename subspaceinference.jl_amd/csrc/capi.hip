@@ -419,6 +419,14 @@ int32_t si_construct_gram_get(si_ctx* ctx, double* G_host, int64_t* K_out) {
   return SI_OK;
 }
 
+int32_t si_construct_gram_ptr(si_ctx* ctx, double** G_dev_out, int64_t* K_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->gram_valid) return fail(ctx, SI_ERR_STATE, "si_construct_gram_ptr: call si_construct_gram first");
+  if (G_dev_out) *G_dev_out = ctx->d_G;
+  if (K_out) *K_out = ctx->K;
+  return SI_OK;
+}
+
 int32_t si_construct_gram_set(si_ctx* ctx, const double* G_host) {
   CHECK_CTX(ctx);
   if (!ctx->gram_valid || !G_host)
@@ -569,9 +577,13 @@ static bool alloc_forward(si_ctx* ctx, int slots) {
   return true;
 }
 
-int32_t si_infer_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, int32_t M, const double* W_swa,
-                       const double* P, const double* X, const double* Y, int32_t in_dim, int32_t out_dim,
-                       int64_t B, double sigma_m, int32_t compute_dtype) {
+// where the arrays of an inference set-up live: host (si_infer_setup), device copied (si_infer_setup_dev, borrow = 0),
+// device used in place (borrow = 1)
+enum SetupSrc { SRC_HOST = 0, SRC_DEV_COPY = 1, SRC_DEV_BORROW = 2 };
+
+static int32_t infer_setup_common(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, int32_t M, const double* W_swa,
+                                  const double* P, int64_t ldP_in, const double* X, const double* Y, int32_t in_dim,
+                                  int32_t out_dim, int64_t B, double sigma_m, int32_t compute_dtype, SetupSrc src) {
   CHECK_CTX(ctx);
   if (!layers || L <= 0 || N <= 0 || M <= 0 || !X || !Y || in_dim <= 0 || out_dim <= 0 || B <= 0)
     return fail(ctx, SI_ERR_INVALID, "si_infer_setup: bad argument");
@@ -613,19 +625,27 @@ int32_t si_infer_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
     ctx->i_P = ctx->d_P;
     ctx->ldP = ctx->ldA;
   } else {
-    ctx->ldP = pad_ld(N);
-    if (dev_alloc(&ctx->d_iswa, (size_t)ctx->ldP) != hipSuccess ||
-        dev_alloc(&ctx->d_iP, (size_t)ctx->ldP * M) != hipSuccess) {
-      free_infer(ctx);
-      return fail(ctx, SI_ERR_NOMEM, "si_infer_setup: allocation of W_swa / P failed");
+    if (src == SRC_DEV_BORROW) {
+      // used in place: the caller keeps both buffers alive (and unchanged) until the next set-up / si_destroy
+      ctx->ldP = ldP_in;
+      ctx->i_swa = W_swa;
+      ctx->i_P = P;
+    } else {
+      const hipMemcpyKind kind = src == SRC_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+      ctx->ldP = pad_ld(N);
+      if (dev_alloc(&ctx->d_iswa, (size_t)ctx->ldP) != hipSuccess ||
+          dev_alloc(&ctx->d_iP, (size_t)ctx->ldP * M) != hipSuccess) {
+        free_infer(ctx);
+        return fail(ctx, SI_ERR_NOMEM, "si_infer_setup: allocation of W_swa / P failed");
+      }
+      SI_HIP(ctx, hipMemsetAsync(ctx->d_iswa, 0, (size_t)ctx->ldP * sizeof(double), ctx->stream));
+      SI_HIP(ctx, hipMemsetAsync(ctx->d_iP, 0, (size_t)ctx->ldP * M * sizeof(double), ctx->stream));
+      SI_HIP(ctx, hipMemcpyAsync(ctx->d_iswa, W_swa, (size_t)N * sizeof(double), kind, ctx->stream));
+      SI_HIP(ctx, hipMemcpy2DAsync(ctx->d_iP, (size_t)ctx->ldP * sizeof(double), P, (size_t)ldP_in * sizeof(double),
+                                   (size_t)N * sizeof(double), (size_t)M, kind, ctx->stream));
+      ctx->i_swa = ctx->d_iswa;
+      ctx->i_P = ctx->d_iP;
     }
-    SI_HIP(ctx, hipMemsetAsync(ctx->d_iswa, 0, (size_t)ctx->ldP * sizeof(double), ctx->stream));
-    SI_HIP(ctx, hipMemsetAsync(ctx->d_iP, 0, (size_t)ctx->ldP * M * sizeof(double), ctx->stream));
-    SI_HIP(ctx, hipMemcpyAsync(ctx->d_iswa, W_swa, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    SI_HIP(ctx, hipMemcpy2DAsync(ctx->d_iP, (size_t)ctx->ldP * sizeof(double), P, (size_t)N * sizeof(double),
-                                 (size_t)N * sizeof(double), (size_t)M, hipMemcpyHostToDevice, ctx->stream));
-    ctx->i_swa = ctx->d_iswa;
-    ctx->i_P = ctx->d_iP;
   }
   ctx->layers.assign(layers, layers + L);
   ctx->iN = N;
@@ -648,10 +668,48 @@ int32_t si_infer_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
     free_infer(ctx);
     return fail(ctx, SI_ERR_NOMEM, "si_infer_setup: device allocation failed");
   }
-  SI_HIP(ctx, hipMemcpyAsync(ctx->d_X, X, (size_t)in_dim * B * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  SI_HIP(ctx, hipMemcpyAsync(ctx->d_Y, Y, (size_t)out_dim * B * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  {
+    const hipMemcpyKind kind = src == SRC_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    SI_HIP(ctx, hipMemcpyAsync(ctx->d_X, X, (size_t)in_dim * B * sizeof(double), kind, ctx->stream));
+    SI_HIP(ctx, hipMemcpyAsync(ctx->d_Y, Y, (size_t)out_dim * B * sizeof(double), kind, ctx->stream));
+  }
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->i_ready = true;
+  return SI_OK;
+}
+
+int32_t si_infer_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, int32_t M, const double* W_swa,
+                       const double* P, const double* X, const double* Y, int32_t in_dim, int32_t out_dim,
+                       int64_t B, double sigma_m, int32_t compute_dtype) {
+  return infer_setup_common(ctx, layers, L, N, M, W_swa, P, N, X, Y, in_dim, out_dim, B, sigma_m, compute_dtype, SRC_HOST);
+}
+
+int32_t si_infer_setup_dev(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, int32_t M, const double* W_swa_dev,
+                           const double* P_dev, int64_t ldP, int32_t borrow, const double* X_dev, const double* Y_dev,
+                           int32_t in_dim, int32_t out_dim, int64_t B, double sigma_m, int32_t compute_dtype) {
+  CHECK_CTX(ctx);
+  if (W_swa_dev && P_dev) {
+    if (ldP < N) return fail(ctx, SI_ERR_INVALID, "si_infer_setup_dev: ldP < N");
+    if (borrow) {
+      // the streaming kernels read rows in 16-byte pairs: row N of an odd-length column must exist and be aligned
+      if ((ldP & 1) || ldP < N + (N & 1) || (reinterpret_cast<uintptr_t>(P_dev) & 15u) ||
+          (reinterpret_cast<uintptr_t>(W_swa_dev) & 15u))
+        return fail(ctx, SI_ERR_INVALID,
+                    "si_infer_setup_dev: borrowed W_swa / P need 16-byte aligned bases, an even ldP >= N + (N mod 2) and "
+                    "N + (N mod 2) readable elements of W_swa");
+    }
+  }
+  return infer_setup_common(ctx, layers, L, N, M, W_swa_dev, P_dev, ldP, X_dev, Y_dev, in_dim, out_dim, B, sigma_m,
+                            compute_dtype, borrow ? SRC_DEV_BORROW : SRC_DEV_COPY);
+}
+
+int32_t si_construct_result_ptr(si_ctx* ctx, double** W_swa_dev_out, double** P_dev_out, int64_t* ld_out, int32_t* M_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->c_finished) return fail(ctx, SI_ERR_STATE, "si_construct_result_ptr: no finished construction");
+  if (W_swa_dev_out) *W_swa_dev_out = ctx->d_swa;
+  if (P_dev_out) *P_dev_out = ctx->d_P;
+  if (ld_out) *ld_out = ctx->ldA;
+  if (M_out) *M_out = ctx->M_built;
   return SI_OK;
 }
 
@@ -777,6 +835,7 @@ int32_t si_logdensity(si_ctx* ctx, const double* Z, int32_t C, double* lp_out) {
   CHECK_CTX(ctx);
   if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_logdensity: call si_infer_setup first");
   if (!Z || C <= 0 || !lp_out) return fail(ctx, SI_ERR_INVALID, "si_logdensity: bad argument");
+  if (ctx->sw_Z) return fail(ctx, SI_ERR_STATE, "si_logdensity: a step-wise RWMH session is open; its proposal / SSE buffers are shared (si_rwmh_end or si_rwmh_abort first)");
   BIND(ctx);
   int32_t rc = ensure_chains(ctx, C);
   if (rc != SI_OK) return rc;
@@ -827,6 +886,7 @@ int32_t si_logdensity_grad(si_ctx* ctx, const double* z, double* lp_out, double*
   CHECK_CTX(ctx);
   if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_logdensity_grad: call si_infer_setup first");
   if (!z || !lp_out || !grad_out) return fail(ctx, SI_ERR_INVALID, "si_logdensity_grad: bad argument");
+  if (ctx->sw_Z) return fail(ctx, SI_ERR_STATE, "si_logdensity_grad: a step-wise RWMH session is open; its proposal / SSE buffers are shared (si_rwmh_end or si_rwmh_abort first)");
   BIND(ctx);
   int32_t rc = ensure_chains(ctx, 1);
   if (rc != SI_OK) return rc;
@@ -920,6 +980,7 @@ int32_t si_forward(si_ctx* ctx, const double* z, double* Yhat_out) {
   CHECK_CTX(ctx);
   if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_forward: call si_infer_setup first");
   if (!z || !Yhat_out) return fail(ctx, SI_ERR_INVALID, "si_forward: bad argument");
+  if (ctx->sw_Z) return fail(ctx, SI_ERR_STATE, "si_forward: a step-wise RWMH session is open; its proposal / SSE buffers are shared (si_rwmh_end or si_rwmh_abort first)");
   BIND(ctx);
   int32_t rc = ensure_chains(ctx, 1);
   if (rc != SI_OK) return rc;
@@ -935,6 +996,7 @@ int32_t si_predict(si_ctx* ctx, const double* Z, int32_t C, const double* Xnew, 
   CHECK_CTX(ctx);
   if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_predict: call si_infer_setup first");
   if (!Z || C <= 0 || !Xnew || Bn <= 0 || !Yhat_out) return fail(ctx, SI_ERR_INVALID, "si_predict: bad argument");
+  if (ctx->sw_Z) return fail(ctx, SI_ERR_STATE, "si_predict: a step-wise RWMH session is open; its proposal / SSE buffers are shared (si_rwmh_end or si_rwmh_abort first)");
   BIND(ctx);
   int32_t rc = ensure_chains(ctx, C);
   if (rc != SI_OK) return rc;
@@ -995,6 +1057,7 @@ int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, 
   if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_sample_rwmh: call si_infer_setup first");
   if (itr <= 0 || nchains <= 0 || chain_id0 < 0 || !(sigma_z > 0.0))
     return fail(ctx, SI_ERR_INVALID, "si_sample_rwmh: itr, nchains, sigma_z must be positive");
+  if (ctx->sw_Z) return fail(ctx, SI_ERR_STATE, "si_sample_rwmh: a step-wise RWMH session is open; its proposal / SSE buffers are shared (si_rwmh_end or si_rwmh_abort first)");
   BIND(ctx);
   const int32_t C = nchains, M = ctx->iM;
   int32_t rc = ensure_chains(ctx, C);
@@ -1087,7 +1150,6 @@ int32_t si_rwmh_step_eval(si_ctx* ctx, double* sse_local_out) {
   CHECK_CTX(ctx);
   if (!ctx->sw_Z || ctx->sw_next >= ctx->sw_itr || ctx->sw_evaluated)
     return fail(ctx, SI_ERR_STATE, "si_rwmh_step_eval: call si_rwmh_begin first / accept the pending step / chain finished");
-  if (!sse_local_out) return fail(ctx, SI_ERR_INVALID, "si_rwmh_step_eval: NULL output");
   BIND(ctx);
   const int32_t C = ctx->sw_C;
   launch_rwmh_propose(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->iM, C, ctx->sw_sigma_z, ctx->sw_seed, ctx->sw_chain0,
@@ -1096,8 +1158,10 @@ int32_t si_rwmh_step_eval(si_ctx* ctx, double* sse_local_out) {
     const int32_t rc = eval_density_all(ctx, C);
     if (rc != SI_OK) return rc;
   }
-  SI_HIP(ctx, hipMemcpyAsync(sse_local_out, ctx->d_sse, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (sse_local_out) {  // NULL: the partial sums stay on the device (si_rwmh_sse_ptr) -- no copy, no synchronisation
+    SI_HIP(ctx, hipMemcpyAsync(sse_local_out, ctx->d_sse, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   ctx->sw_evaluated = true;
   return SI_OK;
 }
@@ -1105,17 +1169,37 @@ int32_t si_rwmh_step_eval(si_ctx* ctx, double* sse_local_out) {
 int32_t si_rwmh_step_accept(si_ctx* ctx, const double* sse_total) {
   CHECK_CTX(ctx);
   if (!ctx->sw_Z || !ctx->sw_evaluated) return fail(ctx, SI_ERR_STATE, "si_rwmh_step_accept: no evaluated step pending");
-  if (!sse_total) return fail(ctx, SI_ERR_INVALID, "si_rwmh_step_accept: NULL input");
   BIND(ctx);
   const int32_t C = ctx->sw_C;
-  SI_HIP(ctx, hipMemcpyAsync(ctx->d_sse, sse_total, (size_t)C * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));  // sse_total is caller-owned
+  if (sse_total) {  // NULL: the device buffer of si_rwmh_sse_ptr already holds the totals (all-reduced in place)
+    SI_HIP(ctx, hipMemcpyAsync(ctx->d_sse, sse_total, (size_t)C * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));  // sse_total is caller-owned
+  }
   const double c0 = mvnormal_c0(ctx->sw_d, ctx->sigma_m), s2 = ctx->sigma_m * ctx->sigma_m;
   launch_rwmh_accept(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->d_lpcur, ctx->d_sse, ctx->d_nacc, ctx->iM, C, c0, s2,
                      ctx->sw_seed, ctx->sw_chain0, ctx->d_steps, ctx->sw_Z, ctx->sw_lp, ctx->sw_itr);
   SI_HIP(ctx, hipGetLastError());
   ctx->sw_next += 1;
   ctx->sw_evaluated = false;
+  return SI_OK;
+}
+
+int32_t si_rwmh_sse_ptr(si_ctx* ctx, double** sse_dev_out, int32_t* nchains_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->sw_Z) return fail(ctx, SI_ERR_STATE, "si_rwmh_sse_ptr: call si_rwmh_begin first");
+  if (sse_dev_out) *sse_dev_out = ctx->d_sse;
+  if (nchains_out) *nchains_out = ctx->sw_C;
+  return SI_OK;
+}
+
+int32_t si_rwmh_abort(si_ctx* ctx) {
+  CHECK_CTX(ctx);
+  BIND(ctx);
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  dev_free(ctx->sw_Z);
+  dev_free(ctx->sw_lp);
+  ctx->sw_evaluated = false;
+  ctx->sw_next = ctx->sw_itr = 0;
   return SI_OK;
 }
 

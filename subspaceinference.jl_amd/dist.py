@@ -129,18 +129,143 @@ def allgather_rows(local, n_total):
     return full[:, 0] if local.ndim == 1 else np.asfortranarray(full)
 
 
+def _on_rccl():
+    d = _dist()
+    return d is not None and d.get_backend() == "nccl"
+
+
+_side_streams = {}
+
+
+def bind_stream(ctx):
+    """Under RCCL: run the library's kernels on a torch side stream (torch's default stream is the NULL stream, which
+    the library maps to its own) and return that stream.  Collectives issued inside `with torch.cuda.stream(s)` are then
+    stream-ordered with the kernels before and after them: no hipStreamSynchronize, no host staging around an in-place
+    all-reduce of a library buffer."""
+    import torch
+    dev = getattr(ctx, "device", 0)
+    s = _side_streams.get(dev)
+    if s is None:
+        s = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    if getattr(ctx, "_bound_stream", None) is not s:
+        ctx.set_stream(s.cuda_stream)
+        ctx._bound_stream = s
+    return s
+
+
+def _dev_view(ptr, shape, strides_elems=None):
+    """torch view of library-owned device memory (fp64).  shape / strides in elements, torch (row-major) index order."""
+    import torch
+    iface = {"shape": tuple(int(v) for v in shape), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+    if strides_elems is not None:
+        iface["strides"] = tuple(8 * int(v) for v in strides_elems)
+
+    class _Buf:
+        __cuda_array_interface__ = iface
+    return torch.as_tensor(_Buf(), device="cuda")
+
+
+def allreduce_inplace(ctx, ptr, n):
+    """all-reduce(sum) of n doubles at device address `ptr` (a buffer owned by `ctx`'s library) IN PLACE over RCCL,
+    stream-ordered on the stream the library runs on."""
+    import torch
+    d = _dist()
+    s = bind_stream(ctx)
+    with torch.cuda.stream(s):
+        d.all_reduce(_dev_view(ptr, (n,)), op=d.ReduceOp.SUM)
+
+
 def sharded_construct_finish(ctx, m, n_total=None, gather=True):
     """Row-sharded `U,s,V = psvd(A); P = U[:,1:M]*Diagonal(s[1:M])` (src/subspace_construction.jl:63,65).
 
     `ctx` holds this rank's row block (pushed with si_construct_push).  G = sum over ranks of the local A'A, the
-    eigensolve is replicated, P rows are local.  With gather=True the full W_swa / P are assembled on every rank."""
+    eigensolve is replicated, P rows are local.  With gather=True the full W_swa / P are assembled on every rank.
+
+    Under RCCL the K x K Gram matrix is all-reduced in place on the library's device buffer (si_construct_gram_ptr),
+    ordered on the library's stream: no D2H / H2D of G and no synchronisation of its own.  gloo (CPU tests) stages it
+    through the host."""
     ctx.construct_gram()
-    g = allreduce_sum(ctx.construct_gram_get())
-    ctx.construct_gram_set(g)
+    if _on_rccl():
+        ptr, k = ctx.construct_gram_ptr()
+        allreduce_inplace(ctx, ptr, k * k)
+    else:
+        ctx.construct_gram_set(allreduce_sum(ctx.construct_gram_get()))
     w_loc, p_loc, s, k = ctx.construct_finish(m)
     if not gather or n_total is None:
         return w_loc, p_loc, s, k
     return allgather_rows(w_loc, n_total), allgather_rows(p_loc, n_total), s, k
+
+
+def sharded_construct_finish_dev(ctx, m, n_total):
+    """The same, results kept on the DEVICE (RCCL only): every rank ends with torch tensors (W_swa [ld], P [M, ld]
+    = column-major ld x M, ld = n_total rounded up to 64, padding rows zero) assembled by ONE all-gather of the padded
+    row blocks -- what si_infer_setup_dev(borrow=1) takes.  Nothing crosses PCIe.  Returns (w_swa_t, p_t, ld, s)."""
+    import torch
+    d = _dist()
+    rank, ws = world()
+    ctx.construct_gram()
+    if d is not None:
+        ptr, k = ctx.construct_gram_ptr()
+        allreduce_inplace(ctx, ptr, k * k)
+    _, _, s, _ = ctx.construct_finish(m, want_swa=False, want_p=False)
+    wptr, pptr, ld_loc, _ = ctx.construct_result_ptr()
+    sizes = [row_shard(n_total, r, ws)[1] - row_shard(n_total, r, ws)[0] for r in range(ws)]
+    n_loc, mx = sizes[rank], max(sizes)
+    ld = (n_total + 63) // 64 * 64
+    st = bind_stream(ctx)
+    with torch.cuda.stream(st):
+        loc = torch.zeros((m + 1, mx), dtype=torch.float64, device="cuda")
+        loc[:m, :n_loc] = _dev_view(pptr, (m, n_loc), (ld_loc, 1))
+        loc[m, :n_loc] = _dev_view(wptr, (n_loc,))
+        if d is not None:
+            allg = torch.empty((ws, m + 1, mx), dtype=torch.float64, device="cuda")
+            d.all_gather_into_tensor(allg, loc)
+        else:
+            allg = loc[None]
+        p_t = torch.zeros((m, ld), dtype=torch.float64, device="cuda")
+        w_t = torch.zeros((ld,), dtype=torch.float64, device="cuda")
+        for r in range(ws):
+            r0, r1 = row_shard(n_total, r, ws)
+            p_t[:, r0:r1] = allg[r, :m, :r1 - r0]
+            w_t[r0:r1] = allg[r, m, :r1 - r0]
+        del allg, loc
+    return w_t, p_t, ld, s
+
+
+def replicate_subspace_dev(ctx, n, m, src=0):
+    """(W_swa, P) of the construction finished on rank `src` -> every rank, DEVICE TO DEVICE (cfg3: 168 MB at cfg2, once;
+    cfg5: 26 GB): the source broadcasts straight out of the library's buffers (si_construct_result_ptr), the others
+    receive into torch tensors that si_infer_setup_dev(borrow=1) then uses in place.  Returns (w_swa_t, p_t, ld)."""
+    import torch
+    d = _dist()
+    rank, _ = world()
+    ld = (n + 63) // 64 * 64
+    st = bind_stream(ctx)
+    with torch.cuda.stream(st):
+        if rank == src:
+            wptr, pptr, ld_src, m_src = ctx.construct_result_ptr()
+            assert ld_src == ld and m_src == m
+            w_t, p_t = _dev_view(wptr, (ld,)), _dev_view(pptr, (m, ld))
+        else:
+            w_t = torch.empty((ld,), dtype=torch.float64, device="cuda")
+            p_t = torch.empty((m, ld), dtype=torch.float64, device="cuda")
+        if d is not None:
+            d.broadcast(w_t, src=src)
+            d.broadcast(p_t, src=src)
+    return w_t, p_t, ld
+
+
+def infer_setup_from_tensors(ctx, table, n, m, w_t, p_t, ld, x_t, y_t, sigma_m):
+    """si_infer_setup_dev on torch tensors: W_swa / P used in place (kept alive on the ctx), X / Y copied D2D.
+    x_t is [B, in] row-major == in x B column-major (likewise y_t)."""
+    import torch
+    st = bind_stream(ctx)
+    st.synchronize()
+    torch.cuda.current_stream().synchronize()
+    ctx._borrowed = (w_t, p_t)
+    b = x_t.shape[0]
+    ctx.infer_setup_dev(table, n, m, w_t.data_ptr(), p_t.data_ptr(), ld, x_t.data_ptr(), y_t.data_ptr(),
+                        x_t.shape[1], y_t.shape[1], b, sigma_m, borrow=True)
 
 
 def col_shard(b, rank, world_size):
@@ -156,8 +281,21 @@ def sample_data_sharded(ctx, itr, sigma_z, seed, d_total, chain_id0=0, nchains=1
     sums of squared errors are all-reduced (8*nchains bytes) before the accept step; all ranks return the same chain.
     d_total = out_dim * (observations over all ranks)."""
     ctx.rwmh_begin(itr, sigma_z, seed, chain_id0, nchains, d_total)
-    for _ in range(itr):
-        ctx.rwmh_step_accept(allreduce_sum(ctx.rwmh_step_eval()))
+    if _on_rccl():
+        # the partial sums never leave the device: eval -> in-place RCCL all-reduce -> accept, all on one stream
+        import torch
+        d = _dist()
+        st = bind_stream(ctx)
+        ptr, c = ctx.rwmh_sse_ptr()
+        sse = _dev_view(ptr, (c,))
+        with torch.cuda.stream(st):
+            for _ in range(itr):
+                ctx.rwmh_step_eval(on_device=True)
+                d.all_reduce(sse, op=d.ReduceOp.SUM)
+                ctx.rwmh_step_accept(None)
+    else:
+        for _ in range(itr):
+            ctx.rwmh_step_accept(allreduce_sum(ctx.rwmh_step_eval()))
     return ctx.rwmh_end()
 
 
@@ -179,11 +317,8 @@ def train_step_data_parallel(ctx, idx_local, nb_total):
     sse = ctx.train_grad(idx_local, nb_total)
     if d is not None:
         if d.get_backend() == "nccl":
-            import torch
             ptr, n = ctx.train_grad_ptr()
-            g = torch.as_tensor(_DeviceBuffer(ptr, n), device="cuda")  # si_train_grad has synchronised the library's stream
-            d.all_reduce(g, op=d.ReduceOp.SUM)
-            torch.cuda.current_stream().synchronize()                 # RCCL ran on torch's stream
+            allreduce_inplace(ctx, ptr, n)  # ordered on the library's stream: si_train_apply follows without a host sync
         else:
             ctx.train_grad_set(allreduce_sum(ctx.train_grad_get()))
         sse = float(allreduce_sum(np.array([sse]))[0])

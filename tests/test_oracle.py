@@ -132,3 +132,19 @@ def test_golden_vectors_match_oracle():
     z, lp, w, nacc = so.sub_inference(table, d["X"], d["Y"], d["W_swa"], d["P"], 1.0, 1.0, 10, seed=1234)
     assert np.allclose(z, d["Z_chain"], rtol=1e-12) and np.allclose(lp, d["lp_chain"], rtol=1e-12)
     assert nacc == int(d["nacc"])
+
+
+def test_c_port_equals_numpy_port():
+    """oracle/subspace_oracle_c.c (the compiled CPU-baseline leg of bench.py) against the NumPy restatement: forward and
+    log-density on ragged shapes (row / column edges of the 16x12 and 8x6 micro-kernels, out = 1 heads, every activation)."""
+    from oracle import c_port
+    rng = np.random.default_rng(4)
+    for dims, acts, b in [([10, 20, 20, 2], [0, 0, 0], 100), ([7, 33, 50, 3], [1, 2, 3], 211), ([5, 17, 1], [2, 0], 13),
+                          ([128, 96, 64, 1], [1, 1, 0], 1000)]:
+        table, n = so.layer_table(dims, acts)
+        w = 0.2 * rng.standard_normal(n)
+        p = 0.05 * rng.standard_normal((n, 4))
+        x, y, z = rng.standard_normal((dims[0], b)), rng.standard_normal((dims[-1], b)), rng.standard_normal(4)
+        for threads in (1, 0):
+            assert np.allclose(c_port.forward(table, w + p @ z, x, threads), so.forward(table, w + p @ z, x), rtol=1e-12, atol=1e-13)
+            assert np.isclose(c_port.logdensity(table, w, p, x, y, 0.8, z, threads), so.logdensity(table, w, p, x, y, 0.8, z), rtol=1e-12)
