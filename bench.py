@@ -172,7 +172,8 @@ def cpu_baseline(table, w_swa, p, x, y, z0, budget_s):
     lp0 = None
     try:
         from oracle import c_port
-        cores = c_port.max_threads()
+        cores = c_port.max_threads()     # affinity mask capped by the cgroup CPU quota (oracle/c_port.py cpu_budget)
+        out["cpu_budget"] = {"usable_cpus": c_port.cpu_budget()[0], "cgroup_quota_cpus": c_port.cpu_budget()[1]}
         lpc = c_port.logdensity(table, w_swa, p, x, y, SIGMA_M, z0, threads=cores)   # warm-up + parity
         t0 = time.perf_counter()
         n = 0
@@ -198,6 +199,15 @@ def cpu_baseline(table, w_swa, p, x, y, z0, budget_s):
                                  if i.get("user_api") == "blas"})) or blas
     except Exception:
         pass
+    limiter = None
+    try:  # OpenBLAS would start one thread per logical CPU it sees; keep it within what the container may use
+        from threadpoolctl import threadpool_limits
+        from oracle import c_port as _cp
+        if _cp.cpu_budget()[0] < threads:
+            threads = _cp.cpu_budget()[0]
+            limiter = threadpool_limits(limits=threads)
+    except Exception:
+        pass
     t0 = time.perf_counter()
     lpn = so.logdensity(table, w_swa, p, x, y, SIGMA_M, z0)
     t1 = time.perf_counter() - t0
@@ -206,6 +216,8 @@ def cpu_baseline(table, w_swa, p, x, y, z0, budget_s):
     for _ in range(n):
         so.logdensity(table, w_swa, p, x, y, SIGMA_M, z0 + SIGMA_Z * rng.standard_normal(M))
     dt = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits()
     legs["numpy_openblas"] = {"value": n / dt, "threads": int(threads), "evaluations": n, "seconds": round(dt, 2), "blas": blas}
     if lp0 is None:
         lp0 = lpn

@@ -62,8 +62,31 @@ def isa():
     return {2: "avx512f", 1: "avx2+fma", 0: "scalar"}[load().so_isa()]
 
 
+def cpu_budget():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a container that sees 256
+    logical CPUs but is throttled to 16 runs SLOWER with 256 threads than with 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:          # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:                                                 # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def max_threads():
-    return int(load().so_max_threads())
+    return min(int(load().so_max_threads()), cpu_budget()[0])
 
 
 def forward(table, wflat, x, threads=0):

@@ -167,6 +167,26 @@ void so_reconstruct(const double* w_swa, const double* P, int64_t N, int32_t M, 
   }
 }
 
+/* workspace kept between calls (a fresh 768 MB malloc per evaluation costs more in page faults than the GEMM of a
+ * small layer; Julia's GC-managed temporaries would pay that too -- the baseline is meant to flatter the CPU) */
+static double* g_ws[4] = {NULL, NULL, NULL, NULL};
+static size_t g_ws_cap[4] = {0, 0, 0, 0};
+static double* ws_get(int slot, size_t elems) {
+  if (g_ws_cap[slot] < elems) {
+    free(g_ws[slot]);
+    g_ws[slot] = (double*)malloc(elems * sizeof(double));
+    g_ws_cap[slot] = g_ws[slot] ? elems : 0;
+  }
+  return g_ws[slot];
+}
+void so_release(void) {
+  for (int i = 0; i < 4; ++i) {
+    free(g_ws[i]);
+    g_ws[i] = NULL;
+    g_ws_cap[i] = 0;
+  }
+}
+
 /* forward of the whole chain on the flat weight vector; yhat_out is out_dim x B.  Returns 0, or -1 on allocation failure. */
 int so_forward(const so_layer* layers, int32_t L, const double* w, const double* X, int64_t B, double* yhat_out, int threads) {
   if (threads <= 0) threads = omp_get_num_procs();
@@ -175,13 +195,9 @@ int so_forward(const so_layer* layers, int32_t L, const double* w, const double*
     if (layers[l].out > maxw) maxw = layers[l].out;
   double* buf[2] = {NULL, NULL};
   if (L > 1) {
-    buf[0] = (double*)malloc((size_t)maxw * B * sizeof(double));
-    buf[1] = L > 2 ? (double*)malloc((size_t)maxw * B * sizeof(double)) : NULL;
-    if (!buf[0] || (L > 2 && !buf[1])) {
-      free(buf[0]);
-      free(buf[1]);
-      return -1;
-    }
+    buf[0] = ws_get(0, (size_t)maxw * B);
+    buf[1] = L > 2 ? ws_get(1, (size_t)maxw * B) : NULL;
+    if (!buf[0] || (L > 2 && !buf[1])) return -1;
   }
   const double* h = X;
   for (int l = 0; l < L; ++l) {
@@ -189,8 +205,6 @@ int so_forward(const so_layer* layers, int32_t L, const double* w, const double*
     dense_forward(w + layers[l].w_off, w + layers[l].b_off, h, o, layers[l].out, layers[l].in, B, layers[l].act, threads);
     h = o;
   }
-  free(buf[0]);
-  free(buf[1]);
   return 0;
 }
 
@@ -199,13 +213,9 @@ int so_logdensity(const so_layer* layers, int32_t L, int64_t N, int32_t M, const
                   const double* X, const double* Y, int32_t out_dim, int64_t B, double sigma_m, const double* z,
                   double* lp_out, int threads) {
   if (threads <= 0) threads = omp_get_num_procs();
-  double* w = (double*)malloc((size_t)N * sizeof(double));
-  double* yhat = (double*)malloc((size_t)out_dim * B * sizeof(double));
-  if (!w || !yhat) {
-    free(w);
-    free(yhat);
-    return -1;
-  }
+  double* w = ws_get(2, (size_t)N);
+  double* yhat = ws_get(3, (size_t)out_dim * B);
+  if (!w || !yhat) return -1;
   so_reconstruct(w_swa, P, N, M, z, w, threads);
   int rc = so_forward(layers, L, w, X, B, yhat, threads);
   if (rc == 0) {
@@ -220,7 +230,5 @@ int so_logdensity(const so_layer* layers, int32_t L, int64_t N, int32_t M, const
     const double c0 = -((double)d * log(2.0 * M_PI) + (double)d * log(sigma_m * sigma_m)) / 2.0;
     *lp_out = c0 - (sse / (sigma_m * sigma_m)) / 2.0;
   }
-  free(w);
-  free(yhat);
   return rc;
 }

@@ -1,26 +1,49 @@
 # SubspaceInferenceHIP.jl -- the `ccall` side of the drop-in boundary (include/subspace_hip.h).
 #
 # NOT EXECUTED IN THIS REPOSITORY'S CI: Julia is absent from the build image and from the GPU boxes, so this file is
-# the binding a maintainer of efmanu/SubspaceInference.jl would add (INTEGRATION.md); every executable test goes
-# through the Python ctypes binding (_capi.py) over the IDENTICAL C ABI.
+# the binding a maintainer of efmanu/SubspaceInference.jl would add (INTEGRATION.md).  What CAN be checked without
+# Julia is checked: tests/test_julia_binding.py parses every `ccall((:si_..., LIB), ret, (argtypes...), ...)` below and
+# every prototype of include/subspace_hip.h and asserts symbol, arity and type-by-type agreement (Int32 <-> int32_t,
+# Ptr{Float64} <-> double*, ...), the SiLayer field layout against `si_layer`, and that the exported names and keyword
+# defaults are the reference's.  Every executable test goes through the Python ctypes binding (_capi.py) over the
+# IDENTICAL C ABI.
 #
 # It keeps the reference's exported names and keyword arguments (src/SubspaceInference.jl:27-34):
 #   subspace_construction(model, cost, data, opt; T, c, M, print_freq)              -> W_swa, P
 #   subspace_inference(model, cost, data, opt; σ_z, σ_m, σ_p, itr, T, c, M, ...)      -> chn, lp, W_swa
 #   sub_inference(in_model, data, W_swa, P; σ_z, σ_m, σ_p, itr, M, alg, backend)      -> chn, lp
 #   inference(...)  (README.md:153-154 name), alg = :mh ≡ :rwmh
-# The gradient / optimiser step (src/subspace_construction.jl:39-43) stays in Julia (Zygote + Flux): an arbitrary
-# `cost` closure and optimiser cannot cross a C ABI.  Everything after `extract_params` runs on the GPU.
+#
+# What runs where:
+#   * src/subspace_construction.jl:45-52,61-65 (SWA update, deviation, append, psvd, P)        -> GPU, always
+#   * src/subspace_construction.jl:39-43 (gradient + Flux.update!)                               -> Julia (Zygote + Flux)
+#       by default: an arbitrary `cost` closure and optimiser cannot cross a C ABI;
+#       with device_training = true (the caller asserts cost(m, x, y) == Flux.Losses.mse(m(x), y) and opt is a fresh
+#       Descent / Momentum / ADAM)                                                                -> GPU (si_train_*)
+#   * src/space_inference.jl:90-95 `density(z)` and :107 `ℓπ_grad(θ)`                          -> GPU (si_logdensity,
+#       si_logdensity_grad: ONE reverse sweep instead of M-wide ForwardDiff duals; `backend` is accepted and unused)
+#   * :rwmh / :mh sampler loop (:111-116)                                                        -> GPU (si_sample_rwmh)
+#   * :mala / :hmc / :nuts sampler logic (:117-120, :139-160)                                    -> the reference's own
+#       AdvancedMH / AdvancedHMC calls, unchanged, driven by the two device callbacks above
+#   * output map :125                                                                            -> GPU (si_reconstruct)
 module SubspaceInferenceHIP
 
-using Flux, Zygote
-export subspace_construction, subspace_inference, sub_inference, inference
+using Flux, Zygote, Random
+using Distributions: MvNormal
+using AdvancedMH, AdvancedHMC
+export subspace_construction, subspace_inference, sub_inference, inference, predict
 
 const LIB = get(ENV, "SUBSPACE_HIP_LIB", joinpath(@__DIR__, "..", "libsubspace_hip.so"))
 const SI_F32, SI_F64 = Int32(0), Int32(1)
 
+# mirrors `si_layer` (include/subspace_hip.h) field by field
 struct SiLayer
-    kind::Int32; in::Int32; out::Int32; act::Int32; w_off::Int64; b_off::Int64
+    kind::Int32
+    in::Int32
+    out::Int32
+    act::Int32
+    w_off::Int64
+    b_off::Int64
 end
 
 mutable struct Ctx
@@ -61,29 +84,89 @@ function layer_table(model)
     return tbl, off
 end
 
+# ---- on-device training step (SURVEY 8 f1): src/subspace_construction.jl:39-43 for cost = mse ----------------------
+# (kind, η, p1, p2) of a fresh Flux 0.11.2 optimiser [upstream field names: Descent.eta; Momentum.eta/.rho; ADAM.eta/.beta]
+function device_optimiser(opt)
+    opt isa Descent && return (Int32(0), Float64(opt.eta), 0.0, 0.0)
+    opt isa Momentum && isempty(opt.velocity) && return (Int32(1), Float64(opt.eta), Float64(opt.rho), 0.0)
+    opt isa ADAM && isempty(opt.state) && return (Int32(2), Float64(opt.eta), Float64(opt.beta[1]), Float64(opt.beta[2]))
+    throw("Error: device_training needs a fresh Descent / Momentum / ADAM optimiser")
+end
+
+# the observation indices of every batch of one epoch, as the DataLoader would deliver them
+# [upstream Flux 0.11.2 DataLoader: fields data, batchsize, nobs, partial, imax, indices, shuffle; shuffle!(indices) at i == 0]
+function index_batches(d)
+    d.shuffle && shuffle!(d.indices)
+    out = Vector{Vector{Int64}}()
+    i = 0
+    while i < d.imax
+        nexti = min(i + d.batchsize, d.nobs)
+        push!(out, Int64.(d.indices[i+1:nexti]) .- 1)        # 0-based for the C ABI
+        i += d.batchsize
+    end
+    return out
+end
+
+function train_on_device!(ctx::Ctx, model, data, opt, T, c, print_freq)
+    tbl, N = layer_table(model)
+    kind, η, p1, p2 = device_optimiser(opt)
+    ps = Flux.params(model)
+    w0 = Float32.(extract_params(ps))
+    X, Y = Float64.(data.data[1]), Float64.(data.data[2])
+    GC.@preserve tbl w0 X Y check(ctx, ccall((:si_train_setup, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{SiLayer}, Int32, Int64, Ptr{Float32}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Int64, Int64,
+         Int32, Float64, Float64, Float64),
+        ctx.h, tbl, length(tbl), N, w0, X, Y, size(X, 1), size(Y, 1), size(X, 2), min(data.batchsize, data.nobs),
+        kind, η, p1, p2))
+    loss = Ref{Float64}(0.0)
+    for i in 1:T
+        for ids in index_batches(data)
+            GC.@preserve ids check(ctx, ccall((:si_train_step, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int64, Ref{Float64}),
+                                              ctx.h, ids, length(ids), loss))
+            # :45-52 with W read in place from the device-resident Float32 weights (no extract_params, no PCIe)
+            mod(i, c) == 0 && check(ctx, ccall((:si_train_push, LIB), Int32, (Ptr{Cvoid}, Float64), ctx.h, i / c))
+        end
+        if (mod(i, print_freq) == 0) || (i == T)
+            println("Traing loss: ", loss[], " Epoch: ", i)
+        end
+    end
+    # Flux.update! works in place: hand the trained weights back to the model's arrays
+    w = Vector{Float32}(undef, N)
+    GC.@preserve w check(ctx, ccall((:si_train_get_weights, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}), ctx.h, w))
+    off = 0
+    for p in ps
+        copyto!(p, reshape(view(w, off+1:off+length(p)), size(p)))
+        off += length(p)
+    end
+end
+
 function subspace_construction(model, cost, data, opt; T = 10, c = 1, M = 3, print_freq = 1, device = 0,
-                               ctx = Ctx(device), max_cols = 0, keep_on_device = false)
+                               ctx = Ctx(device), max_cols = 0, keep_on_device = false, device_training = false)
     training_loss = 0.0
     ps = Flux.params(model)
     N = sum(length, ps)
     npush = count(i -> mod(i, c) == 0, 1:T) * length(data)
     check(ctx, ccall((:si_construct_begin, LIB), Int32, (Ptr{Cvoid}, Int64, Int64, Int32), ctx.h, N, npush, max_cols))
-    for i in 1:T
-        for d in data
-            gs = gradient(ps) do
-                training_loss = cost(model, d...)
-                return training_loss
+    if device_training
+        train_on_device!(ctx, model, data, opt, T, c, print_freq)
+    else
+        for i in 1:T
+            for d in data
+                gs = gradient(ps) do
+                    training_loss = cost(model, d...)
+                    return training_loss
+                end
+                Flux.update!(opt, ps, gs)
+                if mod(i, c) == 0
+                    W = extract_params(ps)                      # Float32 for Flux's default init
+                    dt = eltype(W) == Float32 ? SI_F32 : SI_F64
+                    GC.@preserve W check(ctx, ccall((:si_construct_push, LIB), Int32,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float64), ctx.h, pointer(W), dt, i / c))
+                end
             end
-            Flux.update!(opt, ps, gs)
-            if mod(i, c) == 0
-                W = extract_params(ps)                      # Float32 for Flux's default init
-                dt = eltype(W) == Float32 ? SI_F32 : SI_F64
-                GC.@preserve W check(ctx, ccall((:si_construct_push, LIB), Int32,
-                    (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float64), ctx.h, pointer(W), dt, i / c))
+            if (mod(i, print_freq) == 0) || (i == T)
+                println("Traing loss: ", training_loss, " Epoch: ", i)
             end
-        end
-        if (mod(i, print_freq) == 0) || (i == T)
-            println("Traing loss: ", training_loss, " Epoch: ", i)
         end
     end
     W_swa = Vector{Float64}(undef, N)
@@ -95,9 +178,43 @@ function subspace_construction(model, cost, data, opt; T = 10, c = 1, M = 3, pri
     return W_swa, P
 end
 
+# ---- the two device callbacks every sampler of sub_inference is driven by ------------------------------------------
+# src/space_inference.jl:90-95  density(z)
+function logdensity(ctx::Ctx, z::AbstractVector{<:Real})
+    zz = Vector{Float64}(z); lp = Ref{Float64}(0.0)
+    GC.@preserve zz check(ctx, ccall((:si_logdensity, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int32, Ref{Float64}),
+                                     ctx.h, zz, 1, lp))
+    return lp[]
+end
+
+# src/space_inference.jl:107  ℓπ_grad(θ) = (density(θ), gradient(density, θ))
+function logdensity_grad(ctx::Ctx, z::AbstractVector{<:Real})
+    zz = Vector{Float64}(z); lp = Ref{Float64}(0.0); g = Vector{Float64}(undef, length(zz))
+    GC.@preserve zz g check(ctx, ccall((:si_logdensity_grad, LIB), Int32,
+                                       (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}, Ptr{Float64}), ctx.h, zz, lp, g))
+    return lp[], g
+end
+
+# callable handed to AdvancedMH's DensityModel; MALA asks the model for value + gradient through
+# AdvancedMH.logdensity_and_gradient, which defaults to ForwardDiff on the closure [upstream AdvancedMH 0.6.2 src/MALA.jl]
+# -- dual numbers cannot enter a ccall, so the device gradient is plugged in at that hook.
+struct DeviceDensity <: Function
+    ctx::Ctx
+end
+(d::DeviceDensity)(z) = logdensity(d.ctx, z)
+AdvancedMH.logdensity_and_gradient(m::DensityModel{DeviceDensity}, θ) = logdensity_grad(m.logdensity.ctx, θ)
+
+function reconstruct(ctx::Ctx, Z::Matrix{Float64}, N)
+    Wm = Matrix{Float64}(undef, N, size(Z, 2))                      # :125 map(z -> W_swa + P*z.params, chm)
+    GC.@preserve Z Wm check(ctx, ccall((:si_reconstruct, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}), ctx.h, Z, size(Z, 2), Wm))
+    return [Wm[:, t] for t in 1:size(Z, 2)]
+end
+
 function sub_inference(in_model, data, W_swa, P; σ_z = 1.0, σ_m = 1.0, σ_p = 1.0, itr = 100, M = 3, alg = :rwmh,
                        backend = :forwarddiff, device = 0, ctx = Ctx(device), seed = 0, chain_id = 0)
-    (alg == :rwmh || alg == :mh) || throw("$alg is not available")
+    alg == :mh && (alg = :rwmh)                                     # README.md:153-154
+    alg in (:rwmh, :mala, :hmc, :nuts) || throw("$alg is not available")       # :162 (:advi is outside this build)
     in_model isa Chain || throw("Error: density function is not avaliable for this model")
     X, Y = Float64.(data.data[1]), Float64.(data.data[2])          # split_data (src/libs.jl:75-77)
     tbl, N = layer_table(in_model)
@@ -107,24 +224,54 @@ function sub_inference(in_model, data, W_swa, P; σ_z = 1.0, σ_m = 1.0, σ_p = 
         (Ptr{Cvoid}, Ptr{SiLayer}, Int32, Int64, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
          Int32, Int32, Int64, Float64, Int32),
         ctx.h, tbl, length(tbl), N, M, Wp, Pp, X, Y, size(X, 1), size(Y, 1), size(X, 2), σ_m, SI_F64))
-    Z = Matrix{Float64}(undef, M, itr); lp = Vector{Float64}(undef, itr); acc = Ref{Float64}(0.0)
-    GC.@preserve Z lp check(ctx, ccall((:si_sample_rwmh, LIB), Int32,
-        (Ptr{Cvoid}, Int64, Float64, UInt64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
-        ctx.h, itr, σ_z, seed, chain_id, 1, Z, lp, acc))
-    Wm = Matrix{Float64}(undef, N, itr)                             # :125 map(z -> W_swa + P*z.params, chm)
-    GC.@preserve Z Wm check(ctx, ccall((:si_reconstruct, LIB), Int32,
-        (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}), ctx.h, Z, itr, Wm))
-    return [Wm[:, t] for t in 1:itr], lp
+    if alg == :rwmh
+        # :111-116 on the device: chain state, proposals (Philox) and accept decisions never leave the GPU
+        Z = Matrix{Float64}(undef, M, itr); lp = Vector{Float64}(undef, itr); acc = Ref{Float64}(0.0)
+        GC.@preserve Z lp check(ctx, ccall((:si_sample_rwmh, LIB), Int32,
+            (Ptr{Cvoid}, Int64, Float64, UInt64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+            ctx.h, itr, σ_z, seed, chain_id, 1, Z, lp, acc))
+        return reconstruct(ctx, Z, N), lp
+    end
+    density = DeviceDensity(ctx)
+    ℓπ_grad(θ) = logdensity_grad(ctx, θ)
+    if alg == :mala
+        # :117-120, the reference's own AdvancedMH calls
+        spl = MALA(x -> MvNormal((σ_z^2 / 2) .* x, σ_z))
+        chm = sample(DensityModel(density), spl, itr; init_params = rand(MvNormal(zeros(M), σ_z)))
+        Z = reduce(hcat, [Vector{Float64}(t.params) for t in chm])
+        return reconstruct(ctx, Z, N), map(t -> t.lp, chm)
+    end
+    # :139-160, the reference's own AdvancedHMC calls
+    initial_θ = rand(MvNormal(zeros(M), σ_z))
+    n_samples, n_adapts = itr, Int(round(itr / 2))
+    metric = DiagEuclideanMetric(M)
+    hamiltonian = Hamiltonian(metric, density, ℓπ_grad)
+    integrator = Leapfrog(find_good_stepsize(hamiltonian, initial_θ))
+    proposal = alg == :hmc ? AdvancedHMC.StaticTrajectory(integrator, 1) :
+                             AdvancedHMC.NUTS{MultinomialTS,GeneralisedNoUTurn}(integrator)
+    adaptor = StanHMCAdaptor(MassMatrixAdaptor(metric), StepSizeAdaptor(0.8, integrator))
+    samples, stats = sample(hamiltonian, proposal, initial_θ, n_samples, adaptor, n_adapts; progress = true)
+    return reconstruct(ctx, reduce(hcat, samples), N), map(s -> s.log_density, stats)
 end
 
 inference(args...; kwargs...) = sub_inference(args...; kwargs...)
 
+# posterior predictive on new inputs without materialising weight samples (SURVEY 8 f3): what the reference's users
+# compute as `re(chn[i])(x)` per sample (docs/src/nn_example.md:207-217).  Z is M x C, Xnew is in x Bn.
+function predict(ctx::Ctx, Z::Matrix{Float64}, Xnew::Matrix{Float64}, out_dim::Integer)
+    Yh = Array{Float64}(undef, out_dim, size(Xnew, 2), size(Z, 2))
+    GC.@preserve Z Xnew Yh check(ctx, ccall((:si_predict, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Int64, Ptr{Float64}), ctx.h, Z, size(Z, 2), Xnew, size(Xnew, 2), Yh))
+    return Yh
+end
+
 function subspace_inference(model, cost, data, opt; σ_z = 1.0, σ_m = 1.0, σ_p = 1.0, itr = 1000, T = 25, c = 1, M = 20,
-                            print_freq = 1, alg = :rwmh, backend = :forwarddiff, method = :subspace, device = 0)
+                            print_freq = 1, alg = :rwmh, backend = :forwarddiff, method = :subspace, device = 0,
+                            device_training = false)
     method == :subspace || throw("Error: No method found")
     ctx = Ctx(device)
     W_swa, _ = subspace_construction(model, cost, data, opt; T = T, c = c, M = M, print_freq = print_freq, ctx = ctx,
-                                     keep_on_device = true)
+                                     keep_on_device = true, device_training = device_training)
     chn, lp = sub_inference(model, data, nothing, nothing; σ_z = σ_z, σ_m = σ_m, σ_p = σ_p, itr = itr, M = M,
                             alg = alg, backend = backend, ctx = ctx)   # W_swa / P taken in place on the device
     return chn, lp, W_swa

@@ -1,0 +1,130 @@
+"""The Julia half of the drop-in boundary cannot be executed here (no Julia in the image), so it is checked as TEXT
+against the C header: every `ccall((:si_x, LIB), Ret, (ArgTypes...), ...)` in julia/SubspaceInferenceHIP.jl must name a
+function include/subspace_hip.h declares, with the same arity and, argument by argument, a Julia type that is
+ABI-compatible with the C type; `SiLayer` must mirror `si_layer`; the exported names and keyword defaults must be the
+reference's (src/SubspaceInference.jl:27-34; src/subspace_construction.jl:26; src/space_inference.jl:33-35,82-84)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "subspace_hip.h")
+JL = os.path.join(ROOT, "subspaceinference.jl_amd", "julia", "SubspaceInferenceHIP.jl")
+
+# C type (normalised: no `const`, no parameter name) -> Julia types a ccall may use for it
+COMPAT = {
+    "si_ctx*": {"Ptr{Cvoid}"},
+    "si_ctx**": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
+    "void*": {"Ptr{Cvoid}"},
+    "int32_t": {"Int32", "Cint"},
+    "int": {"Cint", "Int32"},
+    "int64_t": {"Int64"},
+    "uint64_t": {"UInt64"},
+    "uint32_t": {"UInt32"},
+    "double": {"Float64", "Cdouble"},
+    "double*": {"Ptr{Float64}", "Ref{Float64}"},
+    "double**": {"Ptr{Ptr{Float64}}", "Ref{Ptr{Float64}}"},
+    "float*": {"Ptr{Float32}", "Ref{Float32}"},
+    "int64_t*": {"Ptr{Int64}", "Ref{Int64}"},
+    "int32_t*": {"Ptr{Int32}", "Ref{Int32}"},
+    "si_layer*": {"Ptr{SiLayer}"},
+    "si_stats*": {"Ptr{SiStats}", "Ref{SiStats}"},
+    "char*": {"Ptr{UInt8}", "Cstring"},
+}
+RET = {"int32_t": {"Int32", "Cint"}, "int": {"Cint", "Int32"}, "const char*": {"Cstring", "Ptr{UInt8}"}}
+
+
+def _strip_comments(text):
+    return re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+
+
+def header_prototypes():
+    text = _strip_comments(open(HEADER).read())
+    protos = {}
+    for m in re.finditer(r"\b(int32_t|int|const char\s*\*)\s+(si_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        ret = re.sub(r"\s+", " ", m.group(1)).replace(" *", "*")
+        args = []
+        raw = m.group(3).strip()
+        if raw and raw != "void":
+            for a in raw.split(","):
+                a = re.sub(r"\bconst\b", " ", a)
+                a = re.sub(r"\s+", " ", a).strip()
+                stars = a.count("*")
+                base = re.match(r"([A-Za-z_]\w*)", a.replace("*", " ").strip()).group(1)
+                args.append(base + "*" * stars)
+        protos[m.group(2)] = (ret, args)
+    return protos
+
+
+def julia_ccalls():
+    text = "\n".join(ln.split("#")[0] if not ln.lstrip().startswith("#") else "" for ln in open(JL).read().splitlines())
+    calls = []
+    for m in re.finditer(r"ccall\(\(:(si_\w+),\s*LIB\),\s*([\w{}]+),\s*\(([^)]*)\)", text, flags=re.S):
+        args = [a.strip() for a in m.group(3).split(",") if a.strip()]
+        calls.append((m.group(1), m.group(2), args))
+    return calls
+
+
+def test_header_is_parsed_completely():
+    protos = header_prototypes()
+    import subspaceinference_jl_amd as si
+    assert set(protos) == set(si._capi.SIGNATURES), set(protos) ^ set(si._capi.SIGNATURES)
+    assert protos["si_create"] == ("int32_t", ["si_ctx**", "int32_t"])
+    assert protos["si_last_error"] == ("const char*", ["si_ctx*"])
+    assert protos["si_train_grad_ptr"] == ("int32_t", ["si_ctx*", "double**", "int64_t*"])
+
+
+def test_every_ccall_matches_the_header():
+    protos = header_prototypes()
+    calls = julia_ccalls()
+    assert len(calls) >= 15
+    for name, ret, args in calls:
+        assert name in protos, "%s is not declared in include/subspace_hip.h" % name
+        cret, cargs = protos[name]
+        assert ret in RET[cret], "%s: Julia return %s vs C %s" % (name, ret, cret)
+        assert len(args) == len(cargs), "%s: %d Julia argument types vs %d C parameters" % (name, len(args), len(cargs))
+        for i, (ja, ca) in enumerate(zip(args, cargs)):
+            assert ja in COMPAT[ca], "%s argument %d: Julia %s is not ABI-compatible with C %s" % (name, i, ja, ca)
+
+
+def test_the_wrapper_binds_the_whole_single_process_path():
+    bound = {c[0] for c in julia_ccalls()}
+    need = {"si_create", "si_destroy", "si_last_error", "si_construct_begin", "si_construct_push", "si_construct_finish",
+            "si_infer_setup", "si_logdensity", "si_logdensity_grad", "si_sample_rwmh", "si_reconstruct", "si_predict",
+            "si_train_setup", "si_train_step", "si_train_push", "si_train_get_weights"}
+    assert need <= bound, need - bound
+    # what is deliberately NOT bound from Julia: device-pointer / multi-GPU hooks (torch.distributed side), profiling, test read-backs
+    unbound = set(header_prototypes()) - bound
+    for name in unbound:
+        assert re.search(r"_dev$|_ptr$|gram|rwmh_|train_grad|train_apply|profiling|stats|stream|synchronize|version|device_name|"
+                         r"get_A|host_sym_eig|si_forward|push_batch", name), "unbound without a reason: " + name
+
+
+def test_silayer_mirrors_si_layer():
+    text = _strip_comments(open(HEADER).read())
+    body = re.search(r"typedef struct \{([^}]*)\}\s*si_layer;", text, flags=re.S).group(1)
+    cfields = [(t, n) for t, n in re.findall(r"(int32_t|int64_t)\s+(\w+)\s*;", body)]
+    jl = open(JL).read()
+    jbody = re.search(r"struct SiLayer\n(.*?)\nend", jl, flags=re.S).group(1)
+    jfields = [(n, t) for n, t in re.findall(r"(\w+)::(\w+)", jbody)]
+    assert [n for _, n in cfields] == [n for n, _ in jfields]
+    assert [{"int32_t": "Int32", "int64_t": "Int64"}[t] for t, _ in cfields] == [t for _, t in jfields]
+    import ctypes
+    import subspaceinference_jl_amd as si
+    assert ctypes.sizeof(si._capi.SiLayer) == sum(4 if t == "int32_t" else 8 for t, _ in cfields)  # no padding surprises
+
+
+def test_exported_names_and_keyword_defaults_are_the_references():
+    jl = open(JL).read()
+    assert re.search(r"export subspace_construction, subspace_inference, sub_inference, inference", jl)
+    sig = re.search(r"function subspace_construction\(model, cost, data, opt; (.*?)\)", jl, flags=re.S).group(1)
+    assert "T = 10, c = 1, M = 3, print_freq = 1" in sig                       # src/subspace_construction.jl:26
+    sig = re.search(r"function sub_inference\(in_model, data, W_swa, P; (.*?)\)", jl, flags=re.S).group(1)
+    assert "σ_z = 1.0, σ_m = 1.0, σ_p = 1.0, itr = 100, M = 3, alg = :rwmh" in sig and "backend = :forwarddiff" in sig
+    sig = re.search(r"function subspace_inference\(model, cost, data, opt; (.*?)\)", jl, flags=re.S).group(1)
+    assert "σ_z = 1.0, σ_m = 1.0, σ_p = 1.0, itr = 1000, T = 25, c = 1, M = 20" in sig   # src/space_inference.jl:33-35
+    assert "alg = :rwmh, backend = :forwarddiff, method = :subspace" in re.sub(r"\s+", " ", sig)
+    # :mala / :hmc / :nuts keep the reference's sampler calls, fed by the two device callbacks
+    for needle in ("MALA(x -> MvNormal((σ_z^2 / 2) .* x, σ_z))", "Hamiltonian(metric, density, ℓπ_grad)",
+                   "StanHMCAdaptor(MassMatrixAdaptor(metric), StepSizeAdaptor(0.8, integrator))",
+                   "NUTS{MultinomialTS,GeneralisedNoUTurn}", "StaticTrajectory(integrator, 1)"):
+        assert needle in jl, needle
