@@ -123,11 +123,22 @@ int32_t si_construct_gram_set(si_ctx* ctx, const double* G_host /* K*K */);
  * si_construct_gram when the caller runs the collective on the stream given to si_set_stream) and then calls
  * si_construct_finish: no D2H / H2D of G, no extra synchronisation.                                                   */
 int32_t si_construct_gram_ptr(si_ctx* ctx, double** G_dev_out, int64_t* K_out);
+/* Ill-conditioned deviation matrices (s_M below ~3e-5 s_1, where A'A no longer resolves the trailing singular values;
+ * psvd at src/subspace_construction.jl:63 resolves them down to 5 eps): si_construct_finish switches by itself to a
+ * two-stage route -- B = A*V_full on the device, second Gram matrix G2 = B'B, scaled-criterion Jacobi on the host,
+ * P = B*W_M.  A ROW-SHARDED construction has to all-reduce G2 as well, so the stage is exposed:
+ *     si_construct_gram; all-reduce G;  si_construct_needs_refine(M, &flag)   -- same G => same flag on every rank
+ *     if flag:  si_construct_refine  (leaves G2 where G was: si_construct_gram_ptr / _get / _set now address G2);
+ *               all-reduce G2;
+ *     si_construct_finish(M, ...).
+ * After a refine, si_construct_gram_get returns G2 until the next si_construct_gram.                              */
+int32_t si_construct_needs_refine(si_ctx* ctx, int32_t M, int32_t* flag_out);
+int32_t si_construct_refine(si_ctx* ctx);
 /* :61-65  A = reshape(A, N, :); U,s,V = psvd(A); P = U[:,1:M]*Diagonal(s[1:M])  ==  A*V[:,1:M].
  * Outputs may be NULL (results stay on the device for si_infer_setup).  s_out receives the M largest
  * singular values.  Column signs of P are fixed so that the entry of largest magnitude in each column
  * of V is positive (deterministic; the reference's signs are arbitrary).  Returns SI_ERR_BOUNDS when M
- * exceeds the numerical rank of A -- the reference's BoundsError at U[:,1:M].                         */
+ * exceeds the numerical rank of A (s_M <= ~5 eps s_1, psvd's rtol) -- the reference's BoundsError at U[:,1:M]. */
 int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out /* N */,
                             double* P_out /* N x M col-major */, double* s_out /* M */,
                             int64_t* K_out);
@@ -207,6 +218,11 @@ int32_t si_train_step(si_ctx* ctx, const int64_t* idx /* nb observation indices,
 /* :45-52 with W taken in place from the device-resident Float32 weights (no extract_params, no PCIe) */
 int32_t si_train_push(si_ctx* ctx, double n);
 int32_t si_train_get_weights(si_ctx* ctx, float* w_out /* N */);
+/* the optimiser state after the device steps, so that the caller's `opt` can be left as Flux.update! leaves it (its
+ * IdDict state persists across calls in the reference): m_out = Momentum velocity / ADAM first moment, v_out = ADAM
+ * second moment (both Float32, flat layout of the weights; either may be NULL), beta_pows_out[2] = ADAM's running
+ * beta1^t, beta2^t.                                                                                                 */
+int32_t si_train_get_opt_state(si_ctx* ctx, float* m_out /* N */, float* v_out /* N */, double* beta_pows_out /* 2 */);
 /* Data-parallel form of si_train_step (one gradient all-reduce per step).  Every rank holds the same
  * weights / optimiser state and its own nb of the nb_total observations of the batch:
  *   si_train_grad   forward + reverse sweep; leaves  d mse(whole batch)/dw  restricted to this rank's observations
@@ -229,6 +245,10 @@ int si_host_sym_eig(int n, double* a, double* w);
  * g: n x n symmetric column-major, left intact; w_top: m eigenvalues DESCENDING; V: n x m eigenvectors.
  * Returns 0 = verified result, 1 = declined / failed verification (si_construct_finish then uses si_host_sym_eig). */
 int si_host_sym_eig_top(int n, const double* g, int m, double* w_top, double* V);
+/* The second-stage solver of the ill-conditioned route: cyclic two-sided Jacobi with the scaled stopping criterion
+ * |a_pq| <= eps*sqrt(a_pp*a_qq) for a symmetric positive semi-definite matrix (eigenvalues accurate relative to
+ * themselves for graded matrices).  a: n x n column-major, destroyed; w: eigenvalues DESCENDING; v: eigenvectors.   */
+int si_host_jacobi_eig_psd(int n, double* a, double* w, double* v);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,8 @@ SIGNATURES = {
     "si_construct_gram_ptr": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
     "si_construct_result_ptr": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64),
                                           POINTER(c_int32)]),
+    "si_construct_needs_refine": (c_int32, [c_void_p, c_int32, POINTER(c_int32)]),
+    "si_construct_refine": (c_int32, [c_void_p]),
     "si_construct_finish": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, POINTER(c_int64)]),
     "si_construct_get_A": (c_int32, [c_void_p, c_int64, c_int64, c_void_p]),
     "si_infer_setup": (c_int32, [c_void_p, POINTER(SiLayer), c_int32, c_int64, c_int32, c_void_p, c_void_p,
@@ -90,6 +92,7 @@ SIGNATURES = {
     "si_train_step": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "si_train_push": (c_int32, [c_void_p, c_double]),
     "si_train_get_weights": (c_int32, [c_void_p, c_void_p]),
+    "si_train_get_opt_state": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "si_train_grad": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "si_train_grad_ptr": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "si_train_grad_get": (c_int32, [c_void_p, c_void_p]),
@@ -97,6 +100,7 @@ SIGNATURES = {
     "si_train_apply": (c_int32, [c_void_p]),
     "si_host_sym_eig": (c_int, [c_int, c_void_p, c_void_p]),
     "si_host_sym_eig_top": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "si_host_jacobi_eig_psd": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -248,6 +252,15 @@ class Context:
         g = _f64(g)
         self._check(self.lib.si_construct_gram_set(self.h, _ptr(g)))
 
+    def construct_needs_refine(self, m):
+        """True when the Gram route cannot resolve s_M (ill-conditioned A): the two-stage route is needed."""
+        flag = c_int32()
+        self._check(self.lib.si_construct_needs_refine(self.h, int(m), byref(flag)))
+        return bool(flag.value)
+
+    def construct_refine(self):
+        self._check(self.lib.si_construct_refine(self.h))
+
     def construct_gram_ptr(self):
         """(device address, K) of the K x K fp64 Gram matrix, for an in-place RCCL all-reduce."""
         ptr, k = c_void_p(), c_int64()
@@ -332,6 +345,14 @@ class Context:
         w = np.empty(self._tn, dtype=np.float32)
         self._check(self.lib.si_train_get_weights(self.h, _ptr(w)))
         return w
+
+    def train_get_opt_state(self):
+        """(m, v, (beta1^t, beta2^t)) -- Float32 flat state of the device optimiser."""
+        m = np.empty(self._tn, dtype=np.float32)
+        v = np.empty(self._tn, dtype=np.float32)
+        bp = np.empty(2, dtype=np.float64)
+        self._check(self.lib.si_train_get_opt_state(self.h, _ptr(m), _ptr(v), _ptr(bp)))
+        return m, v, (float(bp[0]), float(bp[1]))
 
     # -- density + sampling
     def infer_setup(self, table, n, m, w_swa, p, x, y, sigma_m):
@@ -475,3 +496,14 @@ def host_sym_eig_top(g, m):
     v = np.empty((n, int(m)), dtype=np.float64, order="F")
     rc = lib.si_host_sym_eig_top(n, _ptr(a), int(m), _ptr(w), _ptr(v))
     return (w, v) if rc == 0 else None
+
+
+def host_jacobi_eig_psd(g):
+    """Scaled-criterion Jacobi of the ill-conditioned route (needs no GPU): (w descending, V)."""
+    lib = load()
+    a = np.array(g, dtype=np.float64, order="F")
+    n = a.shape[0]
+    w = np.empty(n, dtype=np.float64)
+    v = np.empty((n, n), dtype=np.float64, order="F")
+    lib.si_host_jacobi_eig_psd(n, _ptr(a), _ptr(w), _ptr(v))
+    return w, v

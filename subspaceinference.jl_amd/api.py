@@ -54,9 +54,13 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
         # reference: reshape of an empty A, then psvd / U[:,1:M] fails
         raise SubspaceError("BoundsError: no snapshot was collected (mod(i,c) never 0 for i in 1:T)")
     dev_opt = flux.device_optimiser(opt) if isinstance(cost, flux.MSE) and hasattr(data, "index_batches") else None
-    if device_training is True and dev_opt is None:
-        raise SubspaceError("device_training needs cost = flux.mse and a fresh Descent / Momentum / ADAM optimiser")
-    use_dev = dev_opt is not None and device_training in ("auto", True)
+    # si_train_* keeps Float32 weights and optimiser state (Flux's default): a Float64 model stays on the host step,
+    # otherwise "auto" and device_training=False would return different (W_swa, P) for the same inputs
+    all_f32 = all(p.dtype == np.float32 for p in ps)
+    if device_training is True and (dev_opt is None or not all_f32):
+        raise SubspaceError("device_training needs cost = flux.mse, a fresh Descent / Momentum / ADAM optimiser and "
+                            "Float32 parameters (the device step keeps Float32 weights and optimiser state)")
+    use_dev = dev_opt is not None and all_f32 and device_training in ("auto", True)
     ctx, own = _get_ctx(ctx, device)
     try:
         ctx.construct_begin(n_par, n_push, max_cols)
@@ -92,6 +96,7 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
                     print("Traing loss: ", training_loss, " Epoch: ", i)  # [sic] reference :57
         if use_dev:
             flux.load_flat(model, ctx.train_get_weights())
+            flux.store_device_state(opt, model, *ctx.train_get_opt_state())  # opt continues where the device left it
         w_swa, p, _, _ = ctx.construct_finish(M, want_swa=True, want_p=not keep_on_device)
         return w_swa, p
     finally:

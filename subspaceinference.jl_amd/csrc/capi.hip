@@ -86,6 +86,8 @@ static void free_construct(Ctx* c) {
   dev_free(c->d_Gpart);
   dev_free(c->d_V);
   dev_free(c->d_P);
+  dev_free(c->d_B);
+  c->refine_stage = 0;
   c->gpart_bytes = 0;
   c->c_active = c->c_finished = c->gram_valid = false;
   c->K = c->Kcap = c->N = c->ldA = 0;
@@ -403,6 +405,11 @@ int32_t si_construct_gram(si_ctx* ctx) {
   launch_gram(ctx->stream, ctx->d_A, ctx->ldA, ctx->N, K, ctx->d_Gpart, ctx->d_G, ctx->num_cu, ctx);
   SI_HIP(ctx, hipGetLastError());
   ctx->gram_valid = true;
+  if (ctx->refine_stage != 0 || ctx->d_B) {  // a fresh first-stage Gram: drop the second stage of an earlier finish
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_B);
+    ctx->refine_stage = 0;
+  }
   return SI_OK;
 }
 
@@ -438,6 +445,132 @@ int32_t si_construct_gram_set(si_ctx* ctx, const double* G_host) {
   return SI_OK;
 }
 
+// ---- H1 + K3 ----------------------------------------------------------------------------------------------------------
+// Two routes to (s, P = A V_M):
+//   Gram route        G = A'A -> top-M eigenpairs -> P = A V_M.  Squares the condition number: used while
+//                     lambda_M > SI_GRAM_ROUTE_MIN * lambda_1 (s_M > ~3e-5 s_1), where it delivers s to ~1e-5 and better.
+//   two-stage route   (ill-conditioned A; what psvd's rtol = 5 eps still resolves)  full eigenbasis V of G ->
+//                     B = A V on the device (columns graded: resolved directions sorted out, the unresolved ones mixed
+//                     among themselves at their own small scale) -> G2 = B'B on the device -> scaled-criterion Jacobi
+//                     on the host (relative accuracy per eigenvalue) -> W -> P = B W_M.  Each stage resolves ~8 decades
+//                     of singular-value spread; what is left is the backward error of ANY fp64 SVD, eps*s_1/s_j.
+// BoundsError (the reference's U[:,1:M] on a psvd that returned fewer columns) only when s_M <= SI_RANK_RTOL * s_1.
+static constexpr double SI_GRAM_ROUTE_MIN = 1e-9;
+static constexpr double SI_EPS = 2.220446049250313e-16;
+
+static int32_t ensure_pin(si_ctx* ctx, size_t elems) {
+  if (ctx->h_pin_cap >= elems) return SI_OK;
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+  ctx->h_pin = nullptr;
+  ctx->h_pin_cap = 0;
+  if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), elems * sizeof(double), hipHostMallocDefault) != hipSuccess)
+    return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: pinned staging allocation failed");
+  ctx->h_pin_cap = elems;
+  return SI_OK;
+}
+
+static int32_t ensure_V(si_ctx* ctx, size_t v_elems) {
+  if (ctx->v_cap >= (int64_t)v_elems) return SI_OK;
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  dev_free(ctx->d_V);
+  ctx->v_cap = 0;
+  if (dev_alloc(&ctx->d_V, v_elems) != hipSuccess) return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: allocation of V failed");
+  ctx->v_cap = (int64_t)v_elems;
+  return SI_OK;
+}
+
+// top-M eigenpairs of the K x K matrix at h_pin[0 .. K*K) (left intact by the fast route, destroyed by the fallback)
+static int32_t top_eigen(si_ctx* ctx, int64_t K, int32_t M, std::vector<double>& wtop, std::vector<double>& Vtop) {
+  double* const G = ctx->h_pin;
+  wtop.assign((size_t)M, 0.0);
+  Vtop.assign((size_t)K * M, 0.0);
+  const auto t0 = std::chrono::steady_clock::now();
+  int erc = 0;
+  if (sym_eig_top((int)K, G, (int)M, wtop.data(), Vtop.data()) != 0) {
+    std::vector<double> lam((size_t)K);
+    erc = sym_eig((int)K, G, lam.data());
+    for (int m = 0; m < M && erc == 0; ++m) {
+      wtop[(size_t)m] = lam[(size_t)(K - 1 - m)];
+      std::copy(G + (size_t)(K - 1 - m) * K, G + (size_t)(K - m) * K, Vtop.data() + (size_t)m * K);
+    }
+  }
+  ctx->stats.ms[SI_K_EIG_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ctx->stats.launches[SI_K_EIG_HOST] += 1;
+  if (erc != 0) return fail(ctx, SI_ERR_INVALID, "si_construct_finish: eigensolver did not converge");
+  return SI_OK;
+}
+
+static int32_t fetch_G(si_ctx* ctx, int64_t K) {
+  const int32_t rc = ensure_pin(ctx, (size_t)K * K * 2 + (size_t)K * project_mpad((int)K));
+  if (rc != SI_OK) return rc;
+  SI_HIP(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_G, (size_t)K * K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+int32_t si_construct_needs_refine(si_ctx* ctx, int32_t M, int32_t* out) {
+  CHECK_CTX(ctx);
+  if (!ctx->gram_valid || !out) return fail(ctx, SI_ERR_STATE, "si_construct_needs_refine: call si_construct_gram first / NULL output");
+  if (M <= 0 || M > ctx->K) return fail(ctx, SI_ERR_BOUNDS, "BoundsError: M exceeds the number of deviation columns K");
+  BIND(ctx);
+  if (ctx->refine_stage == 1) {
+    *out = 0;  // already refined: d_G holds the second-stage Gram matrix
+    return SI_OK;
+  }
+  int32_t rc = fetch_G(ctx, ctx->K);
+  if (rc != SI_OK) return rc;
+  std::vector<double> wtop, Vtop;
+  if ((rc = top_eigen(ctx, ctx->K, M, wtop, Vtop)) != SI_OK) return rc;
+  *out = !(wtop[0] > 0.0) || wtop[(size_t)M - 1] <= SI_GRAM_ROUTE_MIN * wtop[0];
+  return SI_OK;
+}
+
+// second stage: B = A * V_full, G2 = B'B left in d_G (so that si_construct_gram_ptr / _get / _set all-reduce IT for a
+// row-sharded construction: every rank holds the same all-reduced G, hence the same V_full)
+int32_t si_construct_refine(si_ctx* ctx) {
+  CHECK_CTX(ctx);
+  if (!ctx->gram_valid) return fail(ctx, SI_ERR_STATE, "si_construct_refine: call si_construct_gram first");
+  if (ctx->refine_stage == 1) return SI_OK;
+  BIND(ctx);
+  const int64_t K = ctx->K, N = ctx->N;
+  int32_t rc = fetch_G(ctx, K);
+  if (rc != SI_OK) return rc;
+  double* const G = ctx->h_pin;
+  std::vector<double> lam((size_t)K);
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int erc = sym_eig((int)K, G, lam.data());  // ascending; G <- eigenvectors
+    ctx->stats.ms[SI_K_EIG_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ctx->stats.launches[SI_K_EIG_HOST] += 1;
+    if (erc != 0) return fail(ctx, SI_ERR_INVALID, "si_construct_refine: eigensolver did not converge");
+  }
+  ctx->vfull.assign((size_t)K * K, 0.0);
+  for (int64_t j = 0; j < K; ++j) std::copy(G + (size_t)(K - 1 - j) * K, G + (size_t)(K - j) * K, ctx->vfull.data() + (size_t)j * K);
+  const int Kpad = project_mpad((int)K);
+  double* const V = ctx->h_pin + (size_t)K * K * 2;
+  std::fill(V, V + (size_t)K * Kpad, 0.0);
+  for (int64_t j = 0; j < K; ++j)
+    for (int64_t k = 0; k < K; ++k) V[(size_t)k * Kpad + j] = ctx->vfull[(size_t)j * K + k];
+  if ((rc = ensure_V(ctx, (size_t)K * Kpad)) != SI_OK) return rc;
+  if (ctx->d_B == nullptr) {
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (dev_alloc(&ctx->d_B, (size_t)ctx->ldA * K) != hipSuccess)
+      return fail(ctx, SI_ERR_NOMEM, "si_construct_refine: allocation of the second-stage matrix (N x K) failed");
+    SI_HIP(ctx, hipMemsetAsync(ctx->d_B, 0, (size_t)ctx->ldA * K * sizeof(double), ctx->stream));  // padding rows stay zero
+  }
+  SI_HIP(ctx, hipMemcpyAsync(ctx->d_V, V, (size_t)K * Kpad * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  {
+    ProfScope ps(ctx, SI_K_PROJECT, 2.0 * (double)N * (double)K * (double)K, (double)N * (double)(2 * K) * 8.0);
+    launch_project(ctx->stream, ctx->d_A, ctx->ldA, N, K, ctx->d_V, (int32_t)K, Kpad, ctx->d_B, ctx->ldA, ctx->num_cu);
+  }
+  launch_gram(ctx->stream, ctx->d_B, ctx->ldA, N, K, ctx->d_Gpart, ctx->d_G, ctx->num_cu, ctx);
+  SI_HIP(ctx, hipGetLastError());
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the pinned V may be rewritten
+  ctx->refine_stage = 1;
+  return SI_OK;
+}
+
 int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P_out, double* s_out,
                             int64_t* K_out) {
   CHECK_CTX(ctx);
@@ -447,65 +580,70 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
   const int64_t K = ctx->K, N = ctx->N;
   if (K_out) *K_out = K;
   // U[:,1:M] throws BoundsError in the reference when psvd returns fewer than M columns (:65)
-  if (M > K) return fail(ctx, SI_ERR_BOUNDS, "BoundsError: M exceeds the number of deviation columns K");
-  if (!ctx->gram_valid) {
-    int32_t rc = si_construct_gram(ctx);
-    if (rc != SI_OK) return rc;
-  }
-  // H1: eigen-decomposition of G on the host (K x K); G comes down into, and V goes up from, pinned memory
+  if (M > std::min<int64_t>(N, K))
+    return fail(ctx, SI_ERR_BOUNDS, "BoundsError: M exceeds min(N, K), the largest possible rank of the deviation matrix");
+  int32_t rc;
+  if (!ctx->gram_valid && (rc = si_construct_gram(ctx)) != SI_OK) return rc;
   const int Mpad = project_mpad(M);
-  const size_t g_elems = (size_t)K * K, v_elems = (size_t)K * Mpad;
-  if (ctx->h_pin_cap < g_elems + v_elems) {
-    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
-    ctx->h_pin = nullptr;
-    ctx->h_pin_cap = 0;
-    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), (g_elems + v_elems) * sizeof(double), hipHostMallocDefault) != hipSuccess)
-      return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: pinned staging allocation failed");
-    ctx->h_pin_cap = g_elems + v_elems;
-  }
-  double* const G = ctx->h_pin;
-  double* const V = ctx->h_pin + g_elems;
-  std::vector<double> lam((size_t)K);
-  SI_HIP(ctx, hipMemcpyAsync(G, ctx->d_G, g_elems * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  // the M largest eigenpairs: fast route (factored Householder + inverse iteration, verified) or the full QL solver
-  std::vector<double> wtop((size_t)M), Vtop((size_t)K * M);
-  {
-    const auto t0 = std::chrono::steady_clock::now();
-    int erc = 0;
-    if (sym_eig_top((int)K, G, (int)M, wtop.data(), Vtop.data()) != 0) {
-      erc = sym_eig((int)K, G, lam.data());
-      for (int m = 0; m < M && erc == 0; ++m) {
-        wtop[(size_t)m] = lam[(size_t)(K - 1 - m)];
-        std::copy(G + (size_t)(K - 1 - m) * K, G + (size_t)(K - m) * K, Vtop.data() + (size_t)m * K);
-      }
-    }
-    ctx->stats.ms[SI_K_EIG_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    ctx->stats.launches[SI_K_EIG_HOST] += 1;
-    if (erc != 0) return fail(ctx, SI_ERR_INVALID, "si_construct_finish: eigensolver did not converge");
-  }
-  // descending singular values; V_M with a deterministic sign (largest-magnitude entry positive)
-  std::fill(V, V + v_elems, 0.0);
+  const size_t v_elems = (size_t)K * Mpad;
+  const double* src = ctx->d_A;  // matrix the projection reads: A (Gram route) or B (two-stage route)
+  std::vector<double> vcols((size_t)K * M);  // right factor in the basis of `src`, columns m < M
   ctx->svals.assign((size_t)M, 0.0);
+  if (ctx->refine_stage == 0) {
+    // H1: eigen-decomposition of G on the host (K x K); G comes down into, and V goes up from, pinned memory
+    if ((rc = fetch_G(ctx, K)) != SI_OK) return rc;
+    std::vector<double> wtop, Vtop;
+    if ((rc = top_eigen(ctx, K, M, wtop, Vtop)) != SI_OK) return rc;
+    if (!(wtop[0] > 0.0))
+      return fail(ctx, SI_ERR_BOUNDS, "BoundsError: the deviation matrix is zero (rank 0 < M)");
+    if (wtop[(size_t)M - 1] > SI_GRAM_ROUTE_MIN * wtop[0]) {
+      for (int m = 0; m < M; ++m) ctx->svals[(size_t)m] = std::sqrt(wtop[(size_t)m]);
+      vcols = Vtop;
+    } else if ((rc = si_construct_refine(ctx)) != SI_OK) {
+      return rc;
+    }
+  }
+  std::vector<double> vsign;  // vectors the deterministic sign is read from (in the basis of A's columns)
+  if (ctx->refine_stage == 1) {
+    // second-stage Gram matrix (all-reduced by the caller when rows are sharded) -> scaled Jacobi
+    if ((rc = fetch_G(ctx, K)) != SI_OK) return rc;
+    std::vector<double> lam2((size_t)K), W((size_t)K * K);
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      (void)jacobi_eig_psd((int)K, ctx->h_pin, lam2.data(), W.data());
+      ctx->stats.ms[SI_K_EIG_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      ctx->stats.launches[SI_K_EIG_HOST] += 1;
+    }
+    // numerical rank like psvd's rtol = 5 eps, widened by the rounding floor of the two products (~sqrt(K) eps)
+    const double s1 = lam2[0] > 0.0 ? std::sqrt(lam2[0]) : 0.0;
+    const double sM = lam2[(size_t)M - 1] > 0.0 ? std::sqrt(lam2[(size_t)M - 1]) : 0.0;
+    if (!(s1 > 0.0) || sM <= 8.0 * std::sqrt((double)K) * SI_EPS * s1)
+      return fail(ctx, SI_ERR_BOUNDS, "BoundsError: M exceeds the numerical rank of the deviation matrix (s_M <= ~5 eps s_1)");
+    for (int m = 0; m < M; ++m) ctx->svals[(size_t)m] = std::sqrt(lam2[(size_t)m]);
+    std::copy(W.begin(), W.begin() + (size_t)K * M, vcols.begin());
+    src = ctx->d_B;
+    // V_final = V_full * W_M, only for the sign convention
+    vsign.assign((size_t)K * M, 0.0);
+    for (int m = 0; m < M; ++m)
+      for (int64_t j = 0; j < K; ++j) {
+        const double wjm = W[(size_t)m * K + j];
+        const double* vj = ctx->vfull.data() + (size_t)j * K;
+        double* dst = vsign.data() + (size_t)m * K;
+        for (int64_t k = 0; k < K; ++k) dst[k] += vj[k] * wjm;
+      }
+  }
+  // V_M with a deterministic sign (largest-magnitude entry of the right singular vector positive)
+  double* const V = ctx->h_pin + (size_t)K * K * 2;
+  std::fill(V, V + v_elems, 0.0);
   for (int m = 0; m < M; ++m) {
-    const double l = wtop[(size_t)m];
-    ctx->svals[(size_t)m] = l > 0.0 ? std::sqrt(l) : 0.0;
-    const double* v = Vtop.data() + (size_t)m * K;
+    const double* vs = (vsign.empty() ? vcols.data() : vsign.data()) + (size_t)m * K;
     int64_t imax = 0;
     for (int64_t k = 1; k < K; ++k)
-      if (std::fabs(v[k]) > std::fabs(v[imax])) imax = k;
-    const double sgn = v[imax] < 0.0 ? -1.0 : 1.0;
+      if (std::fabs(vs[k]) > std::fabs(vs[imax])) imax = k;
+    const double sgn = vs[imax] < 0.0 ? -1.0 : 1.0;
+    const double* v = vcols.data() + (size_t)m * K;
     for (int64_t k = 0; k < K; ++k) V[(size_t)k * Mpad + m] = sgn * v[k];
   }
-  // numerical rank check.  psvd (rtol 5 eps) returns only rank(A) columns and U[:,1:M] then throws.  Through the
-  // Gram matrix, eigenvalues below ~K*eps*lambda_1 are rounding noise, i.e. singular values under ~1e-6*s_1 cannot
-  // be delivered to the path's rtol of 1e-4: report them as rank deficiency instead of returning noise.
-  const double lam1 = wtop[0], lamM = wtop[(size_t)M - 1];
-  if (!(lam1 > 0.0) || lamM <= 64.0 * (double)K * 2.220446049250313e-16 * lam1 || M > std::min<int64_t>(N, K))
-    return fail(ctx, SI_ERR_BOUNDS,
-                "BoundsError: M exceeds the numerical rank of the deviation matrix (s_M < ~1e-6 s_1 is below what the "
-                "Gram-matrix route resolves)");
   if (ctx->d_P == nullptr || ctx->M_built != M) {
     SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // P is re-allocated: an inference bound to the old P of this construction must not outlive it
@@ -517,18 +655,11 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
     // zeroed once, for the padding rows [N, ldA): the projection writes every row < N of every column on each finish
     SI_HIP(ctx, hipMemsetAsync(ctx->d_P, 0, (size_t)ctx->ldA * M * sizeof(double), ctx->stream));
   }
-  if (ctx->v_cap < (int64_t)v_elems) {
-    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    dev_free(ctx->d_V);
-    ctx->v_cap = 0;
-    if (dev_alloc(&ctx->d_V, v_elems) != hipSuccess)
-      return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: allocation of V failed");
-    ctx->v_cap = (int64_t)v_elems;
-  }
+  if ((rc = ensure_V(ctx, std::max(v_elems, (size_t)K * project_mpad((int)K) * (ctx->refine_stage ? 1 : 0)))) != SI_OK) return rc;
   SI_HIP(ctx, hipMemcpyAsync(ctx->d_V, V, v_elems * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   {
     ProfScope ps(ctx, SI_K_PROJECT, 2.0 * (double)N * (double)K * (double)M, (double)N * (double)(K + M) * 8.0);
-    launch_project(ctx->stream, ctx->d_A, ctx->ldA, N, K, ctx->d_V, M, Mpad, ctx->d_P, ctx->ldA, ctx->num_cu);
+    launch_project(ctx->stream, src, ctx->ldA, N, K, ctx->d_V, M, Mpad, ctx->d_P, ctx->ldA, ctx->num_cu);
   }
   SI_HIP(ctx, hipGetLastError());
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the pinned V may be rewritten by the next finish

@@ -339,4 +339,19 @@ int32_t si_train_get_weights(si_ctx* ctx, float* w_out) {
   return SI_OK;
 }
 
+int32_t si_train_get_opt_state(si_ctx* ctx, float* m_out, float* v_out, double* beta_pows_out) {
+  if (!ctx) return SI_ERR_INVALID;
+  if (!ctx->train) return fail(ctx, SI_ERR_STATE, "si_train_get_opt_state: no training state");
+  SI_HIP(ctx, hipSetDevice(ctx->device));
+  TrainState* t = ctx->train;
+  if (m_out && t->m32) SI_HIP(ctx, hipMemcpyAsync(m_out, t->m32, (size_t)t->N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (v_out && t->v32) SI_HIP(ctx, hipMemcpyAsync(v_out, t->v32, (size_t)t->N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (beta_pows_out) {
+    beta_pows_out[0] = t->bp1;
+    beta_pows_out[1] = t->bp2;
+  }
+  return SI_OK;
+}
+
 }  // extern "C"

@@ -80,6 +80,10 @@ struct Ctx {
   double* d_P = nullptr;      // ldA x M
   int32_t M_built = 0;
   std::vector<double> svals;
+  // ill-conditioned route (second-stage Gram): B = A * V_full, d_G then holds G2 = B'B
+  int refine_stage = 0;           // 0: d_G = A'A;  1: d_B valid and d_G = B'B (possibly all-reduced by the caller)
+  double* d_B = nullptr;          // ldA x K
+  std::vector<double> vfull;      // K x K eigenvectors of A'A, columns DESCENDING by eigenvalue (host)
 
   // ---- inference state (reference src/space_inference.jl:88-95,111-116,125)
   bool i_ready = false;
@@ -249,6 +253,8 @@ int sym_eig(int n, double* a, double* w);
 // M largest eigenpairs without the full eigenvector matrix (eig.cpp); g is left intact; w_top descending, V n x m.
 // Verified (residual, orthogonality); returns non-zero when the caller should use sym_eig instead.
 int sym_eig_top(int n, const double* g, int m, double* w_top, double* V);
+// scaled-criterion two-sided Jacobi for a PSD matrix (eig_dispatch.cpp): a destroyed; w DESCENDING; v eigenvectors
+int jacobi_eig_psd(int n, double* a, double* w, double* v);
 
 }  // namespace si
 

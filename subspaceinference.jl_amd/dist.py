@@ -175,6 +175,14 @@ def allreduce_inplace(ctx, ptr, n):
         d.all_reduce(_dev_view(ptr, (n,)), op=d.ReduceOp.SUM)
 
 
+def _allreduce_gram(ctx):
+    if _on_rccl():
+        ptr, k = ctx.construct_gram_ptr()
+        allreduce_inplace(ctx, ptr, k * k)
+    elif _dist() is not None:
+        ctx.construct_gram_set(allreduce_sum(ctx.construct_gram_get()))
+
+
 def sharded_construct_finish(ctx, m, n_total=None, gather=True):
     """Row-sharded `U,s,V = psvd(A); P = U[:,1:M]*Diagonal(s[1:M])` (src/subspace_construction.jl:63,65).
 
@@ -185,11 +193,10 @@ def sharded_construct_finish(ctx, m, n_total=None, gather=True):
     ordered on the library's stream: no D2H / H2D of G and no synchronisation of its own.  gloo (CPU tests) stages it
     through the host."""
     ctx.construct_gram()
-    if _on_rccl():
-        ptr, k = ctx.construct_gram_ptr()
-        allreduce_inplace(ctx, ptr, k * k)
-    else:
-        ctx.construct_gram_set(allreduce_sum(ctx.construct_gram_get()))
+    _allreduce_gram(ctx)
+    if ctx.construct_needs_refine(m):   # ill-conditioned A: every rank sees the same G, hence the same answer
+        ctx.construct_refine()          # B = A V on this rank's rows; the second-stage Gram matrix replaces G
+        _allreduce_gram(ctx)
     w_loc, p_loc, s, k = ctx.construct_finish(m)
     if not gather or n_total is None:
         return w_loc, p_loc, s, k
@@ -204,9 +211,10 @@ def sharded_construct_finish_dev(ctx, m, n_total):
     d = _dist()
     rank, ws = world()
     ctx.construct_gram()
-    if d is not None:
-        ptr, k = ctx.construct_gram_ptr()
-        allreduce_inplace(ctx, ptr, k * k)
+    _allreduce_gram(ctx)
+    if ctx.construct_needs_refine(m):
+        ctx.construct_refine()
+        _allreduce_gram(ctx)
     _, _, s, _ = ctx.construct_finish(m, want_swa=False, want_p=False)
     wptr, pptr, ld_loc, _ = ctx.construct_result_ptr()
     sizes = [row_shard(n_total, r, ws)[1] - row_shard(n_total, r, ws)[0] for r in range(ws)]

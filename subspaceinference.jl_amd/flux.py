@@ -214,6 +214,23 @@ def device_optimiser(opt):
     return None
 
 
+def store_device_state(opt, model, m_flat, v_flat, beta_pows):
+    """Leave `opt` as Flux.update! would have left it after the steps the device took for it (src/subspace_construction.jl:43
+    keeps the optimiser's IdDict state across calls): Momentum velocity / ADAM moments per parameter array, ADAM's running
+    beta powers.  A later call with this optimiser continues on the host (device_optimiser() declines a used one)."""
+    if isinstance(opt, Descent):
+        return
+    for (fin, fout, _, w_off, b_off), l in zip(layer_table(model)[0], model.layers):
+        for arr, off, shape in ((l.W, w_off, (fout, fin)), (l.b, b_off, (fout,))):
+            size = int(np.prod(shape))
+            mv = m_flat[off:off + size].reshape(shape, order="F").astype(arr.dtype)
+            if isinstance(opt, Momentum):
+                opt.v[id(arr)] = mv
+            else:
+                vv = v_flat[off:off + size].reshape(shape, order="F").astype(arr.dtype)
+                opt.state[id(arr)] = [mv, vv, [beta_pows[0], beta_pows[1]]]
+
+
 def update(opt, ps, gs):
     """Flux.update!(opt, ps, gs): `x .-= apply!(opt, x, g)` -- Float32 x minus Float64 step, rounded once to Float32."""
     for p, g in zip(ps, gs):

@@ -133,9 +133,19 @@ function train_on_device!(ctx::Ctx, model, data, opt, T, c, print_freq)
     # Flux.update! works in place: hand the trained weights back to the model's arrays
     w = Vector{Float32}(undef, N)
     GC.@preserve w check(ctx, ccall((:si_train_get_weights, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}), ctx.h, w))
+    # ... and leave `opt` as Flux.update! would have (its IdDict state persists across calls in the reference)
+    m = Vector{Float32}(undef, N); v = Vector{Float32}(undef, N); βp = Vector{Float64}(undef, 2)
+    GC.@preserve m v βp check(ctx, ccall((:si_train_get_opt_state, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float64}), ctx.h, m, v, βp))
     off = 0
     for p in ps
-        copyto!(p, reshape(view(w, off+1:off+length(p)), size(p)))
+        sl = off+1:off+length(p)
+        copyto!(p, reshape(view(w, sl), size(p)))
+        if opt isa Momentum            # [upstream Flux 0.11.2: Momentum.velocity::IdDict, x => v]
+            opt.velocity[p] = reshape(m[sl], size(p))
+        elseif opt isa ADAM            # [upstream Flux 0.11.2: ADAM.state::IdDict, x => (mt, vt, βp)]
+            opt.state[p] = (reshape(m[sl], size(p)), reshape(v[sl], size(p)), [βp[1], βp[2]])
+        end
         off += length(p)
     end
 end

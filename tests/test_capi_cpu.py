@@ -197,3 +197,26 @@ def test_stan_windowed_adaptation():
         z, lp, acc = sampler(fn, 3, 3000, 1.0, np.random.default_rng(0))
         assert np.allclose(z[:, 1500:].std(axis=1), scales, rtol=0.15), sampler.__name__
         assert 0.6 < acc <= 1.0
+
+
+def test_jacobi_resolves_graded_psd_matrices(si):
+    """The second-stage solver of the ill-conditioned route: eigenvalues of a graded Gram matrix B'B (columns spread
+    over 12 decades, mixed inside the small block) to RELATIVE accuracy."""
+    rng = np.random.default_rng(0)
+    n, k = 300, 12
+    u, _ = np.linalg.qr(rng.standard_normal((n, k)))
+    sv = np.logspace(0, -12, k)
+    mix = np.eye(k)
+    q, _ = np.linalg.qr(rng.standard_normal((6, 6)))
+    mix[6:, 6:] = q                                   # unresolved directions arrive mixed among themselves
+    b = (u * sv[None, :]) @ mix                       # graded columns: the product is formed WITHOUT cancellation
+    g2 = b.T @ b
+    w, v = si._capi.host_jacobi_eig_psd(g2)
+    assert np.all(np.diff(w) <= 0)
+    assert np.allclose(np.sqrt(w), sv, rtol=1e-6)     # twelve decades, each singular value relative to ITSELF
+    assert np.allclose(v.T @ v, np.eye(k), atol=1e-12)
+    # well-conditioned input: agrees with LAPACK to rounding
+    a = rng.standard_normal((40, 9))
+    w2, v2 = si._capi.host_jacobi_eig_psd(a.T @ a)
+    assert np.allclose(w2, np.linalg.eigvalsh(a.T @ a)[::-1], rtol=1e-12)
+    assert np.allclose((a.T @ a) @ v2, v2 * w2[None, :], atol=1e-11 * w2[0])

@@ -16,7 +16,7 @@ class FakeCtx:
     """Rank-local stand-in for _capi.Context: same method names, NumPy arithmetic on this rank's row block."""
 
     def __init__(self, a_local, w_local, eig):
-        self.a, self.w, self.eig, self.g = a_local, w_local, eig, None
+        self.a, self.w, self.eig, self.g, self.refined = a_local, w_local, eig, None, False
 
     def construct_gram(self):
         self.g = self.a.T @ self.a
@@ -27,7 +27,23 @@ class FakeCtx:
     def construct_gram_set(self, g):
         self.g = np.array(g)
 
-    def construct_finish(self, m):
+    def construct_needs_refine(self, m):
+        lam = np.linalg.eigvalsh(self.g)[::-1]
+        return (not self.refined) and lam[m - 1] <= 1e-9 * lam[0]
+
+    def construct_refine(self):
+        """second stage of the ill-conditioned route on this rank's rows: B = A V_full, the Gram of B replaces G"""
+        _, v = np.linalg.eigh(self.g)
+        self.vfull = v[:, ::-1]
+        self.b = self.a @ self.vfull
+        self.g = self.b.T @ self.b
+        self.refined = True
+
+    def construct_finish(self, m, **kw):
+        if self.refined:
+            import subspaceinference_jl_amd as si
+            lam, w = si._capi.host_jacobi_eig_psd(self.g)
+            return self.w, self.b @ w[:, :m], np.sqrt(lam[:m]), self.a.shape[1]
         lam, v = self.eig(self.g)
         v = v[:, ::-1][:, :m]
         v = v * np.sign(v[np.argmax(np.abs(v), axis=0), np.arange(m)])[None, :]
@@ -122,6 +138,18 @@ def _worker(rank, world, port, q):
         ok = ok and np.allclose(p_full * sign, p_ref, rtol=1e-7, atol=1e-10)
         # the all-reduced Gram is the full one on every rank
         ok = ok and np.allclose(ctx.g, a.T @ a, rtol=1e-12)
+        # ill-conditioned A (ten decades of singular-value spread): the second-stage Gram matrix is all-reduced too
+        rq = np.random.default_rng(3)
+        uu, _ = np.linalg.qr(rq.standard_normal((n, 8)))
+        vv, _ = np.linalg.qr(rq.standard_normal((8, 8)))
+        sv = np.logspace(0, -10, 8)
+        a_ill = (uu * sv[None, :]) @ vv.T
+        ci = FakeCtx(a_ill[r0:r1], w_swa[r0:r1], si.host_sym_eig)
+        _, p_ill, s_ill, _ = sd.sharded_construct_finish(ci, 8, n_total=n, gather=True)
+        ok = ok and ci.refined and np.allclose(s_ill, sv, rtol=1e-4)
+        p_true = uu * sv[None, :]
+        sg = np.sign(np.sum(p_ill * p_true, axis=0))
+        ok = ok and np.allclose(p_ill * sg, p_true, rtol=0, atol=1e-4 * np.abs(p_true).max(axis=0)[None, :])
         # chains: 5 chains over 2 ranks, gathered == one rank running all five
         z, lp, acc = sd.sample_chains(ctx, 5, 7, 0.3, seed=9)
         zr, lpr, _ = FakeCtx(None, None, None).sample_rwmh(7, 0.3, 9, 0, 5)

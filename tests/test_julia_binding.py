@@ -96,7 +96,7 @@ def test_the_wrapper_binds_the_whole_single_process_path():
     unbound = set(header_prototypes()) - bound
     for name in unbound:
         assert re.search(r"_dev$|_ptr$|gram|rwmh_|train_grad|train_apply|profiling|stats|stream|synchronize|version|device_name|"
-                         r"get_A|host_sym_eig|si_forward|push_batch", name), "unbound without a reason: " + name
+                         r"get_A|host_sym_eig|host_jacobi|refine|si_forward|push_batch", name), "unbound without a reason: " + name
 
 
 def test_silayer_mirrors_si_layer():
