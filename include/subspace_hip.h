@@ -42,18 +42,32 @@ enum {
 
 enum { SI_F32 = 0, SI_F64 = 1 };                                  /* dtype of a weight snapshot */
 enum { SI_ACT_IDENTITY = 0, SI_ACT_RELU = 1, SI_ACT_TANH = 2, SI_ACT_SIGMOID = 3 };
-enum { SI_LAYER_DENSE = 0 };
+enum { SI_LAYER_DENSE = 0, SI_LAYER_CONV = 1, SI_LAYER_MAXPOOL = 2, SI_LAYER_FLATTEN = 3 };
 
-/* One Dense layer of a Flux Chain inside the flat weight vector.  Layout contract of the whole path
- * (src/libs.jl:19-22 extract_params, src/libs.jl:55-57 Flux.destructure/re):
- *   [vec(W1) (out x in, column-major); b1; vec(W2); b2; ...]                                          */
+/* One layer of a Flux Chain.  Layout contract of the whole path inside the flat weight vector (src/libs.jl:19-22
+ * extract_params, src/libs.jl:55-57 Flux.destructure/re -- `model_re` restructures ANY Chain):
+ *   Dense  [vec(W) (out x in, column-major); b]          Conv  [vec(weight) (kw x kh x cin x cout, column-major); bias]
+ * in the order of the layers; MaxPool and flatten own no parameters.  Activations between layers are (features x B)
+ * matrices whose feature index runs in Julia's (W, H, C) column-major order -- the (W, H, C, N) arrays of Flux.
+ *   SI_LAYER_DENSE    in, out, act, w_off, b_off                                  (geometry fields unused: 0)
+ *   SI_LAYER_CONV     Flux 0.11.2 Conv((kw, kh), cin => cout, act; stride, pad, dilation) with NNlib's default TRUE
+ *                     convolution (flipped kernel); in = wi*hi*cin, out = wo*ho*cout,
+ *                     wo = (wi + 2*pw - dw*(kw-1) - 1) / sw + 1
+ *   SI_LAYER_MAXPOOL  MaxPool((kw, kh); stride = (sw, sh), pad = 0); cin == cout channels
+ *   SI_LAYER_FLATTEN  (W, H, C, N) -> (W*H*C, N); in == out                                                          */
 typedef struct {
-  int32_t kind;  /* SI_LAYER_DENSE */
+  int32_t kind;  /* SI_LAYER_*      */
   int32_t in;    /* input features  */
   int32_t out;   /* output features */
   int32_t act;   /* SI_ACT_*        */
-  int64_t w_off; /* offset of vec(W) in the flat vector (elements) */
-  int64_t b_off; /* offset of b                                     */
+  int64_t w_off; /* offset of vec(W) / vec(weight) in the flat vector (elements) */
+  int64_t b_off; /* offset of the bias                                           */
+  int32_t kw, kh;         /* Conv kernel / MaxPool window                         */
+  int32_t cin, cout;      /* channels                                             */
+  int32_t wi, hi;         /* input width, height                                  */
+  int32_t sw, sh;         /* stride                                               */
+  int32_t pw, ph;         /* Conv zero padding (each side)                        */
+  int32_t dw, dh;         /* Conv dilation                                        */
 } si_layer;
 
 /* kernel classes timed by the library's own hipEvents (si_set_profiling) */
@@ -69,7 +83,9 @@ enum {
   SI_K_DENSE_MAIN = 8, /* K5 the largest layer only (dominant kernel) */
   SI_K_EIG_HOST = 9,   /* H1 K x K symmetric eigensolve: HOST wall time, not a device kernel */
   SI_K_BACKWARD = 10,  /* reverse sweep of si_logdensity_grad: delta, dW (split-K MFMA), W'delta, P'g */
-  SI_K_COUNT = 11
+  SI_K_CONV = 11,      /* K5 Conv layer: implicit-GEMM convolution (MFMA f64), forward                */
+  SI_K_CONV_AUX = 12,  /* K5 Conv stacks: weight re-pack, MaxPool, layout changes (HBM-bound)         */
+  SI_K_COUNT = 13
 };
 
 typedef struct {
@@ -79,7 +95,7 @@ typedef struct {
   double bytes[SI_K_COUNT];     /* accumulated ALGORITHMIC HBM bytes per class                 */
 } si_stats;
 
-int32_t si_version(void);
+int32_t si_version(void); /* 200: si_layer carries the Conv / MaxPool geometry */
 
 /* ---- context ------------------------------------------------------------------------------- */
 int32_t si_create(si_ctx** out, int32_t device_id);

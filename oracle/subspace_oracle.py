@@ -107,15 +107,108 @@ def _act(a, kind):
     raise ValueError(kind)
 
 
+# ---- Conv / MaxPool / flatten rows of a Chain (`model_re` restructures ANY Chain, src/libs.jl:55-57).
+# A table row is a Dense 5-tuple (in, out, act, w_off, b_off) or one of
+#   ("conv", (KW, KH, CIN, COUT), (Wi, Hi), (sw, sh), (pw, ph), (dw, dh), act, w_off, b_off)
+#   ("maxpool", (PW, PH), C, (Wi, Hi), (sw, sh))
+#   ("flatten", C, (Wi, Hi))
+# Activations between such rows are matrices [features x B] whose feature index runs in Julia's WHC column-major order
+# (w fastest), i.e. the (W, H, C, N) arrays of Flux reshaped to (W*H*C, N) -- which is exactly what `flatten` does.
+def conv_out_size(wi, k, s, p, d):
+    """NNlib 0.7.23 output_size: floor((in + 2 pad - dil*(k-1) - 1) / stride) + 1  [upstream, Manifest.toml:918]"""
+    return (wi + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def conv_forward(x4, w4, b, stride, pad, dil):
+    """Flux 0.11.2 `Conv` forward before the activation: conv(x, weight) .+ reshape(b, 1, 1, :, 1) with NNlib's DEFAULT
+    `flipkernel = false`, i.e. a TRUE convolution (kernel index reversed) [upstream NNlib 0.7.23 conv_direct!: x index
+    (o-1)*stride - pad + 1 + (k-1)*dil, weight index K - k + 1].  x4 is (W, H, CIN, N), w4 is (KW, KH, CIN, COUT)."""
+    kw, kh, cin, cout = w4.shape
+    wi, hi, _, n = x4.shape
+    wo, ho = conv_out_size(wi, kw, stride[0], pad[0], dil[0]), conv_out_size(hi, kh, stride[1], pad[1], dil[1])
+    xp = np.zeros((wi + 2 * pad[0], hi + 2 * pad[1], cin, n), dtype=np.float64)
+    xp[pad[0]:pad[0] + wi, pad[1]:pad[1] + hi] = x4
+    y = np.zeros((wo, ho, cout, n), dtype=np.float64)
+    for a in range(kw):
+        for c in range(kh):
+            xs = xp[a * dil[0]: a * dil[0] + (wo - 1) * stride[0] + 1: stride[0],
+                    c * dil[1]: c * dil[1] + (ho - 1) * stride[1] + 1: stride[1]]
+            y += np.einsum("whin,io->whon", xs, w4[kw - 1 - a, kh - 1 - c], optimize=True)
+    return y + b[None, None, :, None]
+
+
+def maxpool_forward(x4, win, stride):
+    """Flux 0.11.2 MaxPool(k; pad = 0, stride = k) [upstream NNlib maxpool]."""
+    wi, hi, c, n = x4.shape
+    wo, ho = (wi - win[0]) // stride[0] + 1, (hi - win[1]) // stride[1] + 1
+    y = np.full((wo, ho, c, n), -np.inf)
+    for a in range(win[0]):
+        for d in range(win[1]):
+            y = np.maximum(y, x4[a: a + (wo - 1) * stride[0] + 1: stride[0], d: d + (ho - 1) * stride[1] + 1: stride[1]])
+    return y
+
+
+def _layer_forward(row, wflat, h):
+    """one table row: [features x B] -> [features x B]; also returns what the reverse sweep needs"""
+    bsz = h.shape[1]
+    if row[0] == "conv":
+        _, (kw, kh, cin, cout), (wi, hi), stride, pad, dil, act, w_off, b_off = row
+        w4 = wflat[w_off:w_off + kw * kh * cin * cout].reshape((kw, kh, cin, cout), order="F")
+        y = _act(conv_forward(h.reshape((wi, hi, cin, bsz), order="F"), w4, wflat[b_off:b_off + cout], stride, pad, dil), act)
+        return y.reshape((-1, bsz), order="F")
+    if row[0] == "maxpool":
+        _, win, c, (wi, hi), stride = row
+        return maxpool_forward(h.reshape((wi, hi, c, bsz), order="F"), win, stride).reshape((-1, bsz), order="F")
+    if row[0] == "flatten":
+        return h
+    fin, fout, act, w_off, b_off = row
+    w = wflat[w_off:w_off + fin * fout].reshape((fout, fin), order="F")
+    return _act(w @ h + wflat[b_off:b_off + fout][:, None], act)
+
+
 def forward(table, wflat, x):
-    """src/libs.jl:55-57 (`re(W)`: reshape consecutive slices, column-major) followed by the Flux 0.11.2
-    Dense forward `sigma.(W*x .+ b)` for every layer (src/space_inference.jl:94 `new_model(in_data)`)."""
+    """src/libs.jl:55-57 (`re(W)`: reshape consecutive slices, column-major) followed by the Flux 0.11.2 forward of every
+    layer (src/space_inference.jl:94 `new_model(in_data)`): Dense `sigma.(W*x .+ b)`, Conv, MaxPool, flatten."""
     h = x
-    for (fin, fout, act, w_off, b_off) in table:
-        w = wflat[w_off:w_off + fin * fout].reshape((fout, fin), order="F")
-        b = wflat[b_off:b_off + fout]
-        h = _act(w @ h + b[:, None], act)
+    for row in table:
+        h = _layer_forward(row, wflat, h)
     return h
+
+
+def conv_table(spec, in_whc):
+    """Layout of a Chain with Conv / MaxPool / flatten / Dense layers inside the flat weight vector, in `Flux.params`
+    order (Conv: weight (KW, KH, CIN, COUT) column-major then bias; Dense: W then b) -- src/libs.jl:19-22, 55-57.
+    spec entries: ("conv", (kw, kh), cout, act, stride, pad, dil) | ("maxpool", (pw, ph)[, stride]) | ("flatten",) |
+    ("dense", out, act).  Returns (table, N)."""
+    wi, hi, c = in_whc
+    feat, off, table = None, 0, []
+    for e in spec:
+        if e[0] == "conv":
+            (kw, kh), cout, act = e[1], e[2], e[3]
+            stride = e[4] if len(e) > 4 else (1, 1)
+            pad = e[5] if len(e) > 5 else (0, 0)
+            dil = e[6] if len(e) > 6 else (1, 1)
+            w_off = off
+            off += kw * kh * c * cout
+            b_off = off
+            off += cout
+            table.append(("conv", (kw, kh, c, cout), (wi, hi), tuple(stride), tuple(pad), tuple(dil), act, w_off, b_off))
+            wi, hi, c = conv_out_size(wi, kw, stride[0], pad[0], dil[0]), conv_out_size(hi, kh, stride[1], pad[1], dil[1]), cout
+        elif e[0] == "maxpool":
+            win = e[1]
+            stride = e[2] if len(e) > 2 else win
+            table.append(("maxpool", tuple(win), c, (wi, hi), tuple(stride)))
+            wi, hi = (wi - win[0]) // stride[0] + 1, (hi - win[1]) // stride[1] + 1
+        elif e[0] == "flatten":
+            table.append(("flatten", c, (wi, hi)))
+            feat = wi * hi * c
+        else:
+            fin = feat if feat is not None else wi * hi * c
+            fout, act = e[1], e[2]
+            table.append((fin, fout, act, off, off + fin * fout))
+            off += fin * fout + fout
+            feat = fout
+    return table, off
 
 
 def mvnormal_logpdf_iso(y, mu, sigma):
@@ -161,20 +254,58 @@ def logdensity_grad(table, w_swa, p, x, y, sigma_m, z):
     the same scalar, restated here as one reverse sweep in NumPy.  Returns (lp, d lp / d z, d lp / d w)."""
     new_w = w_swa + p @ z
     hs = [x]
-    for (fin, fout, act, w_off, b_off) in table:
-        w = new_w[w_off:w_off + fin * fout].reshape((fout, fin), order="F")
-        hs.append(_act(w @ hs[-1] + new_w[b_off:b_off + fout][:, None], act))
+    for row in table:
+        hs.append(_layer_forward(row, new_w, hs[-1]))
     lp, _ = mvnormal_logpdf_iso(y.reshape(-1, order="F"), hs[-1].reshape(-1, order="F"), sigma_m)
     gw = np.zeros_like(new_w)
-    delta = (y - hs[-1]) / (sigma_m * sigma_m) * _dact(hs[-1], table[-1][2])
+    g = (y - hs[-1]) / (sigma_m * sigma_m)          # d lp / d (output of the last layer)
     for l in range(len(table) - 1, -1, -1):
-        fin, fout, act, w_off, b_off = table[l]
-        gw[w_off:w_off + fin * fout] = (delta @ hs[l].T).reshape(-1, order="F")
-        gw[b_off:b_off + fout] = delta.sum(axis=1)
-        if l > 0:
-            w = new_w[w_off:w_off + fin * fout].reshape((fout, fin), order="F")
-            delta = (w.T @ delta) * _dact(hs[l], table[l - 1][2])
+        g = _layer_backward(table[l], new_w, hs[l], hs[l + 1], g, gw)
     return lp, p.T @ gw, gw
+
+
+def _layer_backward(row, wflat, h_in, h_out, g_out, gw):
+    """reverse sweep through one row: g_out = d lp / d h_out -> returns d lp / d h_in, adds the parameter gradient to gw"""
+    bsz = h_in.shape[1]
+    if row[0] == "flatten":
+        return g_out
+    if row[0] == "maxpool":
+        _, win, c, (wi, hi), stride = row
+        x4 = h_in.reshape((wi, hi, c, bsz), order="F")
+        y4 = h_out.reshape(((wi - win[0]) // stride[0] + 1, (hi - win[1]) // stride[1] + 1, c, bsz), order="F")
+        g4 = g_out.reshape(y4.shape, order="F")
+        gx = np.zeros_like(x4)
+        wo, ho = y4.shape[:2]
+        for a in range(win[0]):       # every element equal to its window's maximum receives the gradient [upstream NNlib ∇maxpool]
+            for d in range(win[1]):
+                sl = (slice(a, a + (wo - 1) * stride[0] + 1, stride[0]), slice(d, d + (ho - 1) * stride[1] + 1, stride[1]))
+                gx[sl] += g4 * (x4[sl] == y4)
+        return gx.reshape((-1, bsz), order="F")
+    if row[0] == "conv":
+        _, (kw, kh, cin, cout), (wi, hi), stride, pad, dil, act, w_off, b_off = row
+        wo, ho = conv_out_size(wi, kw, stride[0], pad[0], dil[0]), conv_out_size(hi, kh, stride[1], pad[1], dil[1])
+        w4 = wflat[w_off:w_off + kw * kh * cin * cout].reshape((kw, kh, cin, cout), order="F")
+        d4 = (g_out * _dact(h_out, act)).reshape((wo, ho, cout, bsz), order="F")
+        x4 = h_in.reshape((wi, hi, cin, bsz), order="F")
+        xp = np.zeros((wi + 2 * pad[0], hi + 2 * pad[1], cin, bsz))
+        xp[pad[0]:pad[0] + wi, pad[1]:pad[1] + hi] = x4
+        gxp = np.zeros_like(xp)
+        gw4 = np.zeros_like(w4)
+        for a in range(kw):
+            for c in range(kh):
+                sl = (slice(a * dil[0], a * dil[0] + (wo - 1) * stride[0] + 1, stride[0]),
+                      slice(c * dil[1], c * dil[1] + (ho - 1) * stride[1] + 1, stride[1]))
+                gw4[kw - 1 - a, kh - 1 - c] = np.einsum("whin,whon->io", xp[sl], d4, optimize=True)
+                gxp[sl] += np.einsum("whon,io->whin", d4, w4[kw - 1 - a, kh - 1 - c], optimize=True)
+        gw[w_off:w_off + w4.size] = gw4.reshape(-1, order="F")
+        gw[b_off:b_off + cout] = d4.sum(axis=(0, 1, 3))
+        return gxp[pad[0]:pad[0] + wi, pad[1]:pad[1] + hi].reshape((-1, bsz), order="F")
+    fin, fout, act, w_off, b_off = row
+    delta = g_out * _dact(h_out, act)
+    gw[w_off:w_off + fin * fout] = (delta @ h_in.T).reshape(-1, order="F")
+    gw[b_off:b_off + fout] = delta.sum(axis=1)
+    w = wflat[w_off:w_off + fin * fout].reshape((fout, fin), order="F")
+    return w.T @ delta
 
 
 def reconstruct(w_swa, p, z):

@@ -17,7 +17,9 @@ LIB_PATH = os.path.join(HERE, "libsubspace_hip.so")
 SI_OK, SI_ERR_INVALID, SI_ERR_STATE, SI_ERR_HIP, SI_ERR_NOMEM, SI_ERR_BOUNDS, SI_ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 SI_F32, SI_F64 = 0, 1
 ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
-K_NAMES = ["push", "gram", "gram_reduce", "project", "reconstruct", "dense", "sse", "rwmh", "dense_main", "eig_host", "backward"]
+K_NAMES = ["push", "gram", "gram_reduce", "project", "reconstruct", "dense", "sse", "rwmh", "dense_main", "eig_host", "backward",
+           "conv", "conv_aux"]
+LAYER_DENSE, LAYER_CONV, LAYER_MAXPOOL, LAYER_FLATTEN = 0, 1, 2, 3
 K_COUNT = len(K_NAMES)
 
 
@@ -35,7 +37,9 @@ class BoundsError(SubspaceError, IndexError):
 
 class SiLayer(Structure):
     _fields_ = [("kind", c_int32), ("in_", c_int32), ("out", c_int32), ("act", c_int32),
-                ("w_off", c_int64), ("b_off", c_int64)]
+                ("w_off", c_int64), ("b_off", c_int64),
+                ("kw", c_int32), ("kh", c_int32), ("cin", c_int32), ("cout", c_int32), ("wi", c_int32), ("hi", c_int32),
+                ("sw", c_int32), ("sh", c_int32), ("pw", c_int32), ("ph", c_int32), ("dw", c_int32), ("dh", c_int32)]
 
 
 class SiStats(Structure):
@@ -135,12 +139,31 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(c_void_p)
 
 
+def conv_out_size(wi, k, s, p, d):
+    return (wi + 2 * p - d * (k - 1) - 1) // s + 1
+
+
 def _layer_array(table):
-    """table rows: (in, out, act, w_off, b_off) for Dense, or full 6+-tuples handled by the layer helpers."""
+    """table rows: Dense (in, out, act, w_off, b_off), or
+         ("conv", (kw, kh, cin, cout), (wi, hi), (sw, sh), (pw, ph), (dw, dh), act, w_off, b_off)
+         ("maxpool", (pw, ph), c, (wi, hi), (sw, sh))        ("flatten", c, (wi, hi))"""
     arr = (SiLayer * len(table))()
     for i, row in enumerate(table):
-        fin, fout, act, w_off, b_off = row[:5]
-        arr[i] = SiLayer(0, int(fin), int(fout), int(act), int(w_off), int(b_off))
+        if row[0] == "conv":
+            _, (kw, kh, cin, cout), (wi, hi), (sw, sh), (pw, ph), (dw, dh), act, w_off, b_off = row
+            wo, ho = conv_out_size(wi, kw, sw, pw, dw), conv_out_size(hi, kh, sh, ph, dh)
+            arr[i] = SiLayer(LAYER_CONV, wi * hi * cin, wo * ho * cout, int(act), int(w_off), int(b_off), kw, kh, cin, cout,
+                             wi, hi, sw, sh, pw, ph, dw, dh)
+        elif row[0] == "maxpool":
+            _, (kw, kh), c, (wi, hi), (sw, sh) = row
+            wo, ho = (wi - kw) // sw + 1, (hi - kh) // sh + 1
+            arr[i] = SiLayer(LAYER_MAXPOOL, wi * hi * c, wo * ho * c, 0, 0, 0, kw, kh, c, c, wi, hi, sw, sh, 0, 0, 1, 1)
+        elif row[0] == "flatten":
+            _, c, (wi, hi) = row
+            arr[i] = SiLayer(LAYER_FLATTEN, wi * hi * c, wi * hi * c, 0, 0, 0, 0, 0, c, c, wi, hi, 1, 1, 0, 0, 1, 1)
+        else:
+            fin, fout, act, w_off, b_off = row[:5]
+            arr[i] = SiLayer(LAYER_DENSE, int(fin), int(fout), int(act), int(w_off), int(b_off))
     return arr
 
 
@@ -288,9 +311,7 @@ class Context:
 
     # -- on-device training (f1)
     def train_setup(self, table, n, w0, x, y, batch_max, opt_kind, eta, p1=0.0, p2=0.0):
-        arr = (SiLayer * len(table))()
-        for i, (fin, fout, act, w_off, b_off) in enumerate(table):
-            arr[i] = SiLayer(0, int(fin), int(fout), int(act), int(w_off), int(b_off))
+        arr = _layer_array(table)
         x, y = _f64(x), _f64(y)
         w0 = np.ascontiguousarray(w0, dtype=np.float32)
         if w0.size != n or x.ndim != 2 or y.ndim != 2 or x.shape[1] != y.shape[1]:
@@ -357,9 +378,7 @@ class Context:
     # -- density + sampling
     def infer_setup(self, table, n, m, w_swa, p, x, y, sigma_m):
         """table: list of (in, out, act, w_off, b_off); w_swa/p None => reuse the finished construction."""
-        arr = (SiLayer * len(table))()
-        for i, (fin, fout, act, w_off, b_off) in enumerate(table):
-            arr[i] = SiLayer(0, int(fin), int(fout), int(act), int(w_off), int(b_off))
+        arr = _layer_array(table)
         x = _f64(x)
         y = _f64(y)
         if x.ndim != 2 or y.ndim != 2 or x.shape[1] != y.shape[1]:

@@ -67,9 +67,10 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
         training_loss = 0.0
         dp_rank, dp_world = dist.world() if use_dev else (0, 1)
         if use_dev:
-            table, _ = flux.layer_table(model)
+            xm, ym, in_size = flux.data_matrices(data)
+            table, _ = flux.layer_table(model, in_size)
             bmax = min(data.batchsize, data.nobs)
-            ctx.train_setup(table, n_par, flux.extract_params(ps), data.data[0], data.data[1], bmax, *dev_opt)
+            ctx.train_setup(table, n_par, flux.extract_params(ps), xm, ym, bmax, *dev_opt)
         for i in range(1, T + 1):
             if use_dev:
                 last = (i % print_freq == 0) or (i == T)
@@ -127,8 +128,8 @@ def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=10
         raise SubspaceError("%s is not available" % a)  # reference :162
     if not isinstance(in_model, flux.Chain):
         raise SubspaceError("Error: density function is not avaliable for this model")  # [sic] reference :103
-    x, y = data.data[0], data.data[1]  # split_data, src/libs.jl:75-77 (full data, not the batches)
-    table, n_par = flux.layer_table(in_model)
+    x, y, in_size = flux.data_matrices(data)  # split_data, src/libs.jl:75-77 (full data, not the batches)
+    table, n_par = flux.layer_table(in_model, in_size)
     ctx, own = _get_ctx(ctx, device)
     try:
         if W_swa is None:

@@ -21,12 +21,14 @@ SOURCES = [
     ("kernels_gemm.hip", []),
     ("kernels_gram.hip", []),
     ("kernels_bwd.hip", []),
+    ("kernels_conv.hip", []),
+    ("capi_net.hip", []),
     ("eig.cpp", ["-DSI_EIG_NS=base"]),
     ("eig.cpp", ["-DSI_EIG_NS=avx2", "-mavx2", "-mfma"], "eig_avx2"),   # same source, other ISAs (eig_dispatch.cpp chooses)
     ("eig.cpp", ["-DSI_EIG_NS=avx512", "-mavx512f", "-mavx512vl", "-mavx512dq", "-mfma"], "eig_avx512"),
     ("eig_dispatch.cpp", []),
 ]
-HEADERS = ["si_internal.h", "philox.h", "kernels_gemm.h", os.path.join("..", "..", "include", "subspace_hip.h")]
+HEADERS = ["si_internal.h", "philox.h", "kernels_gemm.h", "gemm_pipeline.h", os.path.join("..", "..", "include", "subspace_hip.h")]
 
 
 def _hipcc():

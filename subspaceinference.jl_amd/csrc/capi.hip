@@ -118,6 +118,13 @@ static void free_infer(Ctx* c) {
   dev_free(c->d_gz);
   c->g_ready = false;
   c->fuse_tail = false;
+  dev_free(c->d_Xc);
+  dev_free(c->d_wpack);
+  dev_free(c->g_scratch.bwpart);
+  dev_free(c->g_scratch.rspart);
+  dev_free(c->g_scratch.wt);
+  dev_free(c->g_scratch.dbtmp);
+  c->plan = NetPlan();
   dev_free(c->d_zcur);
   dev_free(c->d_zprop);
   dev_free(c->d_lpcur);
@@ -142,7 +149,7 @@ using namespace si;
 
 extern "C" {
 
-int32_t si_version(void) { return 100; }
+int32_t si_version(void) { return 200; }
 
 const char* si_last_error(si_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -723,28 +730,24 @@ static int32_t infer_setup_common(si_ctx* ctx, const si_layer* layers, int32_t L
     return fail(ctx, SI_ERR_INVALID, "si_infer_setup: only compute_dtype = SI_F64 (the reference's arithmetic) is implemented");
   if ((W_swa == nullptr) != (P == nullptr))
     return fail(ctx, SI_ERR_INVALID, "si_infer_setup: W_swa and P must both be given or both be NULL");
-  // model must be a Chain of Dense layers (reference throws "model_re function is not available", libs.jl:59)
-  int32_t width = in_dim;
-  int64_t maxw = 0;
+  // the Chain: Dense / Conv / MaxPool / flatten layers (anything else: the reference's "model_re function is not
+  // available for this model", libs.jl:59)
+  NetPlan plan;
+  {
+    const int32_t prc = net_plan(ctx, "si_infer_setup", layers, L, N, in_dim, out_dim, plan);
+    if (prc != SI_OK) return prc;
+  }
   int main_layer = 0;
   double main_flops = -1.0;
   for (int l = 0; l < L; ++l) {
-    const si_layer& ly = layers[l];
-    if (ly.kind != SI_LAYER_DENSE)
-      return fail(ctx, SI_ERR_INVALID, "Error: model_re function is not available for this model (only Dense layers)");
-    if (ly.in != width || ly.out <= 0 || ly.act < 0 || ly.act > SI_ACT_SIGMOID)
-      return fail(ctx, SI_ERR_INVALID, "si_infer_setup: layer dimensions do not chain");
-    if (ly.w_off < 0 || ly.b_off < 0 || ly.w_off + (int64_t)ly.in * ly.out > N || ly.b_off + ly.out > N)
-      return fail(ctx, SI_ERR_INVALID, "si_infer_setup: layer offsets outside the flat weight vector");
-    width = ly.out;
-    maxw = std::max<int64_t>(maxw, ly.out);
-    const double fl = 2.0 * ly.in * (double)ly.out;
+    const LayerPlan& q = plan.L[(size_t)l];
+    const double fl = q.kind == SI_LAYER_DENSE ? 2.0 * q.in_feat * (double)q.out_feat
+                      : q.kind == SI_LAYER_CONV ? 2.0 * q.KW * q.KH * q.C * (double)q.Co * q.Wo * q.Ho : 0.0;
     if (fl > main_flops) {
       main_flops = fl;
       main_layer = l;
     }
   }
-  if (width != out_dim) return fail(ctx, SI_ERR_INVALID, "si_infer_setup: last layer width != out_dim");
   BIND(ctx);
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   free_infer(ctx);
@@ -787,15 +790,18 @@ static int32_t infer_setup_common(si_ctx* ctx, const si_layer* layers, int32_t L
   ctx->sigma_m = sigma_m;
   ctx->main_layer = main_layer;
   // fused tail: a narrow last layer (regression heads: out = 1) is folded into the epilogue of the layer before it
-  ctx->fuse_tail = (L >= 2) && layers[L - 1].out <= SI_FUSE_MAX_OUT;
+  ctx->plan = plan;
+  ctx->fuse_tail = !plan.has_conv && (L >= 2) && layers[L - 1].out <= SI_FUSE_MAX_OUT;
   ctx->fuse_slots = ctx->fuse_tail ? dense_fused_slots(layers[L - 2].out) : 0;
   int64_t maxstored = 1;
-  for (int l = 0; l < (ctx->fuse_tail ? L - 2 : L); ++l) maxstored = std::max<int64_t>(maxstored, layers[l].out);
+  for (int l = 0; l < (ctx->fuse_tail ? L - 2 : L); ++l) maxstored = std::max<int64_t>(maxstored, plan.L[(size_t)l].out_elems);
   ctx->max_stored = maxstored;
   ctx->act_elems = pad_ld(maxstored * B);
   ctx->sse_blocks = sse_num_blocks((int64_t)out_dim * B, ctx->num_cu);
   if (dev_alloc(&ctx->d_X, (size_t)in_dim * B) != hipSuccess || dev_alloc(&ctx->d_Y, (size_t)out_dim * B) != hipSuccess ||
-      !alloc_forward(ctx, 1)) {
+      !alloc_forward(ctx, 1) ||
+      (plan.has_conv && dev_alloc(&ctx->d_wpack, plan.wpack_elems) != hipSuccess) ||
+      (plan.input_spatial && dev_alloc(&ctx->d_Xc, (size_t)plan.in_elems * B) != hipSuccess)) {
     free_infer(ctx);
     return fail(ctx, SI_ERR_NOMEM, "si_infer_setup: device allocation failed");
   }
@@ -804,6 +810,8 @@ static int32_t infer_setup_common(si_ctx* ctx, const si_layer* layers, int32_t L
     SI_HIP(ctx, hipMemcpyAsync(ctx->d_X, X, (size_t)in_dim * B * sizeof(double), kind, ctx->stream));
     SI_HIP(ctx, hipMemcpyAsync(ctx->d_Y, Y, (size_t)out_dim * B * sizeof(double), kind, ctx->stream));
   }
+  if (plan.input_spatial) net_input(ctx, plan, ctx->d_X, ctx->d_Xc, B);  // (W, H, C, N) -> channel-fastest, once
+  SI_HIP(ctx, hipGetLastError());
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->i_ready = true;
   return SI_OK;
@@ -850,6 +858,7 @@ int32_t si_construct_result_ptr(si_ctx* ctx, double** W_swa_dev_out, double** P_
 // per chain) keeps one slot.
 static constexpr double SI_BATCH_BYTES = 2.0 * 1024.0 * 1024.0 * 1024.0;
 static int batch_width(const si_ctx* ctx, int C) {
+  if (ctx->plan.has_conv) return 1;  // chains with Conv layers fill the chip one chain at a time
   const double per = 8.0 * (2.0 * (double)ctx->act_elems + ((double)ctx->fuse_slots + 1.0) * (double)ctx->out_dim * (double)ctx->B +
                             (double)pad_ld(ctx->iN) + (double)ctx->sse_blocks);
   const double fit = std::floor(SI_BATCH_BYTES / per);
@@ -895,6 +904,23 @@ static int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out
     ProfScope ps(ctx, SI_K_RECON, 2.0 * (double)N * M * dn, (double)N * (M + 1 + dn) * 8.0);
     launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, ctx->d_zprop + (size_t)c0 * M, nc, ctx->d_w, ldw,
                        ctx->num_cu);
+  }
+  if (ctx->plan.has_conv) {
+    // generic path (capi_net.hip): Conv / MaxPool / flatten / Dense layers one after the other, ping-pong activations
+    const size_t nl = ctx->plan.L.size();
+    std::vector<double*> outs(nl);
+    for (size_t l = 0; l < nl; ++l) outs[l] = ctx->d_act[l & 1];
+    const int32_t rc = net_forward(ctx, ctx->plan, ctx->d_w, ctx->plan.input_spatial ? ctx->d_Xc : ctx->d_X, B, outs.data(),
+                                   ctx->d_wpack);
+    if (rc != SI_OK) return rc;
+    const int64_t d = (int64_t)ctx->out_dim * B;
+    {
+      ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d, 16.0 * (double)d);
+      launch_sse(ctx->stream, outs[nl - 1], ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, 1, ctx->act_elems);
+    }
+    SI_HIP(ctx, hipGetLastError());
+    if (yhat_out) *yhat_out = outs[nl - 1];
+    return SI_OK;
   }
   ChainBatch cb;
   cb.n = nc;
@@ -984,6 +1010,30 @@ int32_t si_logdensity(si_ctx* ctx, const double* Z, int32_t C, double* lp_out) {
 static int32_t ensure_grad(si_ctx* ctx) {
   if (ctx->g_ready) return SI_OK;
   const int64_t B = ctx->B;
+  if (ctx->plan.has_conv) {
+    const NetPlan& p = ctx->plan;
+    size_t nb, nr, nw, nd;
+    net_scratch_sizes(p, B, ctx->num_cu, &nb, &nr, &nw, &nd);
+    ctx->d_hs.assign(p.L.size(), nullptr);
+    bool ok = true;
+    for (size_t l = 0; l < p.L.size() && ok; ++l) ok = dev_alloc(&ctx->d_hs[l], (size_t)p.L[l].out_elems * B) == hipSuccess;
+    ok = ok && dev_alloc(&ctx->d_delta[0], (size_t)p.max_elems * B) == hipSuccess &&
+         dev_alloc(&ctx->d_delta[1], (size_t)p.max_elems * B) == hipSuccess &&
+         dev_alloc(&ctx->d_gw, (size_t)pad_ld(ctx->iN)) == hipSuccess && dev_alloc(&ctx->g_scratch.bwpart, nb) == hipSuccess &&
+         dev_alloc(&ctx->g_scratch.rspart, nr) == hipSuccess && dev_alloc(&ctx->g_scratch.wt, nw) == hipSuccess &&
+         dev_alloc(&ctx->g_scratch.dbtmp, nd) == hipSuccess &&
+         dev_alloc(&ctx->d_ptgpart, (size_t)ptg_blocks() * ctx->iM) == hipSuccess && dev_alloc(&ctx->d_gz, (size_t)ctx->iM) == hipSuccess;
+    if (!ok) {
+      for (auto& h : ctx->d_hs) dev_free(h);
+      ctx->d_hs.clear();
+      dev_free(ctx->d_delta[0]); dev_free(ctx->d_delta[1]); dev_free(ctx->d_gw); dev_free(ctx->g_scratch.bwpart);
+      dev_free(ctx->g_scratch.rspart); dev_free(ctx->g_scratch.wt); dev_free(ctx->g_scratch.dbtmp); dev_free(ctx->d_ptgpart);
+      dev_free(ctx->d_gz);
+      return fail(ctx, SI_ERR_NOMEM, "si_logdensity_grad: workspace allocation failed");
+    }
+    ctx->g_ready = true;
+    return SI_OK;
+  }
   int64_t maxw = 1;
   size_t maxpart = 1;
   ctx->d_hs.assign(ctx->layers.size(), nullptr);
@@ -1030,6 +1080,35 @@ int32_t si_logdensity_grad(si_ctx* ctx, const double* z, double* lp_out, double*
   {
     ProfScope ps(ctx, SI_K_RECON, 2.0 * (double)N * M, (double)N * (M + 2) * 8.0);
     launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, ctx->d_zprop, 1, ctx->d_w, pad_ld(N), ctx->num_cu);
+  }
+  if (ctx->plan.has_conv) {
+    // generic path: forward with every output kept, d lp / d yhat = (y - yhat) / sigma^2, reverse sweep, P' g_w
+    const NetPlan& p = ctx->plan;
+    const double* xin = p.input_spatial ? ctx->d_Xc : ctx->d_X;
+    if ((rc = net_forward(ctx, p, ctx->d_w, xin, B, ctx->d_hs.data(), ctx->d_wpack)) != SI_OK) return rc;
+    const int64_t d = (int64_t)ctx->out_dim * B;
+    const double* yhat = ctx->d_hs[nl - 1];
+    launch_sse(ctx->stream, yhat, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse);
+    {
+      double bflops = 0.0;
+      for (const auto& q : p.L)
+        bflops += q.kind == SI_LAYER_DENSE ? 4.0 * (double)q.in_feat * q.out_feat * (double)B
+                  : q.kind == SI_LAYER_CONV ? 4.0 * (double)q.KW * q.KH * q.C * q.Co * (double)q.Wo * q.Ho * (double)B : 0.0;
+      ProfScope ps(ctx, SI_K_BACKWARD, bflops, 0.0);
+      SI_HIP(ctx, hipMemsetAsync(ctx->d_gw, 0, (size_t)pad_ld(N) * sizeof(double), ctx->stream));
+      launch_delta_out(ctx->stream, ctx->d_Y, yhat, d, 1.0 / s2, SI_ACT_IDENTITY, ctx->d_delta[0]);
+      if ((rc = net_backward(ctx, p, ctx->d_w, xin, B, ctx->d_hs.data(), ctx->d_delta[0], ctx->d_delta[1], ctx->d_gw,
+                             ctx->g_scratch)) != SI_OK)
+        return rc;
+      launch_ptg(ctx->stream, ctx->i_P, ctx->ldP, N, M, ctx->d_gw, ctx->d_ptgpart, ctx->d_gz);
+    }
+    SI_HIP(ctx, hipGetLastError());
+    double sse = 0.0;
+    SI_HIP(ctx, hipMemcpyAsync(&sse, ctx->d_sse, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SI_HIP(ctx, hipMemcpyAsync(grad_out, ctx->d_gz, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *lp_out = mvnormal_c0((double)d, ctx->sigma_m) - (sse / s2) / 2.0;
+    return SI_OK;
   }
   // forward with every layer's output kept for the reverse sweep.  With a narrow head (fuse_tail) the layer in front
   // of it stores its output AND feeds the head from its epilogue, so the head costs no pass over that activation.
@@ -1135,18 +1214,19 @@ int32_t si_predict(si_ctx* ctx, const double* Z, int32_t C, const double* Xnew, 
   // run the ordinary forward path on temporary data buffers sized for Bn (the density's own X, Y stay untouched);
   // like the density, up to `wb` samples share one pass of launches (grid.y), within the same workspace cap
   struct Saved {
-    double *X, *Y, *act0, *act1, *ssepart, *part, *yhat;
+    double *X, *Y, *act0, *act1, *ssepart, *part, *yhat, *Xc;
     int64_t B, act_elems;
     int sse_blocks;
-  } sv{ctx->d_X, ctx->d_Y, ctx->d_act[0], ctx->d_act[1], ctx->d_ssepart, ctx->d_part, ctx->d_yhat,
+  } sv{ctx->d_X, ctx->d_Y, ctx->d_act[0], ctx->d_act[1], ctx->d_ssepart, ctx->d_part, ctx->d_yhat, ctx->d_Xc,
        ctx->B, ctx->act_elems, ctx->sse_blocks};
   const int64_t act_elems = pad_ld(ctx->max_stored * Bn);
   const int sse_blocks = sse_num_blocks((int64_t)ctx->out_dim * Bn, ctx->num_cu);
   const size_t dB = (size_t)ctx->out_dim * (size_t)Bn;
   const double per = 8.0 * (2.0 * (double)act_elems + ((double)ctx->fuse_slots + 1.0) * (double)dB + (double)sse_blocks);
   const size_t wb = (size_t)std::max(1.0, std::min({(double)C, (double)ctx->fw_slots, std::floor(SI_BATCH_BYTES / per)}));
-  double *tX = nullptr, *tY = nullptr, *tA0 = nullptr, *tA1 = nullptr, *tS = nullptr, *tP = nullptr, *tYh = nullptr;
+  double *tX = nullptr, *tY = nullptr, *tA0 = nullptr, *tA1 = nullptr, *tS = nullptr, *tP = nullptr, *tYh = nullptr, *tXc = nullptr;
   bool ok = dev_alloc(&tX, (size_t)ctx->in_dim * Bn) == hipSuccess && dev_alloc(&tY, dB) == hipSuccess &&
+            (!ctx->plan.input_spatial || dev_alloc(&tXc, (size_t)ctx->plan.in_elems * Bn) == hipSuccess) &&
             dev_alloc(&tA0, wb * (size_t)act_elems) == hipSuccess && dev_alloc(&tA1, wb * (size_t)act_elems) == hipSuccess &&
             dev_alloc(&tS, wb * (size_t)sse_blocks) == hipSuccess &&
             (!ctx->fuse_tail || (dev_alloc(&tP, wb * (size_t)ctx->fuse_slots * dB) == hipSuccess &&
@@ -1158,7 +1238,8 @@ int32_t si_predict(si_ctx* ctx, const double* Z, int32_t C, const double* Xnew, 
     if (e == hipSuccess)
       e = hipMemcpyAsync(ctx->d_zprop, Z, (size_t)ctx->iM * C * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     ctx->d_X = tX; ctx->d_Y = tY; ctx->d_act[0] = tA0; ctx->d_act[1] = tA1; ctx->d_ssepart = tS; ctx->d_part = tP;
-    ctx->d_yhat = tYh; ctx->B = Bn; ctx->act_elems = act_elems; ctx->sse_blocks = sse_blocks;
+    ctx->d_yhat = tYh; ctx->B = Bn; ctx->act_elems = act_elems; ctx->sse_blocks = sse_blocks; ctx->d_Xc = tXc;
+    if (ctx->plan.input_spatial) net_input(ctx, ctx->plan, tX, tXc, Bn);
     for (int c0 = 0; c0 < C && e == hipSuccess && rc == SI_OK; c0 += (int)wb) {
       const int nc = std::min<int>((int)wb, C - c0);
       const double* yh = nullptr;
@@ -1173,9 +1254,10 @@ int32_t si_predict(si_ctx* ctx, const double* Z, int32_t C, const double* Xnew, 
     }
     ctx->d_X = sv.X; ctx->d_Y = sv.Y; ctx->d_act[0] = sv.act0; ctx->d_act[1] = sv.act1; ctx->d_ssepart = sv.ssepart;
     ctx->d_part = sv.part; ctx->d_yhat = sv.yhat; ctx->B = sv.B; ctx->act_elems = sv.act_elems; ctx->sse_blocks = sv.sse_blocks;
+    ctx->d_Xc = sv.Xc;
   }
   (void)hipStreamSynchronize(ctx->stream);
-  dev_free(tX); dev_free(tY); dev_free(tA0); dev_free(tA1); dev_free(tS); dev_free(tP); dev_free(tYh);
+  dev_free(tX); dev_free(tY); dev_free(tA0); dev_free(tA1); dev_free(tS); dev_free(tP); dev_free(tYh); dev_free(tXc);
   if (!ok) return fail(ctx, SI_ERR_NOMEM, "si_predict: device allocation failed");
   if (rc != SI_OK) return rc;
   if (e != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string("si_predict: ") + hipGetErrorString(e));

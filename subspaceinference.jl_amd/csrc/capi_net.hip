@@ -1,0 +1,246 @@
+// Host side of chains that contain Conv / MaxPool / flatten layers: validation of the caller's layer
+// table, the geometry every kernel launch needs, and the generic forward pass / reverse sweep over such a chain.
+// The reference's `model_re` restructures ANY Flux Chain (src/libs.jl:55-57) and `density` evaluates it on the full data
+// (src/space_inference.jl:94); pure Dense chains keep their tuned path in capi.hip / capi_train.hip (fused narrow tail,
+// chain batching) and only pass through net_plan() for validation.  No arithmetic happens on the host.
+#include <algorithm>
+
+#include "si_internal.h"
+
+namespace si {
+
+static int even(int c) { return (c + 1) & ~1; }
+static int conv_out(int wi, int k, int s, int p, int d) { return (wi + 2 * p - d * (k - 1) - 1) / s + 1; }
+
+int32_t net_plan(Ctx* c, const char* who, const si_layer* layers, int L, int64_t N, int in_dim, int out_dim, NetPlan& out) {
+  auto bad = [&](const std::string& m) { return fail(c, SI_ERR_INVALID, std::string(who) + ": " + m); };
+  NetPlan p;
+  p.L.resize((size_t)L);
+  bool spatial = false;  // inside a convolutional stack: activations are (W, H, C) images
+  int W = 0, H = 0, C = 0;
+  int feat = in_dim;
+  size_t pack = 0;
+  for (int l = 0; l < L; ++l) {
+    const si_layer& ly = layers[l];
+    LayerPlan& q = p.L[(size_t)l];
+    q.kind = ly.kind;
+    q.act = ly.act;
+    q.w_off = ly.w_off;
+    q.b_off = ly.b_off;
+    q.in_feat = ly.in;
+    q.out_feat = ly.out;
+    if (ly.in != feat || ly.out <= 0) return bad("layer dimensions do not chain");
+    if (ly.kind == SI_LAYER_DENSE) {
+      // a Dense layer on image-shaped activations without a flatten in between fails in Flux too (DimensionMismatch)
+      if (spatial) return bad("DimensionMismatch: Dense layer applied to (W, H, C, N) activations (flatten missing)");
+      if (ly.act < 0 || ly.act > SI_ACT_SIGMOID) return bad("unknown activation");
+      if (ly.w_off < 0 || ly.b_off < 0 || ly.w_off + (int64_t)ly.in * ly.out > N || ly.b_off + ly.out > N)
+        return bad("layer offsets outside the flat weight vector");
+      q.in_elems = ly.in;
+      q.out_elems = ly.out;
+      p.max_rows = std::max(p.max_rows, ly.out);
+    } else if (ly.kind == SI_LAYER_CONV || ly.kind == SI_LAYER_MAXPOOL || ly.kind == SI_LAYER_FLATTEN) {
+      p.has_conv = true;
+      if (ly.wi <= 0 || ly.hi <= 0 || ly.cin <= 0) return bad("Conv / MaxPool / flatten layer without its input geometry");
+      if (!spatial) {
+        if (l != 0) return bad("a Conv / MaxPool / flatten layer cannot follow a Dense layer (no reshape layer is supported)");
+        p.input_spatial = true;
+        p.in_W = W = ly.wi;
+        p.in_H = H = ly.hi;
+        p.in_C = C = ly.cin;
+        p.in_Cp = even(C);
+        spatial = true;
+      }
+      if (ly.wi != W || ly.hi != H || ly.cin != C || (int64_t)W * H * C != ly.in) return bad("layer geometry does not chain");
+      q.C = C;
+      q.Cp = even(C);
+      q.Wi = W;
+      q.Hi = H;
+      q.in_elems = (int64_t)q.Cp * W * H;
+      if (ly.kind == SI_LAYER_FLATTEN) {
+        if (ly.out != ly.in) return bad("flatten: in != out");
+        q.Co = C;
+        q.Cop = q.Cp;
+        q.Wo = W;
+        q.Ho = H;
+        q.out_elems = ly.out;
+        spatial = false;
+      } else {
+        if (ly.kw <= 0 || ly.kh <= 0 || ly.sw <= 0 || ly.sh <= 0) return bad("kernel / window and stride must be positive");
+        q.KW = ly.kw;
+        q.KH = ly.kh;
+        q.sw = ly.sw;
+        q.sh = ly.sh;
+        if (ly.kind == SI_LAYER_MAXPOOL) {
+          if (ly.cout != C) return bad("MaxPool: cin != cout");
+          if (ly.pw != 0 || ly.ph != 0) return bad("MaxPool: only pad = 0 (Flux's default) is implemented");
+          if (ly.kw > W || ly.kh > H) return bad("MaxPool window larger than its input");
+          q.Co = C;
+          q.Cop = q.Cp;
+          q.Wo = (W - ly.kw) / ly.sw + 1;
+          q.Ho = (H - ly.kh) / ly.sh + 1;
+        } else {
+          if (ly.act < 0 || ly.act > SI_ACT_SIGMOID) return bad("unknown activation");
+          if (ly.cout <= 0 || ly.pw < 0 || ly.ph < 0 || ly.dw <= 0 || ly.dh <= 0) return bad("Conv: bad cout / pad / dilation");
+          const int64_t nw = (int64_t)ly.kw * ly.kh * C * ly.cout;
+          if (ly.w_off < 0 || ly.b_off < 0 || ly.w_off + nw > N || ly.b_off + ly.cout > N)
+            return bad("layer offsets outside the flat weight vector");
+          q.Co = ly.cout;
+          q.Cop = even(ly.cout);
+          q.Wo = conv_out(W, ly.kw, ly.sw, ly.pw, ly.dw);
+          q.Ho = conv_out(H, ly.kh, ly.sh, ly.ph, ly.dh);
+          if (q.Wo <= 0 || q.Ho <= 0) return bad("Conv: kernel larger than the padded input");
+          q.Kp = (q.Cp * ly.kw * ly.kh + 15) / 16 * 16;
+          q.KpT = (q.Cop * ly.kw * ly.kh + 15) / 16 * 16;
+          q.wp_off = pack;
+          pack += (size_t)q.Cop * q.Kp;
+          q.bp_off = pack;
+          pack += (size_t)q.Cop;
+          pack = (pack + 1) & ~(size_t)1;  // keep every pack 16-byte aligned
+          p.wt_elems = std::max(p.wt_elems, (size_t)q.Cp * q.KpT);
+          // forward gather: patches of the INPUT tensor, positions = output pixels
+          q.g = ConvGeom{q.Cp, W, H, q.Wo, q.Ho, ly.kw, ly.kh, ly.sw, ly.sh, 1, 1, ly.pw, ly.ph, ly.dw, ly.dh,
+                         q.Cp * ly.kw * ly.kh, (int64_t)q.Cp * W * H};
+          // data gradient: patches of the DELTA tensor (Cop channels on the Wo x Ho grid), positions = input pixels,
+          // wo = (wi - (dil*(K-1) - pad) + a'*dil) / stride
+          q.gT = ConvGeom{q.Cop, q.Wo, q.Ho, W, H, ly.kw, ly.kh, 1, 1, ly.sw, ly.sh, ly.dw * (ly.kw - 1) - ly.pw,
+                          ly.dh * (ly.kh - 1) - ly.ph, ly.dw, ly.dh, q.Cop * ly.kw * ly.kh, (int64_t)q.Cop * q.Wo * q.Ho};
+          p.max_rows = std::max(p.max_rows, std::max(q.Cop, q.Cp));
+        }
+        if ((int64_t)q.Wo * q.Ho * q.Co != ly.out) return bad("layer output size does not match its geometry");
+        q.out_elems = (int64_t)q.Cop * q.Wo * q.Ho;
+        W = q.Wo;
+        H = q.Ho;
+        C = q.Co;
+      }
+    } else {
+      return fail(c, SI_ERR_INVALID, "Error: model_re function is not available for this model (unknown layer kind)");
+    }
+    feat = ly.out;
+    p.max_elems = std::max(p.max_elems, std::max(q.in_elems, q.out_elems));
+  }
+  if (spatial) return bad("the chain must end on (features x B) activations (flatten / Dense after the last Conv)");
+  if (feat != out_dim) return bad("last layer width != out_dim");
+  p.in_elems = p.input_spatial ? (int64_t)p.in_Cp * p.in_W * p.in_H : in_dim;
+  p.max_elems = std::max(p.max_elems, p.in_elems);
+  p.wpack_elems = std::max<size_t>(pack, 2);
+  out = std::move(p);
+  return SI_OK;
+}
+
+void net_input(Ctx* c, const NetPlan& p, const double* X, double* Xc, int64_t B) {
+  launch_whcn_to_cwhn(c->stream, X, Xc, p.in_W, p.in_H, p.in_C, p.in_Cp, B);
+}
+
+int32_t net_forward(Ctx* c, const NetPlan& p, const double* w, const double* xin, int64_t B, double* const* outs, double* wpack) {
+  hipStream_t st = c->stream;
+  const double* h = xin;
+  for (size_t l = 0; l < p.L.size(); ++l) {
+    const LayerPlan& q = p.L[l];
+    double* o = outs[l];
+    if ((double)std::max(q.in_elems, q.out_elems) * (double)B >= 2147483648.0)
+      return fail(c, SI_ERR_INVALID, "activation tensors of 2^31 elements or more are not supported by the conv kernels");
+    switch (q.kind) {
+      case SI_LAYER_DENSE: {
+        ProfScope ps(c, SI_K_DENSE, 2.0 * (double)q.in_feat * q.out_feat * (double)B,
+                     ((double)q.in_feat * q.out_feat + q.out_feat + (double)(q.in_feat + q.out_feat) * (double)B) * 8.0);
+        launch_dense_f64(st, w + q.w_off, w + q.b_off, h, o, q.out_feat, q.in_feat, B, q.act);
+        break;
+      }
+      case SI_LAYER_CONV: {
+        const int64_t npos = (int64_t)q.Wo * q.Ho * B;
+        {
+          ProfScope ps(c, SI_K_CONV_AUX, 0.0, ((double)q.KW * q.KH * q.C * q.Co + (double)q.Cop * q.Kp) * 8.0);
+          launch_conv_pack(st, w + q.w_off, w + q.b_off, wpack + q.wp_off, wpack + q.bp_off, q.KW, q.KH, q.C, q.Co, q.Cp, q.Cop, q.Kp);
+        }
+        ProfScope ps(c, SI_K_CONV, 2.0 * (double)q.KW * q.KH * q.C * q.Co * (double)npos,
+                     ((double)q.in_elems + (double)q.out_elems) * (double)B * 8.0 + (double)q.Cop * q.Kp * 8.0);
+        launch_conv_forward(st, wpack + q.wp_off, wpack + q.bp_off, h, o, q.g, q.Cop, q.Kp, npos, q.act);
+        break;
+      }
+      case SI_LAYER_MAXPOOL: {
+        ProfScope ps(c, SI_K_CONV_AUX, 0.0, ((double)q.in_elems + (double)q.out_elems) * (double)B * 8.0);
+        launch_maxpool(st, h, o, q.Cp, q.Wi, q.Hi, q.Wo, q.Ho, q.KW, q.KH, q.sw, q.sh, B);
+        break;
+      }
+      default: {  // flatten: channel-fastest -> the reference's (W, H, C) feature order
+        ProfScope ps(c, SI_K_CONV_AUX, 0.0, ((double)q.in_elems + (double)q.out_elems) * (double)B * 8.0);
+        launch_cwhn_to_whcn(st, h, o, q.Wi, q.Hi, q.C, q.Cp, B);
+        break;
+      }
+    }
+    h = o;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, SI_ERR_HIP, std::string("net_forward: ") + hipGetErrorString(e));
+  return SI_OK;
+}
+
+void net_scratch_sizes(const NetPlan& p, int64_t B, int num_cu, size_t* bwpart, size_t* rspart, size_t* wt, size_t* dbtmp) {
+  size_t part = 1;
+  for (const LayerPlan& q : p.L) {
+    int64_t ks;
+    if (q.kind == SI_LAYER_DENSE) {
+      const int ns = backward_weight_splits(q.out_feat, q.in_feat, B, num_cu, &ks);
+      part = std::max(part, (size_t)ns * q.out_feat * q.in_feat);
+    } else if (q.kind == SI_LAYER_CONV) {
+      const int ns = conv_dw_splits(q.Cop, q.Kp, (int64_t)q.Wo * q.Ho * B, num_cu, &ks);
+      part = std::max(part, (size_t)ns * q.Cop * q.Kp);
+    }
+  }
+  *bwpart = part;
+  *rspart = (size_t)rowsum_chunks() * (size_t)p.max_rows;
+  *wt = p.wt_elems;
+  *dbtmp = (size_t)p.max_rows;
+}
+
+int32_t net_backward(Ctx* c, const NetPlan& p, const double* w, const double* xin, int64_t B, double* const* hs, double* g0,
+                     double* g1, double* gw, const NetScratch& s) {
+  hipStream_t st = c->stream;
+  double* g = g0;      // gradient with respect to the OUTPUT of the layer being processed (device layout)
+  double* gn = g1;
+  for (size_t li = p.L.size(); li-- > 0;) {
+    const LayerPlan& q = p.L[li];
+    const double* hin = li > 0 ? hs[li - 1] : xin;
+    const double* hout = hs[li];
+    switch (q.kind) {
+      case SI_LAYER_DENSE: {
+        launch_mul_dact(st, g, hout, (int64_t)q.out_feat * B, q.act, g);                 // Delta = g .* act'(h)
+        launch_rowsum(st, g, q.out_feat, B, s.rspart, gw + q.b_off);                     // db
+        int64_t ks;
+        const int ns = backward_weight_splits(q.out_feat, q.in_feat, B, c->num_cu, &ks);
+        launch_backward_weight(st, g, hin, s.bwpart, q.out_feat, q.in_feat, B, ns, ks, c->num_cu);
+        launch_split_reduce(st, s.bwpart, ns, (int64_t)q.out_feat * q.in_feat, gw + q.w_off);   // dW
+        if (li > 0) launch_backward_data(st, w + q.w_off, g, hin, gn, q.out_feat, q.in_feat, B, SI_ACT_IDENTITY);  // W' Delta
+        break;
+      }
+      case SI_LAYER_FLATTEN:
+        launch_whcn_to_cwhn(st, g, gn, q.Wi, q.Hi, q.C, q.Cp, B);   // back to channel-fastest, pad channels zero
+        break;
+      case SI_LAYER_MAXPOOL:
+        launch_maxpool_bwd(st, hin, hout, g, gn, q.Cp, q.Wi, q.Hi, q.Wo, q.Ho, q.KW, q.KH, q.sw, q.sh, B);
+        break;
+      default: {  // Conv
+        const int64_t npos = (int64_t)q.Wo * q.Ho * B;
+        launch_mul_dact(st, g, hout, (int64_t)q.Cop * npos, q.act, g);
+        launch_rowsum(st, g, q.Cop, npos, s.rspart, s.dbtmp);
+        (void)hipMemcpyAsync(gw + q.b_off, s.dbtmp, (size_t)q.Co * sizeof(double), hipMemcpyDeviceToDevice, st);
+        int64_t ks;
+        const int ns = conv_dw_splits(q.Cop, q.Kp, npos, c->num_cu, &ks);
+        launch_conv_backward_weight(st, g, hin, s.bwpart, q.g, q.Cop, q.Kp, npos, ns, ks);
+        launch_conv_unpack_dw(st, s.bwpart, ns, gw + q.w_off, q.KW, q.KH, q.C, q.Co, q.Cp, q.Cop, q.Kp);
+        if (li > 0) {
+          launch_conv_pack_t(st, w + q.w_off, s.wt, q.KW, q.KH, q.C, q.Co, q.Cp, q.Cop, q.KpT);
+          launch_conv_backward_data(st, s.wt, g, gn, q.gT, q.Cp, q.KpT, (int64_t)q.Wi * q.Hi * B);
+        }
+        break;
+      }
+    }
+    std::swap(g, gn);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, SI_ERR_HIP, std::string("net_backward: ") + hipGetErrorString(e));
+  return SI_OK;
+}
+
+}  // namespace si

@@ -76,7 +76,8 @@ void free_train(Ctx* c) {
   if (!t) return;
   release(t->X); release(t->Y); release(t->Xb); release(t->Yb); release(t->idx); release(t->w32); release(t->m32);
   release(t->v32); release(t->w64); release(t->gw); release(t->delta[0]); release(t->delta[1]); release(t->bwpart);
-  release(t->rspart); release(t->ssepart); release(t->sse); release(t->part);
+  release(t->rspart); release(t->ssepart); release(t->sse); release(t->part); release(t->Xc); release(t->wpack);
+  release(t->scratch.bwpart); release(t->scratch.rspart); release(t->scratch.wt); release(t->scratch.dbtmp);
   for (auto& h : t->hs) release(h);
   delete t;
   c->train = nullptr;
@@ -95,22 +96,24 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
   if (!layers || L <= 0 || N <= 0 || !w0 || !X || !Y || in_dim <= 0 || out_dim <= 0 || B_total <= 0 || batch_max <= 0 ||
       batch_max > B_total || opt_kind < 0 || opt_kind > 2)
     return fail(ctx, SI_ERR_INVALID, "si_train_setup: bad argument");
-  int32_t width = in_dim;
-  int64_t maxw = 1;
-  size_t maxpart = 1;
-  for (int l = 0; l < L; ++l) {
-    const si_layer& ly = layers[l];
-    if (ly.kind != SI_LAYER_DENSE || ly.in != width || ly.out <= 0 || ly.act < 0 || ly.act > SI_ACT_SIGMOID ||
-        ly.w_off < 0 || ly.b_off < 0 || ly.w_off + (int64_t)ly.in * ly.out > N || ly.b_off + ly.out > N)
-      return fail(ctx, SI_ERR_INVALID, "Error: model_re function is not available for this model (Dense chain expected)");
-    width = ly.out;
-    maxw = std::max<int64_t>(maxw, ly.out);
-    int64_t ks;
-    const int ns = backward_weight_splits(ly.out, ly.in, batch_max, ctx->num_cu, &ks);
-    maxpart = std::max(maxpart, (size_t)ns * ly.out * ly.in);
+  NetPlan plan;
+  {
+    const int32_t prc = net_plan(ctx, "si_train_setup", layers, L, N, in_dim, out_dim, plan);
+    if (prc != SI_OK) return prc;
   }
-  if (width != out_dim) return fail(ctx, SI_ERR_INVALID, "si_train_setup: last layer width != out_dim");
-  const bool fuse_tail = (L >= 2) && layers[L - 1].out <= SI_FUSE_MAX_OUT;
+  int64_t maxw = plan.max_elems;
+  size_t maxpart = 1;
+  if (!plan.has_conv) {
+    maxw = 1;
+    for (int l = 0; l < L; ++l) {
+      const si_layer& ly = layers[l];
+      maxw = std::max<int64_t>(maxw, ly.out);
+      int64_t ks;
+      const int ns = backward_weight_splits(ly.out, ly.in, batch_max, ctx->num_cu, &ks);
+      maxpart = std::max(maxpart, (size_t)ns * ly.out * ly.in);
+    }
+  }
+  const bool fuse_tail = !plan.has_conv && (L >= 2) && layers[L - 1].out <= SI_FUSE_MAX_OUT;
   if (fuse_tail) maxpart = std::max(maxpart, tail_bwd_part_elems(layers[L - 1].out, layers[L - 1].in));
   SI_HIP(ctx, hipSetDevice(ctx->device));
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -124,7 +127,13 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
   t->fuse_tail = fuse_tail;
   t->fuse_slots = fuse_tail ? dense_fused_slots(layers[L - 2].out) : 0;
   t->hs.assign((size_t)L, nullptr);
-  bool ok = alloc(&t->X, (size_t)in_dim * B_total) && alloc(&t->Y, (size_t)out_dim * B_total) &&
+  t->plan = plan;
+  size_t nb = 1, nr = 1, nw = 1, nd = 1;
+  if (plan.has_conv) net_scratch_sizes(plan, batch_max, ctx->num_cu, &nb, &nr, &nw, &nd);
+  bool ok = (!plan.has_conv || (alloc(&t->wpack, plan.wpack_elems) && alloc(&t->scratch.bwpart, nb) && alloc(&t->scratch.rspart, nr) &&
+                                alloc(&t->scratch.wt, nw) && alloc(&t->scratch.dbtmp, nd))) &&
+            (!plan.input_spatial || alloc(&t->Xc, (size_t)plan.in_elems * batch_max)) &&
+            alloc(&t->X, (size_t)in_dim * B_total) && alloc(&t->Y, (size_t)out_dim * B_total) &&
             alloc(&t->Xb, (size_t)in_dim * batch_max) && alloc(&t->Yb, (size_t)out_dim * batch_max) &&
             alloc(&t->idx, (size_t)batch_max) && alloc(&t->w32, (size_t)N) && alloc(&t->m32, (size_t)N) &&
             alloc(&t->v32, (size_t)N) && alloc(&t->w64, (size_t)pad_ld(N)) && alloc(&t->gw, (size_t)pad_ld(N)) &&
@@ -132,7 +141,7 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
             alloc(&t->bwpart, maxpart) && alloc(&t->rspart, (size_t)rowsum_chunks() * maxw) &&
             alloc(&t->ssepart, (size_t)t->sse_blocks) && alloc(&t->sse, 1) &&
             (!fuse_tail || alloc(&t->part, (size_t)t->fuse_slots * out_dim * batch_max));
-  for (int l = 0; l < L && ok; ++l) ok = alloc(&t->hs[(size_t)l], (size_t)layers[l].out * batch_max);
+  for (int l = 0; l < L && ok; ++l) ok = alloc(&t->hs[(size_t)l], (size_t)plan.L[(size_t)l].out_elems * batch_max);
   if (!ok) {
     free_train(ctx);
     return fail(ctx, SI_ERR_NOMEM, "si_train_setup: device allocation failed");
@@ -168,6 +177,27 @@ static int32_t train_gradient(si_ctx* ctx, const char* who, const int64_t* idx, 
   hipLaunchKernelGGL(gather_cols_kernel, dim3(grid_for((int64_t)t->out_dim * nb, ctx->num_cu)), dim3(256), 0, st, t->Y,
                      t->out_dim, t->idx, nb, t->Yb);
   hipLaunchKernelGGL(widen_kernel, dim3(grid_for(N, ctx->num_cu)), dim3(256), 0, st, t->w32, N, t->w64);
+  if (t->plan.has_conv) {
+    // chains with Conv / MaxPool / flatten layers: the generic forward / reverse sweep of capi_net.hip
+    const NetPlan& p = t->plan;
+    const double* xin = t->Xb;
+    if (p.input_spatial) {
+      net_input(ctx, p, t->Xb, t->Xc, nb);
+      xin = t->Xc;
+    }
+    int32_t rc = net_forward(ctx, p, t->w64, xin, nb, t->hs.data(), t->wpack);
+    if (rc != SI_OK) return rc;
+    const int64_t d = (int64_t)t->out_dim * nb;
+    const double* yhat = t->hs[nl - 1];
+    launch_sse(st, yhat, t->Yb, d, t->ssepart, sse_num_blocks(d, ctx->num_cu), t->sse);
+    ProfScope ps(ctx, SI_K_BACKWARD, 0.0, 0.0);
+    SI_HIP(ctx, hipMemsetAsync(t->gw, 0, (size_t)pad_ld(N) * sizeof(double), st));
+    launch_delta_out(st, t->Yb, yhat, d, -2.0 / d_total, SI_ACT_IDENTITY, t->delta[0]);   // d mse / d yhat = 2 (yhat - y) / d
+    if ((rc = net_backward(ctx, p, t->w64, xin, nb, t->hs.data(), t->delta[0], t->delta[1], t->gw, t->scratch)) != SI_OK) return rc;
+    SI_HIP(ctx, hipGetLastError());
+    t->grad_ready = true;
+    return SI_OK;
+  }
   // forward with every layer's output kept; a narrow head is fed from the epilogue of the layer in front of it
   const double* h = t->Xb;
   const size_t nplain = t->fuse_tail ? nl - 2 : nl;

@@ -1,0 +1,278 @@
+// The fp64 MFMA GEMM pipeline shared by the reverse-sweep kernels (kernels_bwd.hip) and the implicit-GEMM convolution
+// kernels (kernels_conv.hip): 8 waves, 16-deep k tiles, two LDS buffers, ONE barrier per tile, the MFMAs of a tile split
+// around its LDS / global traffic (same schedule as the forward kernel, kernels_gemm.hip), v_mfma_f64_16x16x4_f64.
+//
+// An operand is described by a STAGER type: it owns the global -> register -> LDS path of one operand tile
+// (R rows x 16 k values per k tile) and leaves one of two LDS images, both conflict-free for the ds_read_b64 operand reads:
+//   LAY = 0 "row-fast"  X[r + ld*k]  -> LDS [k][R+16]          LAY = 1 "k-fast"  X[k + ld*r] -> LDS [r][18]
+// Interface: static LAY, LDS_ELEMS, RP, KP;  load(kt), store(dst), load_edge(kt, klen), store_edge(dst, kt, klen).
+// `Stager` below reads a plain matrix; kernels_conv.hip adds stagers that gather im2col patches on the fly.
+#pragma once
+#include <type_traits>
+
+#include "kernels_gemm.h"
+
+namespace si {
+
+// one operand tile: R rows (feature / batch index) x 16 k values
+template <int R, int LAY_, int NT, bool VEC>
+struct Stager {
+  static constexpr int LAY = LAY_;
+  static constexpr int E = VEC ? 2 : 1;
+  static constexpr int NREG = (16 * R + NT * E - 1) / (NT * E);
+  static constexpr int RP = R + 16, KP = 18;
+  static constexpr int LDS_ELEMS = LAY == 0 ? 16 * RP : R * KP;
+  int go[NREG], lds[NREG], kk[NREG];
+  bool live[NREG];
+  double reg[NREG][E];
+  const double* base;
+  int64_t ld;
+
+  __device__ __forceinline__ void init(const double* X, int64_t ld_, int64_t r0, int64_t rmax, int64_t k0, int tid) {
+    ld = ld_;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      const int idx = (tid + NT * r) * E;
+      if constexpr (LAY == 0) {
+        const int rr = idx % R, k = idx / R;
+        int64_t g = r0 + rr;
+        if (g > rmax - E) g = rmax - E;  // clamped rows only feed outputs that are never stored
+        if (g < 0) g = 0;
+        kk[r] = k;
+        live[r] = k < 16;
+        go[r] = (int)(g - r0) + (int)ld * (k < 16 ? k : 0);
+        lds[r] = k * RP + rr;
+      } else {
+        const int k = idx & 15, rr = idx >> 4;
+        int64_t g = r0 + (rr < R ? rr : 0);
+        if (g > rmax - 1) g = rmax - 1;
+        kk[r] = k;
+        live[r] = rr < R;
+        go[r] = (int)(g - r0) * (int)ld + k;
+        lds[r] = rr * KP + k;
+      }
+    }
+    base = LAY == 0 ? X + r0 + ld * k0 : X + ld * r0 + k0;
+  }
+  // Hot path (every k tile but a ragged last one): loop-invariant per-thread offsets from a block-uniform pointer, no
+  // clamps, no selects -- one address add per load and a bare ds_write per store, like the forward kernel.  (With the
+  // edge logic inline the 16-deep tile cost ~60 VALU instructions per wave next to its 24 MFMAs, and the split-K weight
+  // gradient ran at 51 TFLOP/s.)
+  __device__ __forceinline__ void load(int kt) {
+    const double* p = base + (LAY == 0 ? ld * 16 : (int64_t)16) * kt;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      if constexpr (VEC) {
+        const double2 v = *reinterpret_cast<const double2*>(p + go[r]);
+        reg[r][0] = v.x;
+        reg[r][1] = v.y;
+      } else {
+        reg[r][0] = p[go[r]];
+      }
+    }
+  }
+  __device__ __forceinline__ void store(double* dst) const {
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      if (!live[r]) continue;
+      if constexpr (VEC)
+        *reinterpret_cast<double2*>(dst + lds[r]) = make_double2(reg[r][0], reg[r][1]);
+      else
+        dst[lds[r]] = reg[r][0];
+    }
+  }
+  // Ragged last tile (klen % 16 != 0): k indices past the end are clamped to a legal address and zero-filled in LDS
+  // (they would add into valid outputs).  klen_total = k values of this block's split.
+  __device__ __forceinline__ void load_edge(int kt, int64_t klen_total) {
+    const double* p = base + (LAY == 0 ? ld * 16 : (int64_t)16) * kt;
+    const int64_t kmax = klen_total - (LAY == 1 ? E : 1) - (int64_t)kt * 16;  // last legal k (pair start) in this tile
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      int o = go[r];
+      if (kk[r] > kmax) o -= (int)(LAY == 0 ? ld : 1) * (int)(kk[r] - (kmax > 0 ? kmax : 0));
+      if constexpr (VEC) {
+        const double2 v = *reinterpret_cast<const double2*>(p + o);
+        reg[r][0] = v.x;
+        reg[r][1] = v.y;
+      } else {
+        reg[r][0] = p[o];
+      }
+    }
+  }
+  __device__ __forceinline__ void store_edge(double* dst, int kt, int64_t klen_total) const {
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      if (!live[r]) continue;
+      const bool ok = (int64_t)kt * 16 + kk[r] < klen_total;
+      if constexpr (VEC)
+        *reinterpret_cast<double2*>(dst + lds[r]) = make_double2(ok ? reg[r][0] : 0.0, ok ? reg[r][1] : 0.0);
+      else
+        dst[lds[r]] = ok ? reg[r][0] : 0.0;
+    }
+  }
+};
+
+// acc[a][b] += sum over the nk k tiles the two stagers deliver (klen = k values of this block's range; only the last tile
+// may be ragged).  smem: [2][SA::LDS_ELEMS] then [2][SB::LDS_ELEMS].  wm / wn: this wave's position in the WM x WN grid.
+template <int BM, int BN, int WM, int WN, class SA, class SB>
+__device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, double* smem, int nk, int64_t klen, int wm, int wn, int lane,
+                                              d4 (&acc)[BM / WM / 16][BN / WN / 16], int dbg) {
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int ALAY = SA::LAY, BLAY = SB::LAY;
+  double* sAbuf = smem;
+  double* sBbuf = smem + 2 * SA::LDS_ELEMS;
+  const int q = lane >> 4, c = lane & 15;
+  double fa[2][TM], fb[2][TN];
+  const int aw = wm * (BM / WM) + c, bw = wn * (BN / WN) + c;
+  const double* pa0 = sAbuf + (ALAY == 0 ? q * SA::RP + aw : aw * SA::KP + q);
+  const double* pb0 = sBbuf + (BLAY == 0 ? q * SB::RP + bw : bw * SB::KP + q);
+  auto read_frags = [&](auto BUF, auto S, auto SET) {
+    constexpr int buf = decltype(BUF)::value, s = decltype(S)::value, set = decltype(SET)::value;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+      fa[set][a] = pa0[buf * SA::LDS_ELEMS + (ALAY == 0 ? 4 * s * SA::RP + a * 16 : a * 16 * SA::KP + 4 * s)];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+      fb[set][b] = pb0[buf * SB::LDS_ELEMS + (BLAY == 0 ? 4 * s * SB::RP + b * 16 : b * 16 * SB::KP + 4 * s)];
+  };
+  auto mfma_half = [&](auto SET, auto HALF) {
+    constexpr int set = decltype(SET)::value, half = decltype(HALF)::value;
+    constexpr int lo = half == 0 ? 0 : (TM * TN) / 2, hi = half == 0 ? (TM * TN) / 2 : TM * TN;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int t = lo; t < hi; ++t) {
+      const int a = t / TN, b = t % TN;
+      acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[set][b], fa[set][a], acc[a][b], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  // only the last tile of a split can be ragged; the choice is block-uniform (a scalar branch)
+  const int edge_kt = (klen & 15) ? nk - 1 : -1;
+  auto load_tile = [&](int kt) {
+    if (kt == edge_kt) {
+      sa.load_edge(kt, klen);
+      sb.load_edge(kt, klen);
+    } else {
+      sa.load(kt);
+      sb.load(kt);
+    }
+  };
+  auto store_tile = [&](auto BUF, int kt) {
+    constexpr int buf = decltype(BUF)::value;
+    if (kt == edge_kt) {
+      sa.store_edge(sAbuf + buf * SA::LDS_ELEMS, kt, klen);
+      sb.store_edge(sBbuf + buf * SB::LDS_ELEMS, kt, klen);
+    } else {
+      sa.store(sAbuf + buf * SA::LDS_ELEMS);
+      sb.store(sBbuf + buf * SB::LDS_ELEMS);
+    }
+  };
+  // same pipeline as the forward kernel (kernels_gemm.hip tile_body): [half the MFMAs][LDS / global traffic][other half]
+  auto tile_body = [&](auto BUF, auto NBUF, int kt) {
+    mfma_half(I0{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(BUF, I1{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(I0{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+
+    mfma_half(I1{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(BUF, I2{}, I0{});
+    if (kt + 1 < nk) store_tile(NBUF, kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(I1{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+
+    mfma_half(I0{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(BUF, I3{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(I0{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+
+    mfma_half(I1{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (kt + 1 < nk) read_frags(NBUF, I0{}, I0{});
+    if (kt + 2 < nk && !(dbg & 2)) load_tile(kt + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(I1{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  load_tile(0);
+  store_tile(I0{}, 0);
+  if (nk > 1) load_tile(1);
+  __syncthreads();
+  read_frags(I0{}, I0{}, I0{});
+  for (int kt = 0; kt < nk; kt += 2) {
+    tile_body(I0{}, I1{}, kt);
+    if (kt + 1 < nk) tile_body(I1{}, I0{}, kt + 1);
+  }
+
+}
+
+// Store the accumulators of a block: C[m + ldc*n] = f(acc, offset, m).  MFMA output is D[n = q + 4r][m = c] per 16 x 16
+// tile; with VEC (even Mrows / ldc, 16-B aligned C) the tile is transposed through the idle staging LDS so that every
+// store instruction writes 16 B per lane over whole rows of C.  SMEM_ELEMS = doubles of staging LDS available.
+// f(value, element offset, m) -> value is applied per element (bias + activation, act' factor, ...).
+template <int BM, int BN, int WM, int WN, bool VEC, int SMEM_ELEMS, class F>
+__device__ __forceinline__ void gemm_epilogue(d4 (&acc)[BM / WM / 16][BN / WN / 16], double* smem, double* __restrict__ Cout,
+                                              int64_t ldc, int m0, int64_t n0, int Mrows, int64_t Ncols, int wm, int wn, int lane,
+                                              int wave, F f) {
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int WI = BM / WM;
+  constexpr bool WIDE = VEC && (64 % (WI / 2) == 0) && (WM * WN * 16 * WI <= SMEM_ELEMS);
+  const int q = lane >> 4, c = lane & 15;
+  const int mw0 = m0 + wm * WI;
+  const int64_t nw0 = n0 + wn * (BN / WN);
+  if constexpr (WIDE) {
+    constexpr int CH_ROW = WI / 2, NCH = 16 * CH_ROW / 64;
+    double* reg = smem + wave * (16 * WI);
+    __syncthreads();  // all waves are done with the staging buffers (the loop's last barrier precedes the last reads)
+#pragma unroll
+    for (int bt = 0; bt < TN; ++bt) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) reg[(q + 4 * r) * WI + a * 16 + c] = acc[a][bt][r];
+#pragma unroll
+      for (int p = 0; p < NCH; ++p) {
+        const int chunk = p * 64 + lane;
+        const int row = chunk / CH_ROW, col2 = chunk % CH_ROW;
+        double2 v = *reinterpret_cast<const double2*>(reg + 2 * chunk);
+        const int gm = mw0 + 2 * col2;
+        const int64_t gn = nw0 + bt * 16 + row;
+        if (gm + 1 < Mrows && gn < Ncols) {
+          const int64_t off = gm + ldc * gn;
+          v.x = f(v.x, off, gm);
+          v.y = f(v.y, off + 1, gm + 1);
+          *reinterpret_cast<double2*>(Cout + off) = v;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int gm = mw0 + a * 16 + c;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t gn = nw0 + b * 16 + q + 4 * r;
+          if (gm < Mrows && gn < Ncols) {
+            const int64_t off = gm + ldc * gn;
+            Cout[off] = f(acc[a][b][r], off, gm);
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace si

@@ -16,9 +16,8 @@
 //   layout 0 "row-fast": X[r + ld*k]  -> LDS [k][R+16]      layout 1 "k-fast": X[k + ld*r] -> LDS [r][18]
 // Both LDS images give conflict-free ds_read_b64 operand reads (same bank arithmetic as the forward kernel).
 #include <algorithm>
-#include <type_traits>
 
-#include "kernels_gemm.h"
+#include "gemm_pipeline.h"
 
 namespace si {
 
@@ -38,103 +37,6 @@ __device__ __forceinline__ double dact_from_output(double h, int act) {
   }
 }
 
-// one operand tile: R rows (feature / batch index) x 16 k values
-template <int R, int LAY, int NT, bool VEC>
-struct Stager {
-  static constexpr int E = VEC ? 2 : 1;
-  static constexpr int NREG = (16 * R + NT * E - 1) / (NT * E);
-  static constexpr int RP = R + 16, KP = 18;
-  static constexpr int LDS_ELEMS = LAY == 0 ? 16 * RP : R * KP;
-  int go[NREG], lds[NREG], kk[NREG];
-  bool live[NREG];
-  double reg[NREG][E];
-  const double* base;
-  int64_t ld;
-
-  __device__ __forceinline__ void init(const double* X, int64_t ld_, int64_t r0, int64_t rmax, int64_t k0, int tid) {
-    ld = ld_;
-#pragma unroll
-    for (int r = 0; r < NREG; ++r) {
-      const int idx = (tid + NT * r) * E;
-      if constexpr (LAY == 0) {
-        const int rr = idx % R, k = idx / R;
-        int64_t g = r0 + rr;
-        if (g > rmax - E) g = rmax - E;  // clamped rows only feed outputs that are never stored
-        if (g < 0) g = 0;
-        kk[r] = k;
-        live[r] = k < 16;
-        go[r] = (int)(g - r0) + (int)ld * (k < 16 ? k : 0);
-        lds[r] = k * RP + rr;
-      } else {
-        const int k = idx & 15, rr = idx >> 4;
-        int64_t g = r0 + (rr < R ? rr : 0);
-        if (g > rmax - 1) g = rmax - 1;
-        kk[r] = k;
-        live[r] = rr < R;
-        go[r] = (int)(g - r0) * (int)ld + k;
-        lds[r] = rr * KP + k;
-      }
-    }
-    base = LAY == 0 ? X + r0 + ld * k0 : X + ld * r0 + k0;
-  }
-  // Hot path (every k tile but a ragged last one): loop-invariant per-thread offsets from a block-uniform pointer, no
-  // clamps, no selects -- one address add per load and a bare ds_write per store, like the forward kernel.  (With the
-  // edge logic inline the 16-deep tile cost ~60 VALU instructions per wave next to its 24 MFMAs, and the split-K weight
-  // gradient ran at 51 TFLOP/s.)
-  __device__ __forceinline__ void load(int kt) {
-    const double* p = base + (LAY == 0 ? ld * 16 : (int64_t)16) * kt;
-#pragma unroll
-    for (int r = 0; r < NREG; ++r) {
-      if constexpr (VEC) {
-        const double2 v = *reinterpret_cast<const double2*>(p + go[r]);
-        reg[r][0] = v.x;
-        reg[r][1] = v.y;
-      } else {
-        reg[r][0] = p[go[r]];
-      }
-    }
-  }
-  __device__ __forceinline__ void store(double* dst) const {
-#pragma unroll
-    for (int r = 0; r < NREG; ++r) {
-      if (!live[r]) continue;
-      if constexpr (VEC)
-        *reinterpret_cast<double2*>(dst + lds[r]) = make_double2(reg[r][0], reg[r][1]);
-      else
-        dst[lds[r]] = reg[r][0];
-    }
-  }
-  // Ragged last tile (klen % 16 != 0): k indices past the end are clamped to a legal address and zero-filled in LDS
-  // (they would add into valid outputs).  klen_total = k values of this block's split.
-  __device__ __forceinline__ void load_edge(int kt, int64_t klen_total) {
-    const double* p = base + (LAY == 0 ? ld * 16 : (int64_t)16) * kt;
-    const int64_t kmax = klen_total - (LAY == 1 ? E : 1) - (int64_t)kt * 16;  // last legal k (pair start) in this tile
-#pragma unroll
-    for (int r = 0; r < NREG; ++r) {
-      int o = go[r];
-      if (kk[r] > kmax) o -= (int)(LAY == 0 ? ld : 1) * (int)(kk[r] - (kmax > 0 ? kmax : 0));
-      if constexpr (VEC) {
-        const double2 v = *reinterpret_cast<const double2*>(p + o);
-        reg[r][0] = v.x;
-        reg[r][1] = v.y;
-      } else {
-        reg[r][0] = p[o];
-      }
-    }
-  }
-  __device__ __forceinline__ void store_edge(double* dst, int kt, int64_t klen_total) const {
-#pragma unroll
-    for (int r = 0; r < NREG; ++r) {
-      if (!live[r]) continue;
-      const bool ok = (int64_t)kt * 16 + kk[r] < klen_total;
-      if constexpr (VEC)
-        *reinterpret_cast<double2*>(dst + lds[r]) = make_double2(ok ? reg[r][0] : 0.0, ok ? reg[r][1] : 0.0);
-      else
-        dst[lds[r]] = ok ? reg[r][0] : 0.0;
-    }
-  }
-};
-
 // C[m + ldc*n] (+ epilogue) = sum_k A(m,k) * B(k,n) over k in [k0, k0+klen) of split blockIdx.y
 template <int BM, int BN, int WM, int WN, int MINW, int ALAY, int BLAY, bool VEC, int EPI>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_f64_kernel(
@@ -146,8 +48,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_f64_kernel(
   using SA = Stager<BM, ALAY, NT, VEC>;
   using SB = Stager<BN, BLAY, NT, VEC>;
   extern __shared__ double smem[];
-  double* sAbuf = smem;                           // [2][SA::LDS_ELEMS]
-  double* sBbuf = smem + 2 * SA::LDS_ELEMS;       // [2][SB::LDS_ELEMS]
 
   // nNt >= 8: XCD-grouped map of the forward kernel (the nMt row tiles of one column panel share an XCD's L2).
   // nNt < 8 (weight gradients of narrow layers): that map would leave XCDs empty (measured: a 960x128 dW on ONE XCD,
@@ -177,8 +77,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_f64_kernel(
   const int wm = wave % WM, wn = wave / WM;
   const int m0 = mt * BM;
   const int64_t n0 = nt * BN;
-  const int q = lane >> 4, c = lane & 15;
-
   d4 acc[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -198,152 +96,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_f64_kernel(
 #endif
   const int nk = (int)((klen + 15) / 16);
 
-  double fa[2][TM], fb[2][TN];
-  const int aw = wm * (BM / WM) + c, bw = wn * (BN / WN) + c;
-  const double* pa0 = sAbuf + (ALAY == 0 ? q * SA::RP + aw : aw * SA::KP + q);
-  const double* pb0 = sBbuf + (BLAY == 0 ? q * SB::RP + bw : bw * SB::KP + q);
-  auto read_frags = [&](auto BUF, auto S, auto SET) {
-    constexpr int buf = decltype(BUF)::value, s = decltype(S)::value, set = decltype(SET)::value;
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-      fa[set][a] = pa0[buf * SA::LDS_ELEMS + (ALAY == 0 ? 4 * s * SA::RP + a * 16 : a * 16 * SA::KP + 4 * s)];
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-      fb[set][b] = pb0[buf * SB::LDS_ELEMS + (BLAY == 0 ? 4 * s * SB::RP + b * 16 : b * 16 * SB::KP + 4 * s)];
-  };
-  auto mfma_half = [&](auto SET, auto HALF) {
-    constexpr int set = decltype(SET)::value, half = decltype(HALF)::value;
-    constexpr int lo = half == 0 ? 0 : (TM * TN) / 2, hi = half == 0 ? (TM * TN) / 2 : TM * TN;
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int t = lo; t < hi; ++t) {
-      const int a = t / TN, b = t % TN;
-      acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[set][b], fa[set][a], acc[a][b], 0, 0, 0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  using I3 = std::integral_constant<int, 3>;
-  // only the last tile of a split can be ragged; the choice is block-uniform (a scalar branch)
-  const int edge_kt = (klen & 15) ? nk - 1 : -1;
-  auto load_tile = [&](int kt) {
-    if (kt == edge_kt) {
-      sa.load_edge(kt, klen);
-      sb.load_edge(kt, klen);
-    } else {
-      sa.load(kt);
-      sb.load(kt);
-    }
-  };
-  auto store_tile = [&](auto BUF, int kt) {
-    constexpr int buf = decltype(BUF)::value;
-    if (kt == edge_kt) {
-      sa.store_edge(sAbuf + buf * SA::LDS_ELEMS, kt, klen);
-      sb.store_edge(sBbuf + buf * SB::LDS_ELEMS, kt, klen);
-    } else {
-      sa.store(sAbuf + buf * SA::LDS_ELEMS);
-      sb.store(sBbuf + buf * SB::LDS_ELEMS);
-    }
-  };
-  // same pipeline as the forward kernel (kernels_gemm.hip tile_body): [half the MFMAs][LDS / global traffic][other half]
-  auto tile_body = [&](auto BUF, auto NBUF, int kt) {
-    mfma_half(I0{}, I0{});
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(BUF, I1{}, I1{});
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_half(I0{}, I1{});
-    __builtin_amdgcn_sched_barrier(0);
+  gemm_mainloop<BM, BN, WM, WN>(sa, sb, smem, nk, klen, wm, wn, lane, acc, dbg);
 
-    mfma_half(I1{}, I0{});
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(BUF, I2{}, I0{});
-    if (kt + 1 < nk) store_tile(NBUF, kt + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_half(I1{}, I1{});
-    __builtin_amdgcn_sched_barrier(0);
-
-    mfma_half(I0{}, I0{});
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(BUF, I3{}, I1{});
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_half(I0{}, I1{});
-    __builtin_amdgcn_sched_barrier(0);
-
-    mfma_half(I1{}, I0{});
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    if (kt + 1 < nk) read_frags(NBUF, I0{}, I0{});
-    if (kt + 2 < nk && !(dbg & 2)) load_tile(kt + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_half(I1{}, I1{});
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  load_tile(0);
-  store_tile(I0{}, 0);
-  if (nk > 1) load_tile(1);
-  __syncthreads();
-  read_frags(I0{}, I0{}, I0{});
-  for (int kt = 0; kt < nk; kt += 2) {
-    tile_body(I0{}, I1{}, kt);
-    if (kt + 1 < nk) tile_body(I1{}, I0{}, kt + 1);
-  }
-
-  // epilogue: D[n = q + 4r][m = c] per tile; transposed through LDS for 16-B stores when the shape allows
-  constexpr int WI = BM / WM;
-  constexpr bool WIDE = VEC && (64 % (WI / 2) == 0) && (WM * WN * 16 * WI <= 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS));
-  const int mw0 = m0 + wm * WI;
-  const int64_t nw0 = n0 + wn * (BN / WN);
+  // epilogue: optional multiplication with act'(aux) (EPI_DACT), split partials behind one another (EPI_RAW)
   double* Cout = C + (EPI == EPI_RAW ? split * ldc * Ncols : 0);
-  if constexpr (WIDE) {
-    constexpr int CH_ROW = WI / 2, NCH = 16 * CH_ROW / 64;
-    double* reg = smem + wave * (16 * WI);
-    __syncthreads();  // all waves are done with the staging buffers (the loop's last barrier precedes the last reads)
-#pragma unroll
-    for (int bt = 0; bt < TN; ++bt) {
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) reg[(q + 4 * r) * WI + a * 16 + c] = acc[a][bt][r];
-#pragma unroll
-      for (int p = 0; p < NCH; ++p) {
-        const int chunk = p * 64 + lane;
-        const int row = chunk / CH_ROW, col2 = chunk % CH_ROW;
-        double2 v = *reinterpret_cast<const double2*>(reg + 2 * chunk);
-        const int gm = mw0 + 2 * col2;
-        const int64_t gn = nw0 + bt * 16 + row;
-        if (gm + 1 < Mrows && gn < Ncols) {
-          const int64_t off = gm + ldc * gn;
-          if constexpr (EPI == EPI_DACT) {
-            const double2 h = *reinterpret_cast<const double2*>(aux + off);
-            v.x *= dact_from_output(h.x, act);
-            v.y *= dact_from_output(h.y, act);
-          }
-          *reinterpret_cast<double2*>(Cout + off) = v;
-        }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      const int gm = mw0 + a * 16 + c;
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t gn = nw0 + b * 16 + q + 4 * r;
-          if (gm < Mrows && gn < Ncols) {
-            const int64_t off = gm + ldc * gn;
-            double v = acc[a][b][r];
-            if constexpr (EPI == EPI_DACT) v *= dact_from_output(aux[off], act);
-            Cout[off] = v;
-          }
-        }
-      }
-    }
-  }
+  gemm_epilogue<BM, BN, WM, WN, VEC, 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS)>(
+      acc, smem, Cout, ldc, m0, n0, Mrows, Ncols, wm, wn, lane, wave, [&](double v, int64_t off, int) {
+        if constexpr (EPI == EPI_DACT) v *= dact_from_output(aux[off], act);
+        return v;
+      });
 }
 
 template <int BM, int BN, int ALAY, int BLAY, int EPI>

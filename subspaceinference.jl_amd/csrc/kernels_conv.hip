@@ -1,0 +1,536 @@
+// Conv / MaxPool / flatten layers of a Flux Chain in fp64: forward and reverse sweep.
+//
+// The reference restructures ANY Chain (`model_re`, src/libs.jl:55-57) and evaluates it on the full data
+// (src/space_inference.jl:94); BASELINE config 4 is a Conv CNN.  Flux 0.11.2 / NNlib 0.7.23 semantics restated in
+// oracle/subspace_oracle.py (conv_forward: TRUE convolution, i.e. flipped kernel; weight (KW, KH, CIN, COUT) column-major
+// then bias; WHCN activations; MaxPool(k; stride = k, pad = 0)).
+//
+// Design.  Inside a convolutional stack activations live CHANNEL-FASTEST ("CWHN": element (c, w, h, n) at
+// c + Cp*(w + W*(h + H*n)), Cp = channels rounded up to even), so that
+//   * a convolution is the Dense GEMM of kernels_gemm / gemm_pipeline.h applied to pixels:  Out[co, pos] =
+//     act(sum_k' Wp[co, k'] * patch[k', pos] + b[co]),  k' = cin + Cp*(a + KW*c),  pos = wo + Wo*(ho + Ho*n) -- the output
+//     [COUTp x positions] IS the CWHN tensor of the next layer;
+//   * the im2col operand is never materialised: the B-operand stager of the GEMM pipeline gathers patch[k', pos] from
+//     the input tensor on its way to LDS (16-byte loads along cin; padding / out-of-range taps become zeros);
+//   * the weights are re-packed per evaluation (they change with every z) by a tiny kernel into Wp[COUTp x Kp]
+//     (kernel flipped, pad channels zero, Kp = K' rounded up to 16) -- 1 M weights, microseconds;
+//   * MaxPool and the layout changes at the ends of the stack (WHCN input -> CWHN once at set-up; CWHN -> the
+//     reference's WHC feature order at `flatten`) are HBM-bound index kernels.
+// Reverse sweep: dX is the same gather-GEMM on the Delta tensor with the transposed, un-flipped weights (fractional
+// stride handled by a divisibility test in the gather); dW is a split-K GEMM over positions whose B operand is the
+// transposed im2col gather; db is the row sum of Delta.
+#include <algorithm>
+
+#include "gemm_pipeline.h"
+
+namespace si {
+
+__device__ __forceinline__ double conv_act(double v, int act) {
+  switch (act) {
+    case SI_ACT_RELU: return v > 0.0 ? v : 0.0;
+    case SI_ACT_TANH: return tanh(v);
+    case SI_ACT_SIGMOID: return 1.0 / (1.0 + exp(-v));
+    default: return v;
+  }
+}
+__device__ __forceinline__ double conv_dact(double h, int act) {
+  switch (act) {
+    case SI_ACT_RELU: return h > 0.0 ? 1.0 : 0.0;
+    case SI_ACT_TANH: return 1.0 - h * h;
+    case SI_ACT_SIGMOID: return h * (1.0 - h);
+    default: return 1.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ gather stagers
+// B operand of the forward / data-gradient GEMM: B(k', pos) = T[cin + Cp*(wi + Wi*(hi + Hi*img))] with
+//   (wi, hi) = ((wo, ho) * snum - pad + (a, c) * dil) / sden   (zero when out of range or not divisible by sden).
+// LDS image "k-fast" [pos][18] like Stager<.., LAY = 1>.  Each thread owns NREG (position, k-pair) slots; the position
+// part of the address is fixed per slot, the tap part changes per k tile -- block-uniform when Cp % 16 == 0 (CELLU).
+template <int R, int NT, bool CELLU, bool DEN>
+struct GatherK {
+  static constexpr int LAY = 1;
+  static constexpr int NREG = (16 * R + NT * 2 - 1) / (NT * 2);
+  static constexpr int RP = R + 16, KP = 18;
+  static constexpr int LDS_ELEMS = R * KP;
+  int pb[NREG], wb[NREG], hb[NREG], lds[NREG], kk[NREG];
+  bool live[NREG];
+  double2 reg[NREG];
+  const double* T;
+  ConvGeom g;
+
+  __device__ __forceinline__ void init(const double* T_, const ConvGeom& g_, int64_t n0, int64_t npos, int tid) {
+    T = T_;
+    g = g_;
+    const int wh = g.Wo * g.Ho;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      const int idx = (tid + NT * r) * 2;
+      const int k = idx & 15, rr = idx >> 4;
+      int64_t pos = n0 + (rr < R ? rr : 0);
+      if (pos > npos - 1) pos = npos - 1;  // clamped positions only feed outputs that are never stored
+      const int img = (int)(pos / wh), sp = (int)(pos - (int64_t)img * wh);
+      const int ho = sp / g.Wo, wo = sp - ho * g.Wo;
+      pb[r] = img * (int)g.img_stride;
+      wb[r] = wo * g.snum_w - g.pad_w;
+      hb[r] = ho * g.snum_h - g.pad_h;
+      kk[r] = k;
+      live[r] = rr < R;
+      lds[r] = rr * KP + k;
+    }
+  }
+  __device__ __forceinline__ void fetch(int r, int a_dil, int c_dil, int cin, bool kvalid) {
+    int wi = wb[r] + a_dil, hi = hb[r] + c_dil;
+    bool ok = kvalid && wi >= 0 && hi >= 0;
+    if constexpr (DEN) {
+      ok = ok && (wi % g.sden_w == 0) && (hi % g.sden_h == 0);
+      wi /= g.sden_w;
+      hi /= g.sden_h;
+    }
+    ok = ok && wi < g.Wi && hi < g.Hi;
+    const int off = ok ? pb[r] + g.Cp * (wi + g.Wi * hi) + cin : 0;
+    const double2 v = *reinterpret_cast<const double2*>(T + off);
+    reg[r] = ok ? v : make_double2(0.0, 0.0);
+  }
+  __device__ __forceinline__ void load(int kt) {
+    if constexpr (CELLU) {
+      const int k0 = 16 * kt;                       // block-uniform tap of this k tile
+      const int cell = k0 / g.Cp, cin0 = k0 - cell * g.Cp;
+      const int c = cell / g.KW, a = cell - c * g.KW;
+#pragma unroll
+      for (int r = 0; r < NREG; ++r) fetch(r, a * g.dil_w, c * g.dil_h, cin0 + kk[r], true);
+    } else {
+#pragma unroll
+      for (int r = 0; r < NREG; ++r) {
+        const int kp = 16 * kt + kk[r];
+        const int cell = kp / g.Cp, cin = kp - cell * g.Cp;
+        const int c = cell / g.KW, a = cell - c * g.KW;
+        fetch(r, a * g.dil_w, c * g.dil_h, cin, kp < g.Kvalid);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(double* dst) const {
+#pragma unroll
+    for (int r = 0; r < NREG; ++r)
+      if (live[r]) *reinterpret_cast<double2*>(dst + lds[r]) = reg[r];
+  }
+  // k is padded to whole tiles (Kp % 16 == 0, taps past Kvalid read as zero): there is no ragged tile
+  __device__ __forceinline__ void load_edge(int kt, int64_t) { load(kt); }
+  __device__ __forceinline__ void store_edge(double* dst, int, int64_t) const { store(dst); }
+};
+
+// B operand of the weight-gradient GEMM: B(k = pos, n = k') = patch[k', pos] -- rows are the taps (fixed per slot), the
+// k index walks over positions (split-K).  LDS image "row-fast" [pos][R + 16] like Stager<.., LAY = 0>.
+template <int R, int NT>
+struct GatherN {
+  static constexpr int LAY = 0;
+  static constexpr int NREG = (16 * R + NT * 2 - 1) / (NT * 2);
+  static constexpr int RP = R + 16, KP = 18;
+  static constexpr int LDS_ELEMS = 16 * RP;
+  int adil[NREG], cdil[NREG], cin[NREG], lds[NREG], kq[NREG];
+  bool live[NREG], rowok[NREG];
+  double2 reg[NREG];
+  const double* T;
+  ConvGeom g;
+  int64_t kbase, kend;
+
+  __device__ __forceinline__ void init(const double* T_, const ConvGeom& g_, int64_t n0, int64_t k0, int64_t kend_, int tid) {
+    T = T_;
+    g = g_;
+    kbase = k0;
+    kend = kend_;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      const int idx = (tid + NT * r) * 2;
+      const int rr = idx % R, k = idx / R;
+      const int kp = (int)n0 + rr;
+      const int cell = kp / g.Cp;
+      const int c = cell / g.KW, a = cell - c * g.KW;
+      cin[r] = kp - cell * g.Cp;
+      adil[r] = a * g.dil_w;
+      cdil[r] = c * g.dil_h;
+      rowok[r] = kp < g.Kvalid;
+      kq[r] = k;
+      live[r] = k < 16;
+      lds[r] = k * RP + rr;
+    }
+  }
+  __device__ __forceinline__ void load(int kt) {
+    const int wh = g.Wo * g.Ho;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      const int64_t pos = kbase + 16 * (int64_t)kt + kq[r];
+      const int img = (int)(pos / wh), sp = (int)(pos - (int64_t)img * wh);
+      const int ho = sp / g.Wo, wo = sp - ho * g.Wo;
+      const int wi = wo * g.snum_w - g.pad_w + adil[r], hi = ho * g.snum_h - g.pad_h + cdil[r];
+      const bool ok = rowok[r] && pos < kend && wi >= 0 && hi >= 0 && wi < g.Wi && hi < g.Hi;
+      const int off = ok ? img * (int)g.img_stride + g.Cp * (wi + g.Wi * hi) + cin[r] : 0;
+      const double2 v = *reinterpret_cast<const double2*>(T + off);
+      reg[r] = ok ? v : make_double2(0.0, 0.0);
+    }
+  }
+  __device__ __forceinline__ void store(double* dst) const {
+#pragma unroll
+    for (int r = 0; r < NREG; ++r)
+      if (live[r]) *reinterpret_cast<double2*>(dst + lds[r]) = reg[r];
+  }
+  __device__ __forceinline__ void load_edge(int kt, int64_t) { load(kt); }  // positions past kend are masked in load()
+  __device__ __forceinline__ void store_edge(double* dst, int, int64_t) const { store(dst); }
+};
+
+// ------------------------------------------------------------------------------------------------ GEMM kernels
+// Out[m + Mp*pos] = f(sum_k' Wp[m + Mp*k'] * gather(k', pos))      (forward: f = act(. + bias[m]); data gradient: f = id)
+template <int BM, int BN, int WM, int WN, int MINW, bool CELLU, bool DEN, bool BIASACT>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_kernel(const double* __restrict__ Wp, int Mp,
+                                                                       const double* __restrict__ T, double* __restrict__ Out,
+                                                                       const double* __restrict__ bias, ConvGeom g, int64_t npos,
+                                                                       int Kp, int act, int nMt, int64_t nNt) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  using SA = Stager<BM, 0, NT, true>;
+  using SB = GatherK<BN, NT, CELLU, DEN>;
+  extern __shared__ double smem[];
+  const int64_t bid = blockIdx.x;
+  int mt;
+  int64_t nt;
+  if (nNt >= 8) {  // XCD-grouped: the row tiles of one position panel share an XCD's L2 (the gathered patches overlap)
+    const int xcd = (int)(bid & 7);
+    const int64_t j = bid >> 3;
+    mt = (int)(j % nMt);
+    nt = (j / nMt) * 8 + xcd;
+  } else {
+    mt = (int)(bid % nMt);
+    nt = bid / nMt;
+  }
+  if (nt >= nNt) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int m0 = mt * BM;
+  const int64_t n0 = nt * BN;
+  d4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  SA sa;
+  SB sb;
+  sa.init(Wp, Mp, m0, Mp, 0, tid);
+  sb.init(T, g, n0, npos, tid);
+  gemm_mainloop<BM, BN, WM, WN>(sa, sb, smem, Kp / 16, (int64_t)Kp, wm, wn, lane, acc, 0);
+  gemm_epilogue<BM, BN, WM, WN, true, 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS)>(
+      acc, smem, Out, (int64_t)Mp, m0, n0, Mp, npos, wm, wn, lane, wave, [&](double v, int64_t, int gm) {
+        if constexpr (BIASACT) v = conv_act(v + bias[gm], act);
+        return v;
+      });
+}
+
+// part[split][m + Mp*k'] = sum over the split's positions of Delta[m + Mp*pos] * patch[k', pos]
+template <int BM, int BN, int WM, int WN, int MINW>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void conv_dw_kernel(const double* __restrict__ Delta, int Mp,
+                                                                     const double* __restrict__ T, double* __restrict__ part,
+                                                                     ConvGeom g, int64_t npos, int Kp, int64_t ksplit, int nMt,
+                                                                     int nNt) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  using SA = Stager<BM, 0, NT, true>;
+  using SB = GatherN<BN, NT>;
+  extern __shared__ double smem[];
+  const int mt = (int)(blockIdx.x % nMt), nt = (int)(blockIdx.x / nMt);
+  const int64_t split = blockIdx.y;
+  const int64_t k0 = split * ksplit;
+  int64_t klen = npos - k0;
+  if (klen > ksplit) klen = ksplit;
+  if (klen <= 0 || nt >= nNt) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int m0 = mt * BM, n0 = nt * BN;
+  d4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  SA sa;
+  SB sb;
+  sa.init(Delta, Mp, m0, Mp, k0, tid);
+  sb.init(T, g, n0, k0, k0 + klen, tid);
+  gemm_mainloop<BM, BN, WM, WN>(sa, sb, smem, (int)((klen + 15) / 16), klen, wm, wn, lane, acc, 0);
+  gemm_epilogue<BM, BN, WM, WN, true, 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS)>(
+      acc, smem, part + split * (int64_t)Mp * Kp, (int64_t)Mp, m0, (int64_t)n0, Mp, (int64_t)Kp, wm, wn, lane, wave,
+      [&](double v, int64_t, int) { return v; });
+}
+
+static int conv_pick_bm(int rows) {
+  if (rows <= 64) return 64;
+  auto padded = [&](int bm) { return (rows + bm - 1) / bm * bm; };
+  const int p96 = padded(96), p128 = padded(128), p64 = padded(64);
+  if (p96 < p128 && p96 <= p64) return 96;
+  return p128 <= p64 ? 128 : 64;
+}
+
+template <int BM, bool CELLU, bool DEN, bool BIASACT>
+static void launch_conv_gemm_bm(hipStream_t st, const double* Wp, int Mp, const double* T, double* Out, const double* bias,
+                                const ConvGeom& g, int64_t npos, int Kp, int act) {
+  constexpr int BN = 128, WM = 2, WN = 4, NT = 512;
+  using SA = Stager<BM, 0, NT, true>;
+  using SB = GatherK<BN, NT, CELLU, DEN>;
+  constexpr size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(double);
+  const int nMt = (Mp + BM - 1) / BM;
+  const int64_t nNt = (npos + BN - 1) / BN;
+  const int64_t grid = nNt >= 8 ? (nNt + 7) / 8 * nMt * 8 : nNt * nMt;
+  auto kern = conv_gemm_kernel<BM, BN, WM, WN, 4, CELLU, DEN, BIASACT>;
+  static LdsOptIn optin;
+  optin.ensure(reinterpret_cast<const void*>(kern), lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, Wp, Mp, T, Out, bias, g, npos, Kp, act, nMt, nNt);
+}
+
+template <bool DEN, bool BIASACT>
+static void launch_conv_gemm(hipStream_t st, const double* Wp, int Mp, const double* T, double* Out, const double* bias,
+                             const ConvGeom& g, int64_t npos, int Kp, int act) {
+  const bool cellu = g.Cp % 16 == 0;
+  const int bm = conv_pick_bm(Mp);
+#define SI_CONV_CASE(BM)                                                                                     \
+  if (cellu)                                                                                                 \
+    launch_conv_gemm_bm<BM, true, DEN, BIASACT>(st, Wp, Mp, T, Out, bias, g, npos, Kp, act);                \
+  else                                                                                                       \
+    launch_conv_gemm_bm<BM, false, DEN, BIASACT>(st, Wp, Mp, T, Out, bias, g, npos, Kp, act)
+  if (bm == 64) {
+    SI_CONV_CASE(64);
+  } else if (bm == 96) {
+    SI_CONV_CASE(96);
+  } else {
+    SI_CONV_CASE(128);
+  }
+#undef SI_CONV_CASE
+}
+
+void launch_conv_forward(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, const ConvGeom& g,
+                         int COUTp, int Kp, int64_t npos, int act) {
+  launch_conv_gemm<false, true>(st, Wp, COUTp, In, Out, bp, g, npos, Kp, act);
+}
+
+void launch_conv_backward_data(hipStream_t st, const double* Wt, const double* Delta, double* dX, const ConvGeom& gT, int CINp,
+                               int KpT, int64_t npos_in) {
+  if (gT.sden_w > 1 || gT.sden_h > 1)
+    launch_conv_gemm<true, false>(st, Wt, CINp, Delta, dX, nullptr, gT, npos_in, KpT, 0);
+  else
+    launch_conv_gemm<false, false>(st, Wt, CINp, Delta, dX, nullptr, gT, npos_in, KpT, 0);
+}
+
+int conv_dw_splits(int COUTp, int Kp, int64_t npos, int num_cu, int64_t* ksplit_out) {
+  const int bm = conv_pick_bm(COUTp);
+  const int64_t tiles = (int64_t)((COUTp + bm - 1) / bm) * ((Kp + 127) / 128);
+  int64_t ns = ((int64_t)num_cu * 2 + tiles - 1) / tiles;
+  const int64_t maxsplit = (npos + 255) / 256;
+  ns = std::max<int64_t>(1, std::min(ns, maxsplit));
+  const int64_t ks = ((npos + ns - 1) / ns + 15) / 16 * 16;
+  *ksplit_out = ks;
+  return (int)((npos + ks - 1) / ks);
+}
+
+template <int BM>
+static void launch_conv_dw_bm(hipStream_t st, const double* Delta, int Mp, const double* In, double* part, const ConvGeom& g,
+                              int64_t npos, int Kp, int nsplit, int64_t ksplit) {
+  constexpr int BN = 128, WM = 2, WN = 4, NT = 512;
+  using SA = Stager<BM, 0, NT, true>;
+  using SB = GatherN<BN, NT>;
+  constexpr size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(double);
+  const int nMt = (Mp + BM - 1) / BM, nNt = (Kp + BN - 1) / BN;
+  auto kern = conv_dw_kernel<BM, BN, WM, WN, 4>;
+  static LdsOptIn optin;
+  optin.ensure(reinterpret_cast<const void*>(kern), lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nMt * nNt), (unsigned)nsplit), dim3(NT), lds, st, Delta, Mp, In, part, g, npos, Kp,
+                     ksplit, nMt, nNt);
+}
+
+void launch_conv_backward_weight(hipStream_t st, const double* Delta, const double* In, double* part, const ConvGeom& g,
+                                 int COUTp, int Kp, int64_t npos, int nsplit, int64_t ksplit) {
+  switch (conv_pick_bm(COUTp)) {
+    case 64: launch_conv_dw_bm<64>(st, Delta, COUTp, In, part, g, npos, Kp, nsplit, ksplit); break;
+    case 96: launch_conv_dw_bm<96>(st, Delta, COUTp, In, part, g, npos, Kp, nsplit, ksplit); break;
+    default: launch_conv_dw_bm<128>(st, Delta, COUTp, In, part, g, npos, Kp, nsplit, ksplit); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ index kernels
+static unsigned idx_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+// Wp[co + COUTp*k'] = w[(KW-1-a) + KW*((KH-1-c) + KH*(cin + CIN*co))],  k' = cin + CINp*(a + KW*c); zeros elsewhere.
+// bp[co] = b[co] (0 for the pad channel).
+__global__ __launch_bounds__(256) void conv_pack_kernel(const double* __restrict__ w, const double* __restrict__ b,
+                                                        double* __restrict__ Wp, double* __restrict__ bp, int KW, int KH, int CIN,
+                                                        int COUT, int CINp, int COUTp, int Kp) {
+  const int64_t total = (int64_t)COUTp * Kp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int co = (int)(e % COUTp), kp = (int)(e / COUTp);
+    const int cell = kp / CINp, cin = kp - cell * CINp;
+    const int c = cell / KW, a = cell - c * KW;
+    double v = 0.0;
+    if (co < COUT && cin < CIN && c < KH) v = w[(KW - 1 - a) + KW * ((KH - 1 - c) + KH * (cin + (int64_t)CIN * co))];
+    Wp[e] = v;
+    if (e < COUTp) bp[e] = e < COUT ? b[e] : 0.0;
+  }
+}
+void launch_conv_pack(hipStream_t st, const double* w, const double* b, double* Wp, double* bp, int KW, int KH, int CIN, int COUT,
+                      int CINp, int COUTp, int Kp) {
+  hipLaunchKernelGGL(conv_pack_kernel, dim3(idx_grid((int64_t)COUTp * Kp)), dim3(256), 0, st, w, b, Wp, bp, KW, KH, CIN, COUT,
+                     CINp, COUTp, Kp);
+}
+
+// data gradient: dX[cin, pin] = sum_{co, a', c'} Wt[cin + CINp*k''] * Delta[co, (pin + pad' ... )],  k'' = co + COUTp*(a' + KW*c'),
+// Wt = w[a' + KW*(c' + KH*(cin + CIN*co))]  (the forward kernel flipped twice = not flipped)
+__global__ __launch_bounds__(256) void conv_pack_t_kernel(const double* __restrict__ w, double* __restrict__ Wt, int KW, int KH,
+                                                          int CIN, int COUT, int CINp, int COUTp, int KpT) {
+  const int64_t total = (int64_t)CINp * KpT;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int cin = (int)(e % CINp), kp = (int)(e / CINp);
+    const int cell = kp / COUTp, co = kp - cell * COUTp;
+    const int c = cell / KW, a = cell - c * KW;
+    double v = 0.0;
+    if (co < COUT && cin < CIN && c < KH) v = w[a + KW * (c + KH * (cin + (int64_t)CIN * co))];
+    Wt[e] = v;
+  }
+}
+void launch_conv_pack_t(hipStream_t st, const double* w, double* Wt, int KW, int KH, int CIN, int COUT, int CINp, int COUTp,
+                        int KpT) {
+  hipLaunchKernelGGL(conv_pack_t_kernel, dim3(idx_grid((int64_t)CINp * KpT)), dim3(256), 0, st, w, Wt, KW, KH, CIN, COUT, CINp,
+                     COUTp, KpT);
+}
+
+// gw[(KW-1-a) + KW*((KH-1-c) + KH*(cin + CIN*co))] = sum_split part[split][co + COUTp*k'],  fixed order
+__global__ __launch_bounds__(256) void conv_unpack_dw_kernel(const double* __restrict__ part, int nsplit, double* __restrict__ gw,
+                                                             int KW, int KH, int CIN, int COUT, int CINp, int COUTp, int Kp) {
+  const int64_t total = (int64_t)KW * KH * CIN * COUT;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t plane = (int64_t)COUTp * Kp;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int aw = (int)(e % KW);
+    int64_t t = e / KW;
+    const int cw = (int)(t % KH);
+    t /= KH;
+    const int cin = (int)(t % CIN), co = (int)(t / CIN);
+    const int a = KW - 1 - aw, c = KH - 1 - cw;
+    const int64_t src = co + (int64_t)COUTp * (cin + CINp * (a + KW * c));
+    double s = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[(int64_t)sp * plane + src];
+    gw[e] = s;
+  }
+}
+void launch_conv_unpack_dw(hipStream_t st, const double* part, int nsplit, double* gw, int KW, int KH, int CIN, int COUT,
+                           int CINp, int COUTp, int Kp) {
+  hipLaunchKernelGGL(conv_unpack_dw_kernel, dim3(idx_grid((int64_t)KW * KH * CIN * COUT)), dim3(256), 0, st, part, nsplit, gw,
+                     KW, KH, CIN, COUT, CINp, COUTp, Kp);
+}
+
+// (W, H, C, N) column-major  ->  channel-fastest with pitch Cp (pad channels zero)
+__global__ __launch_bounds__(256) void whcn_to_cwhn_kernel(const double* __restrict__ X, double* __restrict__ Xc, int W, int H,
+                                                           int C, int Cp, int64_t B) {
+  const int64_t total = (int64_t)Cp * W * H * B;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int wh = W * H;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int c = (int)(e % Cp);
+    const int64_t t = e / Cp;
+    const int sp = (int)(t % wh);
+    const int64_t n = t / wh;
+    Xc[e] = c < C ? X[sp + (int64_t)wh * (c + (int64_t)C * n)] : 0.0;
+  }
+}
+void launch_whcn_to_cwhn(hipStream_t st, const double* X, double* Xc, int W, int H, int C, int Cp, int64_t B) {
+  hipLaunchKernelGGL(whcn_to_cwhn_kernel, dim3(idx_grid((int64_t)Cp * W * H * B)), dim3(256), 0, st, X, Xc, W, H, C, Cp, B);
+}
+// channel-fastest (pitch Cp) -> the reference's flatten order  w + W*(h + H*c)  per observation
+__global__ __launch_bounds__(256) void cwhn_to_whcn_kernel(const double* __restrict__ Xc, double* __restrict__ X, int W, int H,
+                                                           int C, int Cp, int64_t B) {
+  const int64_t total = (int64_t)C * W * H * B;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int wh = W * H;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int sp = (int)(e % wh);
+    const int64_t t = e / wh;
+    const int c = (int)(t % C);
+    const int64_t n = t / C;
+    X[e] = Xc[c + (int64_t)Cp * (sp + (int64_t)wh * n)];
+  }
+}
+void launch_cwhn_to_whcn(hipStream_t st, const double* Xc, double* X, int W, int H, int C, int Cp, int64_t B) {
+  hipLaunchKernelGGL(cwhn_to_whcn_kernel, dim3(idx_grid((int64_t)C * W * H * B)), dim3(256), 0, st, Xc, X, W, H, C, Cp, B);
+}
+
+// MaxPool on the channel-fastest layout
+__global__ __launch_bounds__(256) void maxpool_kernel(const double* __restrict__ In, double* __restrict__ Out, int Cp, int Wi, int Hi,
+                                                      int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B) {
+  const int64_t total = (int64_t)Cp * Wo * Ho * B;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int c = (int)(e % Cp);
+    int64_t t = e / Cp;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int64_t n = t / Ho;
+    const double* src = In + c + (int64_t)Cp * ((int64_t)Wi * Hi * n);
+    double m = -__builtin_inf();
+    for (int d = 0; d < PH; ++d)
+      for (int a = 0; a < PW; ++a) {
+        const double v = src[(int64_t)Cp * ((wo * sw + a) + Wi * (ho * sh + d))];
+        m = v > m ? v : m;
+      }
+    Out[e] = m;
+  }
+}
+void launch_maxpool(hipStream_t st, const double* In, double* Out, int Cp, int Wi, int Hi, int Wo, int Ho, int PW, int PH, int sw,
+                    int sh, int64_t B) {
+  hipLaunchKernelGGL(maxpool_kernel, dim3(idx_grid((int64_t)Cp * Wo * Ho * B)), dim3(256), 0, st, In, Out, Cp, Wi, Hi, Wo, Ho, PW,
+                     PH, sw, sh, B);
+}
+// every input element equal to the maximum of a window it belongs to receives that window's gradient [upstream NNlib]
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const double* __restrict__ In, const double* __restrict__ Out,
+                                                          const double* __restrict__ Gout, double* __restrict__ Gin, int Cp, int Wi,
+                                                          int Hi, int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B) {
+  const int64_t total = (int64_t)Cp * Wi * Hi * B;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int c = (int)(e % Cp);
+    int64_t t = e / Cp;
+    const int wi = (int)(t % Wi);
+    t /= Wi;
+    const int hi = (int)(t % Hi);
+    const int64_t n = t / Hi;
+    const double x = In[e];
+    double gsum = 0.0;
+    // windows (wo, ho) with wo*sw <= wi < wo*sw + PW
+    const int wo_hi = wi / sw, ho_hi = hi / sh;
+    for (int ho = ho_hi; ho >= 0 && ho * sh + PH > hi; --ho) {
+      if (ho >= Ho) continue;
+      for (int wo = wo_hi; wo >= 0 && wo * sw + PW > wi; --wo) {
+        if (wo >= Wo) continue;
+        const int64_t o = c + (int64_t)Cp * (wo + (int64_t)Wo * (ho + (int64_t)Ho * n));
+        if (Out[o] == x) gsum += Gout[o];
+      }
+    }
+    Gin[e] = gsum;
+  }
+}
+void launch_maxpool_bwd(hipStream_t st, const double* In, const double* Out, const double* Gout, double* Gin, int Cp, int Wi, int Hi,
+                        int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B) {
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(idx_grid((int64_t)Cp * Wi * Hi * B)), dim3(256), 0, st, In, Out, Gout, Gin, Cp, Wi,
+                     Hi, Wo, Ho, PW, PH, sw, sh, B);
+}
+
+// D[e] = G[e] * act'(H[e])   (pre-activation gradient of a layer from the gradient of its output)
+__global__ __launch_bounds__(256) void mul_dact_kernel(const double* __restrict__ G, const double* __restrict__ H, int64_t n, int act,
+                                                       double* __restrict__ D) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) D[e] = G[e] * conv_dact(H[e], act);
+}
+void launch_mul_dact(hipStream_t st, const double* G, const double* H, int64_t n, int act, double* D) {
+  hipLaunchKernelGGL(mul_dact_kernel, dim3(idx_grid(n)), dim3(256), 0, st, G, H, n, act, D);
+}
+
+}  // namespace si

@@ -21,6 +21,42 @@ struct EventPair {
   int cls;
 };
 
+// geometry of one convolution-shaped gather (kernels_conv.hip): the tensor T holds Cp channels (channel-fastest) on a
+// Wi x Hi grid per image; GEMM position (wo, ho) and tap (a, c) address ((wo, ho)*snum - pad + (a, c)*dil) / sden
+struct ConvGeom {
+  int Cp, Wi, Hi, Wo, Ho, KW, KH;
+  int snum_w, snum_h, sden_w, sden_h, pad_w, pad_h, dil_w, dil_h;
+  int Kvalid;          // Cp*KW*KH: taps at or past it read as zero (k is padded to whole 16-deep tiles)
+  int64_t img_stride;  // Cp*Wi*Hi
+};
+
+// one layer of a Chain as the device executes it (capi_net.hip builds it from the caller's si_layer table)
+struct LayerPlan {
+  int kind = 0, act = 0;
+  int64_t w_off = 0, b_off = 0;
+  int in_feat = 0, out_feat = 0;         // the reference's feature counts (si_layer in / out)
+  int64_t in_elems = 0, out_elems = 0;   // per observation in the layout the device uses (channel pitch inside conv stacks)
+  int C = 0, Cp = 0, Co = 0, Cop = 0;    // input / output channels and their even pitches
+  int Wi = 0, Hi = 0, Wo = 0, Ho = 0, KW = 0, KH = 0, sw = 1, sh = 1;
+  int Kp = 0, KpT = 0;                   // padded tap counts of the forward / data-gradient GEMMs
+  size_t wp_off = 0, bp_off = 0;         // packed weights / bias inside the pack workspace (doubles)
+  ConvGeom g{}, gT{};
+};
+struct NetPlan {
+  std::vector<LayerPlan> L;
+  bool has_conv = false;        // any non-Dense layer: the generic path of capi_net.hip runs the chain
+  bool input_spatial = false;   // the chain starts on (W, H, C) data: X is re-laid channel-fastest once
+  int in_W = 0, in_H = 0, in_C = 0, in_Cp = 0;
+  int64_t in_elems = 0;         // per observation, device layout
+  int64_t max_elems = 1;        // largest per-observation activation (device layout) over input and all layers
+  size_t wpack_elems = 1;       // forward packs of all conv layers
+  size_t wt_elems = 1;          // largest transposed pack (data gradient), one layer at a time
+  int max_rows = 1;             // largest row count handed to the row-sum kernels
+};
+struct NetScratch {             // reverse-sweep workspaces (sized by net_scratch_sizes)
+  double *bwpart = nullptr, *rspart = nullptr, *wt = nullptr, *dbtmp = nullptr;
+};
+
 // on-device training (capi_train.hip)
 struct TrainState {
   std::vector<si_layer> layers;
@@ -40,6 +76,10 @@ struct TrainState {
   bool fuse_tail = false;   // narrow head: folded into the epilogue of the layer in front of it (forward and reverse)
   int fuse_slots = 0;
   double* part = nullptr;   // [fuse_slots][out_last][Bmax] partial head products
+  // chains with Conv / MaxPool / flatten layers (generic path, capi_net.hip)
+  NetPlan plan;
+  double *Xc = nullptr, *wpack = nullptr;
+  NetScratch scratch;
 };
 
 struct Ctx {
@@ -121,6 +161,11 @@ struct Ctx {
   double* d_rspart = nullptr;  // row-sum partials
   double* d_ptgpart = nullptr;
   double* d_gz = nullptr;
+  // chains with Conv / MaxPool / flatten layers (generic path, capi_net.hip)
+  NetPlan plan;
+  double* d_Xc = nullptr;      // X re-laid channel-fastest (input_spatial)
+  double* d_wpack = nullptr;   // packed conv weights of the current evaluation
+  NetScratch g_scratch;
   // sampler state (device)
   double* d_zcur = nullptr;   // M x C
   double* d_zprop = nullptr;  // M x C
@@ -238,6 +283,36 @@ void launch_tail_bwd(hipStream_t st, const double* W, const double* Delta, const
 int rowsum_chunks();
 void launch_ptg(hipStream_t st, const double* P, int64_t ldP, int64_t N, int M, const double* g, double* part, double* gz);
 int ptg_blocks();
+// ---- Conv / MaxPool / flatten (kernels_conv.hip; host side capi_net.hip) ---------------------------------------------
+void launch_conv_pack(hipStream_t st, const double* w, const double* b, double* Wp, double* bp, int KW, int KH, int CIN, int COUT,
+                      int CINp, int COUTp, int Kp);
+void launch_conv_pack_t(hipStream_t st, const double* w, double* Wt, int KW, int KH, int CIN, int COUT, int CINp, int COUTp, int KpT);
+void launch_conv_forward(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, const ConvGeom& g,
+                         int COUTp, int Kp, int64_t npos, int act);
+void launch_conv_backward_data(hipStream_t st, const double* Wt, const double* Delta, double* dX, const ConvGeom& gT, int CINp,
+                               int KpT, int64_t npos_in);
+int conv_dw_splits(int COUTp, int Kp, int64_t npos, int num_cu, int64_t* ksplit_out);
+void launch_conv_backward_weight(hipStream_t st, const double* Delta, const double* In, double* part, const ConvGeom& g, int COUTp,
+                                 int Kp, int64_t npos, int nsplit, int64_t ksplit);
+void launch_conv_unpack_dw(hipStream_t st, const double* part, int nsplit, double* gw, int KW, int KH, int CIN, int COUT, int CINp,
+                           int COUTp, int Kp);
+void launch_whcn_to_cwhn(hipStream_t st, const double* X, double* Xc, int W, int H, int C, int Cp, int64_t B);
+void launch_cwhn_to_whcn(hipStream_t st, const double* Xc, double* X, int W, int H, int C, int Cp, int64_t B);
+void launch_maxpool(hipStream_t st, const double* In, double* Out, int Cp, int Wi, int Hi, int Wo, int Ho, int PW, int PH, int sw,
+                    int sh, int64_t B);
+void launch_maxpool_bwd(hipStream_t st, const double* In, const double* Out, const double* Gout, double* Gin, int Cp, int Wi, int Hi,
+                        int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B);
+void launch_mul_dact(hipStream_t st, const double* G, const double* H, int64_t n, int act, double* D);
+// capi_net.hip: validation + geometry of a layer table (Dense chains included), and the generic forward / reverse sweep
+int32_t net_plan(Ctx* c, const char* who, const si_layer* layers, int L, int64_t N, int in_dim, int out_dim, NetPlan& out);
+// xin: input in device layout (net_input re-lays a (features x B) matrix when the chain starts on images); outs[l] = where
+// layer l writes (out_elems * B doubles each); wpack: plan.wpack_elems doubles
+void net_input(Ctx* c, const NetPlan& p, const double* X, double* Xc, int64_t B);
+int32_t net_forward(Ctx* c, const NetPlan& p, const double* w, const double* xin, int64_t B, double* const* outs, double* wpack);
+void net_scratch_sizes(const NetPlan& p, int64_t B, int num_cu, size_t* bwpart, size_t* rspart, size_t* wt, size_t* dbtmp);
+// g0 holds d / d(output of the last layer) (out_feat x B) on entry; g0 / g1: max_elems * B doubles each; hs[l]: kept outputs
+int32_t net_backward(Ctx* c, const NetPlan& p, const double* w, const double* xin, int64_t B, double* const* hs, double* g0,
+                     double* g1, double* gw, const NetScratch& s);
 // K6
 void launch_rwmh_init(hipStream_t st, double* zcur, double* lpcur, int64_t* nacc, uint64_t* steps, int32_t M, int32_t C);
 void launch_rwmh_propose(hipStream_t st, const double* zcur, double* zprop, int32_t M, int32_t C,

@@ -61,6 +61,73 @@ class Dense:
         return _act_fwd(self.W @ x + self.b[:, None], self.act)
 
 
+def _pair(v):
+    return (int(v), int(v)) if np.isscalar(v) else (int(v[0]), int(v[1]))
+
+
+class Conv:
+    """Flux 0.11.2 `Conv((kw, kh), cin => cout, σ = identity; stride = 1, pad = 0, dilation = 1)`: weight
+    (kw, kh, cin, cout) glorot_uniform Float32, bias zeros(cout); forward `σ.(conv(x, weight) .+ b)` on (W, H, C, N)
+    arrays with NNlib's default TRUE convolution (flipped kernel) [upstream NNlib 0.7.23]."""
+
+    def __init__(self, k, cin, cout, act=identity, stride=1, pad=0, dilation=1, rng=None, dtype=np.float32):
+        rng = rng if rng is not None else np.random.default_rng()
+        self.k, self.stride, self.pad, self.dilation = _pair(k), _pair(stride), _pair(pad), _pair(dilation)
+        kw, kh = self.k
+        scale = np.sqrt(24.0 / (kw * kh * (cin + cout)))        # glorot_uniform: fan_in + fan_out over the receptive field
+        self.weight = ((rng.random((kw, kh, cin, cout)) - 0.5) * scale).astype(dtype)
+        self.bias = np.zeros(cout, dtype=dtype)
+        self.act = _act_id(act)
+
+    def out_size(self, wi, hi):
+        (kw, kh), (sw, sh), (pw, ph), (dw, dh) = self.k, self.stride, self.pad, self.dilation
+        return (wi + 2 * pw - dw * (kw - 1) - 1) // sw + 1, (hi + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+
+    def __call__(self, x):
+        kw, kh, cin, cout = self.weight.shape
+        wi, hi, _, n = x.shape
+        (sw, sh), (pw, ph), (dw, dh) = self.stride, self.pad, self.dilation
+        wo, ho = self.out_size(wi, hi)
+        xp = np.zeros((wi + 2 * pw, hi + 2 * ph, cin, n), dtype=np.result_type(x, self.weight))
+        xp[pw:pw + wi, ph:ph + hi] = x
+        y = np.zeros((wo, ho, cout, n), dtype=xp.dtype)
+        for a in range(kw):
+            for c in range(kh):
+                xs = xp[a * dw: a * dw + (wo - 1) * sw + 1: sw, c * dh: c * dh + (ho - 1) * sh + 1: sh]
+                y += np.einsum("whin,io->whon", xs, self.weight[kw - 1 - a, kh - 1 - c])
+        return _act_fwd(y + self.bias[None, None, :, None], self.act)
+
+
+class MaxPool:
+    """Flux 0.11.2 `MaxPool(k; pad = 0, stride = k)` on (W, H, C, N) arrays."""
+
+    def __init__(self, k, stride=None):
+        self.k = _pair(k)
+        self.stride = self.k if stride is None else _pair(stride)
+
+    def out_size(self, wi, hi):
+        return (wi - self.k[0]) // self.stride[0] + 1, (hi - self.k[1]) // self.stride[1] + 1
+
+    def __call__(self, x):
+        wo, ho = self.out_size(x.shape[0], x.shape[1])
+        y = np.full((wo, ho) + x.shape[2:], -np.inf, dtype=x.dtype)
+        for a in range(self.k[0]):
+            for d in range(self.k[1]):
+                y = np.maximum(y, x[a: a + (wo - 1) * self.stride[0] + 1: self.stride[0],
+                                    d: d + (ho - 1) * self.stride[1] + 1: self.stride[1]])
+        return y
+
+
+class Flatten:
+    """Flux.flatten: (W, H, C, N) -> (W*H*C, N), column-major."""
+
+    def __call__(self, x):
+        return x.reshape((-1, x.shape[-1]), order="F")
+
+
+flatten = Flatten()
+
+
 class Chain:
     def __init__(self, *layers):
         self.layers = list(layers)
@@ -77,9 +144,12 @@ def params(model):
         raise SubspaceError("Error: model_re function is not available for this model")
     out = []
     for l in model.layers:
-        if not isinstance(l, Dense):
-            raise SubspaceError("Error: model_re function is not available for this model (only Dense layers)")
-        out += [l.W, l.b]
+        if isinstance(l, Dense):
+            out += [l.W, l.b]
+        elif isinstance(l, Conv):
+            out += [l.weight, l.bias]
+        elif not isinstance(l, (MaxPool, Flatten)):
+            raise SubspaceError("Error: model_re function is not available for this model")
     return out
 
 
@@ -88,21 +158,63 @@ def extract_params(ps):
     return np.concatenate([p.reshape(-1, order="F") for p in ps])
 
 
-def layer_table(model):
-    """Static layer-offset table that replaces the per-call Flux.destructure/re of src/libs.jl:55-57."""
+def has_conv(model):
+    return any(isinstance(l, (Conv, MaxPool, Flatten)) for l in model.layers)
+
+
+def layer_table(model, input_size=None):
+    """Static layer-offset table that replaces the per-call Flux.destructure/re of src/libs.jl:55-57.  Dense rows are
+    (in, out, act, w_off, b_off); a Chain with Conv / MaxPool / flatten layers needs `input_size` = (W, H, C) of one
+    observation and yields the tagged rows _capi._layer_array documents."""
     table, off = [], 0
+    whc = tuple(int(v) for v in input_size) if input_size is not None else None
     for l in model.layers:
-        fout, fin = l.W.shape
-        table.append((fin, fout, l.act, off, off + fin * fout))
-        off += fin * fout + fout
+        if isinstance(l, Dense):
+            fout, fin = l.W.shape
+            table.append((fin, fout, l.act, off, off + fin * fout))
+            off += fin * fout + fout
+            whc = None
+            continue
+        if whc is None:
+            raise SubspaceError("DimensionMismatch: Conv / MaxPool / flatten need (W, H, C, N) data: pass a 4-D X "
+                                "(or input_size) and keep them in front of the Dense layers")
+        wi, hi, c = whc
+        if isinstance(l, Conv):
+            kw, kh, cin, cout = l.weight.shape
+            if cin != c:
+                raise SubspaceError("DimensionMismatch: Conv expects %d input channels, got %d" % (cin, c))
+            table.append(("conv", (kw, kh, cin, cout), (wi, hi), l.stride, l.pad, l.dilation, l.act, off, off + l.weight.size))
+            off += l.weight.size + cout
+            whc = l.out_size(wi, hi) + (cout,)
+        elif isinstance(l, MaxPool):
+            table.append(("maxpool", l.k, c, (wi, hi), l.stride))
+            whc = l.out_size(wi, hi) + (c,)
+        elif isinstance(l, Flatten):
+            table.append(("flatten", c, (wi, hi)))
+            whc = None
+        else:
+            raise SubspaceError("Error: model_re function is not available for this model")
     return table, off
 
 
 def load_flat(model, w):
     """`re(W)`: write a flat vector back into the model's arrays (column-major slices)."""
-    for (fin, fout, _, w_off, b_off), l in zip(layer_table(model)[0], model.layers):
-        l.W[...] = w[w_off:w_off + fin * fout].reshape((fout, fin), order="F")
-        l.b[...] = w[b_off:b_off + fout]
+    off = 0
+    for p in params(model):
+        p[...] = w[off:off + p.size].reshape(p.shape, order="F")
+        off += p.size
+
+
+def data_matrices(data):
+    """split_data (src/libs.jl:75-77) for the device: X as the (features x B) matrix the C ABI takes -- a (W, H, C, N)
+    array of images is the same memory in Julia's column-major order -- plus the (W, H, C) of one observation."""
+    x, y = np.asarray(data.data[0]), np.asarray(data.data[1])
+    size = tuple(x.shape[:3]) if x.ndim == 4 else None
+    if x.ndim > 2:
+        x = x.reshape((-1, x.shape[-1]), order="F")
+    if y.ndim > 2:
+        y = y.reshape((-1, y.shape[-1]), order="F")
+    return x, y, size
 
 
 class DataLoader:
@@ -140,6 +252,9 @@ class MSE:
         return float(np.mean((model(x) - y) ** 2))
 
     def value_and_grad(self, model, x, y):
+        if has_conv(model):
+            raise SubspaceError("there is no AD on the Python host for Conv / MaxPool layers (Zygote's job in the "
+                                "reference): the training step of such a Chain runs on the device (device_training)")
         acts, pres = [x], []
         for l in model.layers:
             pre = l.W @ acts[-1] + l.b[:, None]
@@ -220,15 +335,15 @@ def store_device_state(opt, model, m_flat, v_flat, beta_pows):
     beta powers.  A later call with this optimiser continues on the host (device_optimiser() declines a used one)."""
     if isinstance(opt, Descent):
         return
-    for (fin, fout, _, w_off, b_off), l in zip(layer_table(model)[0], model.layers):
-        for arr, off, shape in ((l.W, w_off, (fout, fin)), (l.b, b_off, (fout,))):
-            size = int(np.prod(shape))
-            mv = m_flat[off:off + size].reshape(shape, order="F").astype(arr.dtype)
-            if isinstance(opt, Momentum):
-                opt.v[id(arr)] = mv
-            else:
-                vv = v_flat[off:off + size].reshape(shape, order="F").astype(arr.dtype)
-                opt.state[id(arr)] = [mv, vv, [beta_pows[0], beta_pows[1]]]
+    off = 0
+    for arr in params(model):
+        mv = m_flat[off:off + arr.size].reshape(arr.shape, order="F").astype(arr.dtype)
+        if isinstance(opt, Momentum):
+            opt.v[id(arr)] = mv
+        else:
+            vv = v_flat[off:off + arr.size].reshape(arr.shape, order="F").astype(arr.dtype)
+            opt.state[id(arr)] = [mv, vv, [beta_pows[0], beta_pows[1]]]
+        off += arr.size
 
 
 def update(opt, ps, gs):

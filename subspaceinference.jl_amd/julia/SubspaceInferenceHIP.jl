@@ -44,7 +44,20 @@ struct SiLayer
     act::Int32
     w_off::Int64
     b_off::Int64
+    kw::Int32
+    kh::Int32
+    cin::Int32
+    cout::Int32
+    wi::Int32
+    hi::Int32
+    sw::Int32
+    sh::Int32
+    pw::Int32
+    ph::Int32
+    dw::Int32
+    dh::Int32
 end
+dense_layer(i, o, act, w_off, b_off) = SiLayer(0, i, o, act, w_off, b_off, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
 
 mutable struct Ctx
     h::Ptr{Cvoid}
@@ -71,17 +84,56 @@ extract_params(ps) = mapreduce(p -> vec(p), vcat, ps)
 act_id(f) = f === identity ? Int32(0) : f === relu ? Int32(1) : f === tanh ? Int32(2) :
             (f === σ || f === sigmoid) ? Int32(3) : throw("Error: activation $f is not available on the device")
 
-# static layer-offset table replacing the per-call Flux.destructure/re of model_re (src/libs.jl:55-57)
-function layer_table(model)
+conv_out(wi, k, s, p, d) = div(wi + 2p - d * (k - 1) - 1, s) + 1
+
+# static layer-offset table replacing the per-call Flux.destructure/re of model_re (src/libs.jl:55-57): Dense, Conv,
+# MaxPool and flatten layers of any Chain; `insize` = (W, H, C) of one observation when the chain starts on images
+# [upstream Flux 0.11.2 field names: Dense.W/.b/.σ; Conv.weight/.bias/.σ/.stride/.pad/.dilation; MaxPool.k/.pad/.stride]
+function layer_table(model, insize = nothing)
     model isa Chain || throw("Error: model_re function is not available for this model")
     tbl, off = SiLayer[], 0
+    whc = insize
     for l in model.layers
-        l isa Dense || throw("Error: model_re function is not available for this model")
-        o, i = size(l.W)
-        push!(tbl, SiLayer(0, i, o, act_id(l.σ), off, off + i * o))
-        off += i * o + o
+        if l isa Dense
+            o, i = size(l.W)
+            push!(tbl, dense_layer(i, o, act_id(l.σ), off, off + i * o))
+            off += i * o + o
+            whc = nothing
+            continue
+        end
+        whc === nothing && throw("DimensionMismatch: Conv / MaxPool / flatten need (W, H, C, N) data in front of the Dense layers")
+        wi, hi, c = whc
+        if l isa Conv
+            kw, kh, cin, cout = size(l.weight)
+            (sw, sh), (dw, dh) = l.stride, l.dilation
+            pw, ph = l.pad[1], l.pad[end - 1]          # Flux stores (lo, hi) per dimension; symmetric padding assumed
+            (all(l.pad[1:2:end] .== l.pad[2:2:end]) || length(l.pad) == 2) || throw("Error: asymmetric Conv padding is not available on the device")
+            wo, ho = conv_out(wi, kw, sw, pw, dw), conv_out(hi, kh, sh, ph, dh)
+            push!(tbl, SiLayer(1, wi * hi * cin, wo * ho * cout, act_id(l.σ), off, off + length(l.weight),
+                               kw, kh, cin, cout, wi, hi, sw, sh, pw, ph, dw, dh))
+            off += length(l.weight) + cout
+            whc = (wo, ho, cout)
+        elseif l isa MaxPool
+            (kw, kh), (sw, sh) = l.k, l.stride
+            all(l.pad .== 0) || throw("Error: MaxPool padding is not available on the device")
+            wo, ho = div(wi - kw, sw) + 1, div(hi - kh, sh) + 1
+            push!(tbl, SiLayer(2, wi * hi * c, wo * ho * c, 0, 0, 0, kw, kh, c, c, wi, hi, sw, sh, 0, 0, 1, 1))
+            whc = (wo, ho, c)
+        elseif l === Flux.flatten
+            push!(tbl, SiLayer(3, wi * hi * c, wi * hi * c, 0, 0, 0, 0, 0, c, c, wi, hi, 1, 1, 0, 0, 1, 1))
+            whc = nothing
+        else
+            throw("Error: model_re function is not available for this model")
+        end
     end
     return tbl, off
+end
+
+# split_data (src/libs.jl:75-77) as the (features x B) matrices the C ABI takes; a (W, H, C, N) array is the same memory
+function data_matrices(data)
+    X, Y = data.data[1], data.data[2]
+    insize = ndims(X) == 4 ? size(X)[1:3] : nothing
+    return Float64.(reshape(X, :, size(X)[end])), Float64.(reshape(Y, :, size(Y)[end])), insize
 end
 
 # ---- on-device training step (SURVEY 8 f1): src/subspace_construction.jl:39-43 for cost = mse ----------------------
@@ -108,11 +160,11 @@ function index_batches(d)
 end
 
 function train_on_device!(ctx::Ctx, model, data, opt, T, c, print_freq)
-    tbl, N = layer_table(model)
+    X, Y, insize = data_matrices(data)
+    tbl, N = layer_table(model, insize)
     kind, η, p1, p2 = device_optimiser(opt)
     ps = Flux.params(model)
     w0 = Float32.(extract_params(ps))
-    X, Y = Float64.(data.data[1]), Float64.(data.data[2])
     GC.@preserve tbl w0 X Y check(ctx, ccall((:si_train_setup, LIB), Int32,
         (Ptr{Cvoid}, Ptr{SiLayer}, Int32, Int64, Ptr{Float32}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Int64, Int64,
          Int32, Float64, Float64, Float64),
@@ -226,8 +278,8 @@ function sub_inference(in_model, data, W_swa, P; σ_z = 1.0, σ_m = 1.0, σ_p = 
     alg == :mh && (alg = :rwmh)                                     # README.md:153-154
     alg in (:rwmh, :mala, :hmc, :nuts) || throw("$alg is not available")       # :162 (:advi is outside this build)
     in_model isa Chain || throw("Error: density function is not avaliable for this model")
-    X, Y = Float64.(data.data[1]), Float64.(data.data[2])          # split_data (src/libs.jl:75-77)
-    tbl, N = layer_table(in_model)
+    X, Y, insize = data_matrices(data)                              # split_data (src/libs.jl:75-77)
+    tbl, N = layer_table(in_model, insize)
     Wp = W_swa === nothing ? C_NULL : pointer(W_swa)
     Pp = P === nothing ? C_NULL : pointer(P)
     GC.@preserve tbl W_swa P X Y check(ctx, ccall((:si_infer_setup, LIB), Int32,

@@ -62,22 +62,40 @@ def _kinetic(r, minv):
 
 
 def find_good_stepsize(logdensity_grad, z, lp, g, rng, eps=0.1, max_iter=100):
-    """Hoffman & Gelman (2014) Algorithm 4, the heuristic AdvancedHMC's `find_good_stepsize` implements (identity
-    metric: it runs before any adaptation)."""
+    """AdvancedHMC 0.2.x `find_good_stepsize` (called at src/space_inference.jl:147) restated from its published
+    algorithm [upstream, unverifiable offline]: identity metric (it runs before any adaptation), ONE momentum draw,
+      1. crossing: double / halve eps until the one-leapfrog acceptance ratio exp(-dH) crosses a_cross = 0.5
+         (NOT Stan's / Hoffman & Gelman's 0.8 -- ADVICE r1), which leaves a bracket (eps, eps') one doubling apart;
+      2. bisection inside the bracket until a_min = 0.25 < ratio < a_max = 0.75.
+    The result seeds the dual averaging (mu = log 10 eps), so it matters most for short runs (n_adapts = itr / 2)."""
+    a_min, a_cross, a_max = 0.25, 0.5, 0.75
     r = rng.standard_normal(z.size)
     h0 = lp - 0.5 * float(r @ r)
-    _, rp, lpp, _ = _leapfrog(logdensity_grad, z, r, g, eps)
-    dh = lpp - 0.5 * float(rp @ rp) - h0
-    direction = 1.0 if dh > math.log(0.8) else -1.0
+
+    def delta_h(e):
+        _, rp, lpp, _ = _leapfrog(logdensity_grad, z, r, g, e)
+        d = lpp - 0.5 * float(rp @ rp) - h0          # = H - H' : exp(d) is the MH ratio
+        return d if np.isfinite(d) else -np.inf
+    direction = 1 if delta_h(eps) > math.log(a_cross) else -1
+    eps_next = eps
     for _ in range(max_iter):
-        eps *= 2.0 ** direction
-        _, rp, lpp, _ = _leapfrog(logdensity_grad, z, r, g, eps)
-        dh = lpp - 0.5 * float(rp @ rp) - h0
-        if not np.isfinite(dh):
-            dh = -np.inf
-        if (direction > 0 and dh <= math.log(0.8)) or (direction < 0 and dh >= math.log(0.8)):
+        eps_next = 2.0 * eps if direction == 1 else 0.5 * eps
+        d = delta_h(eps_next)
+        if (direction == 1 and not d > math.log(a_cross)) or (direction == -1 and not d < math.log(a_cross)):
             break
-    return eps
+        eps = eps_next
+    lo, hi = (eps, eps_next) if eps < eps_next else (eps_next, eps)
+    for _ in range(max_iter):
+        mid = 0.5 * (lo + hi)
+        d = delta_h(mid)
+        a = math.exp(min(0.0, d)) if d > -np.inf else 0.0
+        if a > a_max:
+            lo = mid
+        elif a < a_min:
+            hi = mid
+        else:
+            return mid
+    return lo
 
 
 class StanAdaptor:

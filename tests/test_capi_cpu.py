@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(si):
         assert hasattr(lib, s), "libsubspace_hip.so does not export %s" % s
     # and the ctypes table binds exactly the declared ABI
     assert sorted(si._capi.SIGNATURES) == syms
-    assert lib.si_version() == 100
+    assert lib.si_version() == 200
 
 
 def test_no_cpu_fallback(si):
@@ -220,3 +220,23 @@ def test_jacobi_resolves_graded_psd_matrices(si):
     w2, v2 = si._capi.host_jacobi_eig_psd(a.T @ a)
     assert np.allclose(w2, np.linalg.eigvalsh(a.T @ a)[::-1], rtol=1e-12)
     assert np.allclose((a.T @ a) @ v2, v2 * w2[None, :], atol=1e-11 * w2[0])
+
+
+def test_find_good_stepsize_crosses_at_one_half_then_bisects():
+    """AdvancedHMC's heuristic crosses at acceptance 0.5 (not Stan's 0.8) and then bisects into (0.25, 0.75).
+    Pinned on Gaussian targets N(0, sigma^2 I): the returned eps_0 must (i) give a one-leapfrog acceptance inside
+    (0.25, 0.75) for the momentum it was tuned with, (ii) scale with sigma, (iii) be reproducible."""
+    from subspaceinference_jl_amd import samplers
+
+    for sigma, d in ((0.01, 5), (1.0, 20), (100.0, 3)):
+        def lg(z, s=sigma):
+            return -0.5 * float(z @ z) / s ** 2, -z / s ** 2
+        z = np.full(d, 0.3 * sigma)
+        lp, g = lg(z)
+        eps = samplers.find_good_stepsize(lg, z, lp, g, np.random.default_rng(5))
+        assert eps == samplers.find_good_stepsize(lg, z, lp, g, np.random.default_rng(5))
+        r = np.random.default_rng(5).standard_normal(d)             # the momentum the search drew
+        _, rp, lpp, _ = samplers._leapfrog(lg, z, r, g, eps)
+        a = np.exp(min(0.0, (lpp - 0.5 * rp @ rp) - (lp - 0.5 * r @ r)))
+        assert 0.25 < a < 0.75, (sigma, eps, a)
+        assert 0.2 * sigma < eps < 20 * sigma, (sigma, eps)         # the step size follows the scale of the target

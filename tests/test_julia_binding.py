@@ -102,7 +102,9 @@ def test_the_wrapper_binds_the_whole_single_process_path():
 def test_silayer_mirrors_si_layer():
     text = _strip_comments(open(HEADER).read())
     body = re.search(r"typedef struct \{([^}]*)\}\s*si_layer;", text, flags=re.S).group(1)
-    cfields = [(t, n) for t, n in re.findall(r"(int32_t|int64_t)\s+(\w+)\s*;", body)]
+    cfields = []
+    for t, names in re.findall(r"(int32_t|int64_t)\s+([\w\s,]+);", body):
+        cfields += [(t, n.strip()) for n in names.split(",")]
     jl = open(JL).read()
     jbody = re.search(r"struct SiLayer\n(.*?)\nend", jl, flags=re.S).group(1)
     jfields = [(n, t) for n, t in re.findall(r"(\w+)::(\w+)", jbody)]

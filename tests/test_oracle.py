@@ -148,3 +148,73 @@ def test_c_port_equals_numpy_port():
         for threads in (1, 0):
             assert np.allclose(c_port.forward(table, w + p @ z, x, threads), so.forward(table, w + p @ z, x), rtol=1e-12, atol=1e-13)
             assert np.isclose(c_port.logdensity(table, w, p, x, y, 0.8, z, threads), so.logdensity(table, w, p, x, y, 0.8, z), rtol=1e-12)
+
+
+def test_conv_restatement_against_scipy_and_brute_force():
+    """Flux 0.11.2 Conv = NNlib's TRUE convolution (flipped kernel) + bias; MaxPool; flatten -- the restatement against
+    scipy.signal.convolve2d ('valid' and 'full'), a brute-force multi-channel loop with stride / pad / dilation, and the
+    reverse sweep against central finite differences."""
+    from scipy.signal import convolve2d
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((9, 7, 1, 1))
+    w = rng.standard_normal((3, 2, 1, 1))
+    y = so.conv_forward(x, w, np.array([0.3]), (1, 1), (0, 0), (1, 1))
+    assert np.allclose(y[:, :, 0, 0], convolve2d(x[:, :, 0, 0], w[:, :, 0, 0], mode="valid") + 0.3, rtol=1e-13, atol=1e-14)
+    yf = so.conv_forward(x, w, np.zeros(1), (1, 1), (2, 1), (1, 1))      # pad = K - 1 is the 'full' convolution
+    assert np.allclose(yf[:, :, 0, 0], convolve2d(x[:, :, 0, 0], w[:, :, 0, 0], mode="full"), rtol=1e-13, atol=1e-14)
+    x = rng.standard_normal((8, 8, 3, 2))
+    w = rng.standard_normal((3, 3, 3, 4))
+    b = rng.standard_normal(4)
+    y = so.conv_forward(x, w, b, (2, 1), (1, 0), (1, 2))
+    assert y.shape == (so.conv_out_size(8, 3, 2, 1, 1), so.conv_out_size(8, 3, 1, 0, 2), 4, 2)
+    for (n, o) in ((0, 0), (1, 2), (1, 3)):
+        for a in range(y.shape[0]):
+            for c in range(y.shape[1]):
+                acc = b[o]
+                for kw in range(3):
+                    for kh in range(3):
+                        xi, yi = a * 2 - 1 + kw, c + 2 * kh
+                        if 0 <= xi < 8 and 0 <= yi < 8:
+                            acc += float(x[xi, yi, :, n] @ w[2 - kw, 2 - kh, :, o])
+                assert abs(acc - y[a, c, o, n]) < 1e-12
+    mp = so.maxpool_forward(x, (3, 2), (2, 1))
+    assert mp.shape == (3, 7, 3, 2) and mp[1, 4, 2, 1] == x[2:5, 4:6, 2, 1].max()
+    # whole-chain gradient (conv / pool / flatten / dense, every activation) against finite differences
+    for spec, whc in (([("conv", (3, 3), 4, so.ACT_TANH, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("conv", (2, 2), 3, so.ACT_SIGMOID, (2, 1), (0, 1)),
+                        ("flatten",), ("dense", 5, so.ACT_TANH), ("dense", 2, so.ACT_IDENTITY)], (6, 6, 2)),
+                      ([("conv", (3, 2), 5, so.ACT_RELU, (1, 2), (2, 0), (2, 1)), ("maxpool", (3, 2), (2, 1)), ("flatten",),
+                        ("dense", 3, so.ACT_IDENTITY)], (9, 8, 3))):
+        table, n = so.conv_table(spec, whc)
+        m, bsz = 3, 7
+        w_swa, p = 0.3 * rng.standard_normal(n), 0.2 * rng.standard_normal((n, m))
+        xx = rng.standard_normal((whc[0] * whc[1] * whc[2], bsz))
+        yy = rng.standard_normal(so.forward(table, w_swa, xx).shape)
+        z = 0.1 * rng.standard_normal(m)
+        lp, gz, gw = so.logdensity_grad(table, w_swa, p, xx, yy, 0.7, z)
+        assert np.isclose(lp, so.logdensity(table, w_swa, p, xx, yy, 0.7, z), rtol=1e-13)
+        eps = 1e-6
+        fd = np.array([(so.logdensity(table, w_swa, p, xx, yy, 0.7, z + eps * np.eye(m)[i]) -
+                        so.logdensity(table, w_swa, p, xx, yy, 0.7, z - eps * np.eye(m)[i])) / (2 * eps) for i in range(m)])
+        assert np.allclose(gz, fd, rtol=1e-6, atol=1e-8)
+    # the flat-vector layout of BASELINE config 4's CNN
+    cfg4 = [("conv", (3, 3), 64, 1, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("conv", (3, 3), 128, 1, (1, 1), (1, 1)), ("maxpool", (2, 2)),
+            ("conv", (3, 3), 256, 1, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("conv", (3, 3), 256, 1, (1, 1), (1, 1)), ("maxpool", (2, 2)),
+            ("flatten",), ("dense", 4096, 1), ("dense", 10, 0)]
+    assert so.conv_table(cfg4, (32, 32, 3))[1] == 5200266
+
+
+def test_flux_conv_standins_match_the_oracle():
+    """flux.Conv / MaxPool / flatten (the caller-side stand-ins) == the oracle's restatement, and their layer table is the
+    one the oracle derives from the same spec."""
+    from subspaceinference_jl_amd import flux
+    rng = np.random.default_rng(1)
+    wr = np.random.default_rng(2)
+    model = flux.Chain(flux.Conv((3, 2), 3, 5, flux.relu, stride=(1, 2), pad=(2, 0), dilation=(2, 1), rng=wr), flux.MaxPool((3, 2), stride=(2, 1)),
+                       flux.flatten, flux.Dense(5 * 4 * 3, 3, rng=wr))
+    x4 = rng.standard_normal((9, 8, 3, 6))
+    spec = [("conv", (3, 2), 5, so.ACT_RELU, (1, 2), (2, 0), (2, 1)), ("maxpool", (3, 2), (2, 1)), ("flatten",), ("dense", 3, so.ACT_IDENTITY)]
+    table, n = so.conv_table(spec, (9, 8, 3))
+    tab2, n2 = flux.layer_table(model, (9, 8, 3))
+    assert n == n2 and [tuple(r) for r in table] == [tuple(r) for r in tab2]
+    wflat = flux.extract_params(flux.params(model)).astype(np.float64)
+    assert np.allclose(model(x4), so.forward(table, wflat, x4.reshape((-1, 6), order="F")), rtol=1e-6, atol=1e-6)
