@@ -20,6 +20,9 @@ SOURCES = [
     ("kernels_stream.hip", ["-ffp-contract=off"]),
     ("kernels_gemm.hip", []),
     ("kernels_gram.hip", []),
+    ("kernels_gram_wave.hip", ["-DSI_GW_PART=0"], "kernels_gram_wave0"),   # same source, three slices of the tile counts
+    ("kernels_gram_wave.hip", ["-DSI_GW_PART=1"], "kernels_gram_wave1"),
+    ("kernels_gram_wave.hip", ["-DSI_GW_PART=2"], "kernels_gram_wave2"),
     ("kernels_bwd.hip", []),
     ("kernels_conv.hip", []),
     ("capi_net.hip", []),
@@ -50,18 +53,24 @@ def build(force=False, verbose=False):
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    objs = []
+    objs, jobs = [], []
     for entry in SOURCES:
         src, extra = entry[0], entry[1]
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, (entry[2] if len(entry) > 2 else os.path.splitext(src)[0]) + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-                   "-c", s, "-o", o] + extra
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
+            jobs.append([hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+                         "-c", s, "-o", o] + extra)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    if jobs:  # the translation units are independent: compile them side by side (the fully unrolled Gram kernels take minutes)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) - 1), 8)) as ex:
+            list(ex.map(run, jobs))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -5,6 +5,7 @@
 //
 // A is N x K column-major with padded leading dimension ldA (multiple of 32 => columns 256-B aligned).
 #include <algorithm>
+#include <cstdlib>
 
 #include "si_internal.h"
 
@@ -391,6 +392,78 @@ static void gram_off_dispatch(hipStream_t st, const double* A, int64_t ldA, int6
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2, K <= 208: ONE pass over A by the LDS-DMA kernel of kernels_gram_wave.hip (one 4-wave workgroup per CU), then a
+// two-stage fixed-order sum of the per-workgroup partial tiles (bit-reproducible): stage 1 gives tile pair p to GR2_Y
+// workgroups, each adding 1/GR2_Y of the partials; stage 2 adds the GR2_Y sums in order and writes both triangles of G.
+// (The one-stage reduction of round 1 gave a tile to ONE workgroup: 28 workgroups pulling 29 MB at K = 100 took 0.05 ms,
+// a fifth of the Gram kernel itself.)
+// ------------------------------------------------------------------------------------------------
+bool launch_gram_wave_part0(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks);
+bool launch_gram_wave_part1(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks);
+bool launch_gram_wave_part2(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks);
+
+constexpr int GR2_Y = 16;
+__global__ __launch_bounds__(256) void gram_reduce_stage1_kernel(const double* __restrict__ Gpart, int nblocks, int P,
+                                                                 double* __restrict__ scr) {
+  const int p = blockIdx.x, y = blockIdx.y, e = threadIdx.x;
+  const int64_t stride = (int64_t)P * 256;
+  const int per = (nblocks + GR2_Y - 1) / GR2_Y;
+  const int sp0 = y * per, sp1 = sp0 + per < nblocks ? sp0 + per : nblocks;
+  const double* src = Gpart + (int64_t)p * 256 + e;
+  double s = 0.0;
+  int sp = sp0;
+  for (; sp + 8 <= sp1; sp += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(sp + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; sp < sp1; ++sp) s += src[(int64_t)sp * stride];
+  scr[((int64_t)y * P + p) * 256 + e] = s;
+}
+__global__ __launch_bounds__(256) void gram_reduce_stage2_kernel(const double* __restrict__ scr, int nt, int K,
+                                                                 double* __restrict__ G) {
+  const int p = blockIdx.x, e = threadIdx.x;
+  const int P = nt * (nt + 1) / 2;
+  double t = 0.0;
+#pragma unroll
+  for (int yy = 0; yy < GR2_Y; ++yy) t += scr[((int64_t)yy * P + p) * 256 + e];
+  const int a = tri_a(p, nt), b = tri_b(p, nt);
+  const int i = e & 15, j = e >> 4;
+  const int gi = a * 16 + i, gj = b * 16 + j;
+  if (gi < K && gj < K && (a != b || i <= j)) {  // diagonal tile: take the upper triangle, mirror it (exactly symmetric output)
+    G[gi + (int64_t)K * gj] = t;
+    G[gj + (int64_t)K * gi] = t;
+  }
+}
+
+static bool gram_wave_dispatch(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* Gpart, double* G, int nblocks,
+                               Ctx* prof, double flops, double bytes) {
+  const int nt = (K + 15) / 16, P = nt * (nt + 1) / 2;
+  double* scr = Gpart + (size_t)nblocks * P * 256;
+  {
+    ProfScope ps(prof, SI_K_GRAM, flops, bytes);
+    if (!(launch_gram_wave_part0(st, A, ldA, N, K, Gpart, nblocks) || launch_gram_wave_part1(st, A, ldA, N, K, Gpart, nblocks) ||
+          launch_gram_wave_part2(st, A, ldA, N, K, Gpart, nblocks)))
+      return false;
+  }
+  ProfScope ps(prof, SI_K_GRAM_RED, 0.0, (double)nblocks * P * 256 * 8.0);
+  hipLaunchKernelGGL(gram_reduce_stage1_kernel, dim3(P, GR2_Y), dim3(256), 0, st, Gpart, nblocks, P, scr);
+  hipLaunchKernelGGL(gram_reduce_stage2_kernel, dim3(P), dim3(256), 0, st, scr, nt, K, G);
+  return true;
+}
+
+// development knob (tools/gram_bench.hip): SI_GRAM_PANELS=1 forces the 128-column panel kernels for every K
+static bool gram_force_panels() {
+  static const bool v = [] {
+    const char* e = getenv("SI_GRAM_PANELS");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+
 size_t launch_gram(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, double* Gpart,
                    double* G, int num_cu, Ctx* prof) {
   // workspace: the largest single launch (an off-diagonal pair of full panels: 64 tiles per block)
@@ -398,9 +471,14 @@ size_t launch_gram(hipStream_t st, const double* A, int64_t ldA, int64_t N, int6
   int64_t nb_diag = std::min<int64_t>((int64_t)num_cu * 2, nslab_d);
   int64_t nb_off = std::min<int64_t>((int64_t)num_cu * 2, nslab_o);
   const int npan = (int)((K + 127) / 128);
-  const size_t need = (size_t)std::max<int64_t>(nb_diag * 36, npan > 1 ? nb_off * 64 : 0) * 256 * sizeof(double);
+  const int ntw = (int)((K + 15) / 16);
+  const bool wave_path = ntw <= 13 && !gram_force_panels();
+  const int64_t nb_wave = std::min<int64_t>((int64_t)num_cu, nslab_d);   // one 4-wave workgroup per CU
+  const size_t need = wave_path ? ((size_t)nb_wave + GR2_Y) * (size_t)(ntw * (ntw + 1) / 2) * 256 * sizeof(double)
+                                : (size_t)std::max<int64_t>(nb_diag * 36, npan > 1 ? nb_off * 64 : 0) * 256 * sizeof(double);
   if (Gpart == nullptr) return need;
   const double tot_flops = (double)N * (double)K * (double)(K + 1), tot_bytes = (double)N * (double)K * 8.0;
+  if (wave_path && gram_wave_dispatch(st, A, ldA, N, (int)K, Gpart, G, (int)nb_wave, prof, tot_flops, tot_bytes)) return need;
   bool first = true;
   for (int I = 0; I < npan; ++I) {
     const int ci0 = I * 128;

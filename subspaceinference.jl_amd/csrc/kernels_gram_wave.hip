@@ -1,0 +1,315 @@
+// K2 Gram matrix G = A'A for K <= 208 in ONE pass over A (round 2): the LDS-DMA fed, one-wave-per-SIMD kernel.
+// (kernels_gram.hip keeps the 128-column panel kernels for wider A, the projection K3 and launch_gram, which dispatches
+// here.)  This file is compiled three times (-DSI_GW_PART=0/1/2, like eig.cpp): the tile counts NT = 1..13 are separate
+// template instantiations with fully unrolled slab loops, and one translation unit holding all of them takes minutes.
+//
+// Decomposition.  4-wave workgroups, ONE per CU, one wave per SIMD: the upper-triangular 16x16 tile pairs of G are cut
+// into PS = 4 / KS contiguous chunks (row-major pair order) and the 8 k steps of a 32-row slab into KS residue classes;
+// wave (kg, g) accumulates chunk g over the k steps s = kg (mod KS).  Every accumulator of the chunk lives in AGPRs (up
+// to 28 tiles = 224 registers), a k step costs ONE ds_read_b64 per column tile the chunk touches for CNT MFMAs.  (The
+// 8-wave kernel of round 1 re-read every operand in each of its 8 waves, lost a third of its LDS cycles to bank
+// conflicts and 12 % to the uneven deal of 28 pairs over 8 waves.)  KS = 4 up to K = 112 (all pairs in every wave:
+// perfectly even), KS = 2 up to K = 160, KS = 1 (pairs only) up to K = 208: A is read once for every K <= 208.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "si_internal.h"
+
+namespace si {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int GR = 32;       // slab rows
+constexpr int GW_WAVES = 4;
+
+__host__ __device__ constexpr int tri_a(int p, int nt) {
+  int a = 0;
+  while (p >= nt - a) {
+    p -= nt - a;
+    ++a;
+  }
+  return a;
+}
+__host__ __device__ constexpr int tri_b(int p, int nt) {
+  int a = 0;
+  while (p >= nt - a) {
+    p -= nt - a;
+    ++a;
+  }
+  return a + p;
+}
+
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
+template <int NT, int KS, int G>
+struct GWave {
+  static constexpr int PS = GW_WAVES / KS;
+  static constexpr int P = NT * (NT + 1) / 2;
+  static constexpr int LO = G * P / PS, HI = (G + 1) * P / PS, CNT = HI - LO;
+  static constexpr unsigned mask() {
+    unsigned m = 0;
+    for (int p = LO; p < HI; ++p) m |= (1u << tri_a(p, NT)) | (1u << tri_b(p, NT));
+    return m;
+  }
+  // FIRST: the very first k step of a workgroup starts the accumulators from the inline constant 0 (a separate
+  // zero-initialisation would materialise 8 * CNT zeros in arch VGPRs before they move to the AGPRs the MFMAs use)
+  // `hook(I)` runs right after MFMA I has been issued: the staging traffic of a slab is dealt out between the MFMAs, one
+  // small piece at a time, so that it executes in the shadow of the matrix pipe instead of in one clump behind a group
+  template <int I, bool FIRST, class HOOK>
+  static __device__ __forceinline__ void mfma(const double (&f)[NT], d4 (&acc)[CNT > 0 ? CNT : 1], HOOK&& hook) {
+    if constexpr (I < CNT) {
+      constexpr int a = tri_a(LO + I, NT), b = tri_b(LO + I, NT);
+      if constexpr (FIRST)
+        acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[a], f[b], (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+      else
+        acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[a], f[b], acc[I], 0, 0, 0);
+      hook(std::integral_constant<int, I>{});
+      mfma<I + 1, FIRST>(f, acc, hook);
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// The same wave decomposition fed by LDS-DMA (global_load_lds_dwordx4) instead of register staging: the slabs of A go
+// straight from HBM into a ring of NB LDS buffers, NB - 1 slabs ahead of the one being multiplied, retired by a COUNTED
+// s_waitcnt vmcnt((NB-2)*NT) + raw s_barrier (a __syncthreads() would drain the ring with vmcnt(0)).  Register staging
+// gives a load one slab time to come back -- at K = 100 the kernel asks HBM for 4.4 TB/s and a slab is 1.5 us: loads are
+// late, the matrix pipe waits (measured: memory side alone 0.13 ms, MFMA side alone 0.20 ms, together 0.27 ms) -- and a
+// second register stage is defeated by the compiler's wait-count placement (loop-carried copies of the staged registers).
+// One wave-instruction writes 1 KiB of LDS contiguously (wave-uniform base + lane*16): lanes 16u..16u+15 bring the 16
+// row pairs of column u of a 4-column group, so the LDS image is [column][32 rows] with NO padding; the bank conflicts of
+// that image (every column starts on the same bank) are removed by permuting WHICH row pair a lane fetches: slot j of
+// column c holds row pair j ^ (c & 15), and the operand read of (column c, row 4s + q) looks in slot (2s + (q >> 1)) ^ c
+// -- the 16 columns of a 32-lane half then cover the 16 slot positions, i.e. all 64 banks exactly once.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+template <int NT, int KS, int KG, int G, int NB>
+__device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int64_t ldA, int64_t N, int K,
+                                               double* __restrict__ Gpart, double* sA) {
+  using GW = GWave<NT, KS, G>;
+  constexpr int NC = NT * 16;
+  constexpr int BUF = NC * GR;            // doubles per LDS buffer (32 rows per column, unpadded)
+  constexpr int H = (GR / 4) / KS;        // k steps of a slab owned by this wave
+  constexpr int CNT = GW::CNT > 0 ? GW::CNT : 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, c = lane & 15;
+  // LDS-DMA piece p of a slab: the 4 columns 16p + 4*wave .. +3; lane -> (column u = lane >> 4, slot j = lane & 15)
+  const double* src[NT];
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+    const int col = 16 * p + 4 * wave + (lane >> 4);
+    const int rp = (lane & 15) ^ (col & 15);
+    src[p] = A + (int64_t)(col < K ? col : K - 1) * ldA + 2 * rp;   // columns past K: finite garbage that only reaches G entries >= K
+  }
+  auto issue_one = [&](int64_t roff, double* dst, auto PC) {
+    constexpr int p = decltype(PC)::value;
+    __builtin_amdgcn_global_load_lds(src[p] + roff, (lds_void_ptr)(dst + 16 * p * GR), 16, 0, 0);
+  };
+  auto issue = [&](int64_t slab, int buf) {
+    const int64_t roff = slab * GR;
+    double* dst = sA + buf * BUF + (4 * wave) * GR;
+    static_for<NT>([&](auto PC) { issue_one(roff, dst, PC); });
+  };
+  // operand element (column 16t + c, row 4s + q) of buffer 0, for the H owned k steps
+  int fb[H];
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const int s = KG + KS * i;
+    fb[i] = c * GR + 2 * ((2 * s + (q >> 1)) ^ c) + (q & 1);
+    asm volatile("" : "+v"(fb[i]));   // keep the reads of neighbouring steps apart (no ds_read2_b64)
+  }
+  const int64_t nslab = (N + GR - 1) / GR;
+  const int64_t stride = gridDim.x;
+  int64_t slab = blockIdx.x;
+  double f0[NT], f1[NT];
+  double* out = Gpart + (int64_t)blockIdx.x * GW::P * 256;
+  if (slab >= nslab) {  // (the launcher never starts more blocks than slabs; keep the partial defined anyway)
+    for (int e = tid; e < GW::P * 256; e += 64 * GW_WAVES) out[e] = 0.0;
+    return;
+  }
+  const int64_t last = nslab - 1;
+  auto clamp = [&](int64_t sl) { return sl < last ? sl : last; };   // past the end: re-fetch the last slab, never used
+  // prologue: the ring is filled -- the current slab plus NB - 1 slabs ahead of it
+#pragma unroll
+  for (int b = 0; b < NB; ++b) issue(clamp(slab + b * stride), b);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * NT) : "memory");
+  __builtin_amdgcn_s_barrier();
+  auto load_frags = [&](const double* buf, int b, double(&f)[NT]) {
+    static_for<NT>([&](auto TC) {
+      constexpr int T = decltype(TC)::value;
+      constexpr unsigned M = GW::mask();
+      if constexpr ((M >> T) & 1u) f[T] = buf[b + T * 16 * GR];
+    });
+  };
+  load_frags(sA, fb[0], f0);
+  d4 acc[CNT];
+  int ring = 0;   // buffer of the current slab
+  // With ONE wave per SIMD nothing hides an instruction that is not an MFMA: an LDS-DMA piece costs 60-190 cycles of issue
+  // and the matrix pipe drains 64 cycles after the last MFMA it was given.  So every memory instruction of a slab is
+  // dealt out BETWEEN MFMAs: the fragments of the next k step behind MFMA 1 of a group, the NT pieces of the slab NB ahead
+  // behind MFMAs 2 .. NT+1 of the last group (measured before: 73 % MFMA-busy with the pieces in one clump per slab).
+  auto one_slab = [&](auto FIRSTSLAB) {
+    constexpr bool first_slab = decltype(FIRSTSLAB)::value;
+    const double* cur = sA + ring * BUF;
+    const int nxt = ring + 1 == NB ? 0 : ring + 1;
+    const int64_t roff = clamp(slab + (int64_t)NB * stride) * GR;
+    double* pdst = sA + ring * BUF + (4 * wave) * GR;
+    static_for<H>([&](auto IC) {
+      constexpr int i = decltype(IC)::value;
+      double(&fc)[NT] = (i & 1) ? f1 : f0;
+      double(&fn)[NT] = (i & 1) ? f0 : f1;
+      if constexpr (i == H - 1) {
+        // every LDS read of this buffer has been issued: retire them and this wave's pieces of the NEXT slab, meet the other
+        // waves; afterwards this buffer belongs to the slab NB ahead
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NB - 2) * NT) : "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      constexpr int FRAG_AT = GW::CNT > 1 ? 1 : 0;   // MFMA behind which the next fragments are fetched
+      auto hook = [&](auto MC) {
+        constexpr int I = decltype(MC)::value;
+        if constexpr (I == FRAG_AT) {
+          if constexpr (i + 1 < H)
+            load_frags(cur, fb[i + 1], fn);
+          else
+            load_frags(sA + nxt * BUF, fb[0], fn);
+        }
+        if constexpr (i == H - 1 && I >= FRAG_AT + 1 && I - (FRAG_AT + 1) < NT) {
+          issue_one(roff, pdst, std::integral_constant<int, I - (FRAG_AT + 1)>{});
+        }
+      };
+      __builtin_amdgcn_s_setprio(1);
+      if constexpr (first_slab && i == 0)
+        GW::template mfma<0, true>(fc, acc, hook);
+      else
+        GW::template mfma<0, false>(fc, acc, hook);
+      __builtin_amdgcn_s_setprio(0);
+      if constexpr (GW::CNT == 0) {   // a wave without tile pairs still stages its share
+        if constexpr (i + 1 < H)
+          load_frags(cur, fb[i + 1], fn);
+        else
+          load_frags(sA + nxt * BUF, fb[0], fn);
+      }
+      if constexpr (i == H - 1) {     // pieces that found no MFMA to hide behind (small chunks)
+        constexpr int done = GW::CNT - (FRAG_AT + 1) > 0 ? (GW::CNT - (FRAG_AT + 1) < NT ? GW::CNT - (FRAG_AT + 1) : NT) : 0;
+        static_for<NT - done>([&](auto PC) { issue_one(roff, pdst, std::integral_constant<int, done + decltype(PC)::value>{}); });
+      }
+    });
+    if constexpr ((H & 1) == 1) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) f0[t] = f1[t];
+    }
+    ring = nxt;
+    slab += stride;
+  };
+  one_slab(std::true_type{});
+  while (slab < nslab) one_slab(std::false_type{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail fetches must land before the buffers are reused
+  // ---- partial sums of the KS waves of a chunk: through LDS, R tiles per round, fixed order ----
+  if constexpr (KS == 1) {
+#pragma unroll
+    for (int i = 0; i < GW::CNT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(GW::LO + i) * 256 + (q + 4 * r) + 16 * c] = acc[i][r];
+  } else {
+    constexpr int PS = GW::PS;
+    constexpr int CMAX = (GW::P + PS - 1) / PS;
+    constexpr int R = (NB * BUF) / (256 * GW_WAVES) > 0 ? (NB * BUF) / (256 * GW_WAVES) : 1;
+    constexpr int ROUNDS = (CMAX + R - 1) / R;
+    __syncthreads();
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int i = rd * R + j;
+        if (i < GW::CNT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sA[(wave * R + j) * 256 + (q + 4 * r) + 16 * c] = acc[i < CNT ? i : 0][r];
+        }
+      }
+      __syncthreads();
+      for (int e = tid; e < PS * R * 256; e += 64 * GW_WAVES) {
+        const int g2 = e / (R * 256), rem = e - g2 * (R * 256);
+        const int j = rem >> 8, el = rem & 255;
+        const int lo2 = g2 * GW::P / PS, cnt2 = (g2 + 1) * GW::P / PS - lo2;
+        const int i = rd * R + j;
+        if (i < cnt2) {
+          double sum = 0.0;
+#pragma unroll
+          for (int kg2 = 0; kg2 < KS; ++kg2) sum += sA[((g2 * KS + kg2) * R + j) * 256 + el];
+          out[(lo2 + i) * 256 + el] = sum;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int NT, int KS, int NB>
+__global__ __launch_bounds__(64 * GW_WAVES, 1) void gram_glds_kernel(const double* __restrict__ A, int64_t ldA, int64_t N, int K,
+                                                                     double* __restrict__ Gpart) {
+  extern __shared__ double sA[];  // [NB][NT*16][32]
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+    case 0: gram_glds_body<NT, KS, 0 % KS, 0 / KS, NB>(A, ldA, N, K, Gpart, sA); break;
+    case 1: gram_glds_body<NT, KS, 1 % KS, 1 / KS, NB>(A, ldA, N, K, Gpart, sA); break;
+    case 2: gram_glds_body<NT, KS, 2 % KS, 2 / KS, NB>(A, ldA, N, K, Gpart, sA); break;
+    default: gram_glds_body<NT, KS, 3 % KS, 3 / KS, NB>(A, ldA, N, K, Gpart, sA); break;
+  }
+}
+
+
+template <int NT, int KS>
+static void launch_nt(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks) {
+  // LDS-DMA ring: as many buffers as 150 KB hold, at most 4
+  constexpr int NB = (150 * 1024) / (NT * 16 * GR * 8) >= 4 ? 4 : (150 * 1024) / (NT * 16 * GR * 8) >= 3 ? 3 : 2;
+  constexpr size_t lds = (size_t)NB * NT * 16 * GR * sizeof(double);
+  static LdsOptIn optin;
+  optin.ensure(reinterpret_cast<const void*>(gram_glds_kernel<NT, KS, NB>), lds);
+  hipLaunchKernelGGL((gram_glds_kernel<NT, KS, NB>), dim3(nblocks), dim3(64 * GW_WAVES), lds, st, A, ldA, N, K, tiles);
+}
+
+#ifndef SI_GW_PART
+#error "compile with -DSI_GW_PART=0|1|2"
+#endif
+// launches the partial-tile kernel for NT = ceil(K / 16) when this part holds it (tiles: nblocks x NT(NT+1)/2 x 256)
+#if SI_GW_PART == 0
+bool launch_gram_wave_part0(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks) {
+  switch ((K + 15) / 16) {
+    case 1: launch_nt<1, 4>(st, A, ldA, N, K, tiles, nblocks); return true;
+    case 2: launch_nt<2, 4>(st, A, ldA, N, K, tiles, nblocks); return true;
+    case 3: launch_nt<3, 4>(st, A, ldA, N, K, tiles, nblocks); return true;
+    case 4: launch_nt<4, 4>(st, A, ldA, N, K, tiles, nblocks); return true;
+    case 5: launch_nt<5, 4>(st, A, ldA, N, K, tiles, nblocks); return true;
+    case 6: launch_nt<6, 4>(st, A, ldA, N, K, tiles, nblocks); return true;
+    case 7: launch_nt<7, 4>(st, A, ldA, N, K, tiles, nblocks); return true;
+    case 8: launch_nt<8, 2>(st, A, ldA, N, K, tiles, nblocks); return true;
+    default: return false;
+  }
+}
+#elif SI_GW_PART == 1
+bool launch_gram_wave_part1(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks) {
+  switch ((K + 15) / 16) {
+    case 9: launch_nt<9, 2>(st, A, ldA, N, K, tiles, nblocks); return true;
+    case 10: launch_nt<10, 2>(st, A, ldA, N, K, tiles, nblocks); return true;
+    case 11: launch_nt<11, 1>(st, A, ldA, N, K, tiles, nblocks); return true;
+    default: return false;
+  }
+}
+#else
+bool launch_gram_wave_part2(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks) {
+  switch ((K + 15) / 16) {
+    case 12: launch_nt<12, 1>(st, A, ldA, N, K, tiles, nblocks); return true;
+    case 13: launch_nt<13, 1>(st, A, ldA, N, K, tiles, nblocks); return true;
+    default: return false;
+  }
+}
+#endif
+
+}  // namespace si

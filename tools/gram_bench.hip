@@ -1,4 +1,5 @@
 // Development harness for K2 (Gram) and K3 (projection) at construct shapes.  Not shipped.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gram_bench.hip subspaceinference.jl_amd/csrc/build/kernels_gram_wave{0,1,2}.o -o tools/bin/gram_bench
 #include "../subspaceinference.jl_amd/csrc/kernels_gram.hip"
 #include <cstdio>
 #include <vector>
@@ -25,16 +26,16 @@ int main(int argc, char** argv) {
   for (int k = 0; k < K; ++k) hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, A + (size_t)k * ldA, (size_t)N, 1000ull + k);
   hipMalloc(&G, (size_t)K * K * 8);
   const size_t need = launch_gram(0, A, ldA, N, K, nullptr, nullptr, 256, nullptr);
-  hipMalloc(&Gp, need);
+  hipMalloc(&Gp, need); hipMemset(Gp, 0, need);
   const int Mpad = project_mpad(M);
   hipMalloc(&V, (size_t)K * Mpad * 8); hipLaunchKernelGGL(fill, dim3(64), dim3(256), 0, 0, V, (size_t)K * Mpad, 7ull);
   hipMalloc(&P, (size_t)ldA * M * 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(e0, 0);
-    launch_gram(0, A, ldA, N, K, Gp, G, 256, nullptr);
+    for (int it = 0; it < 5; ++it) launch_gram(0, A, ldA, N, K, Gp, G, 256, nullptr);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
     hipEventRecord(e0, 0);
     launch_project(0, A, ldA, N, K, V, M, Mpad, P, ldA, 256);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
