@@ -118,6 +118,10 @@ int32_t si_device_name(si_ctx* ctx, char* buf, int32_t buflen);
  * max_cols = 0 keeps every deviation column (the reference's behaviour: the shift at :48-50 is
  * commented out); max_cols = M keeps only the newest M columns (the paper's column shift).        */
 int32_t si_construct_begin(si_ctx* ctx, int64_t N, int64_t K_capacity, int32_t max_cols);
+/* NON-DEFAULT option: start the running mean at the given weights instead of zeros -- what the
+ * reference's docs describe ("Initialize ... W_swa = W_0", docs/src/nn_example.md:44) but its code does not do (:31).
+ * Call right after si_construct_begin.                                                                             */
+int32_t si_construct_set_mean(si_ctx* ctx, const void* w_host, int32_t w_dtype);
 /* :45-52  W = extract_params(ps); n = i/c; W_swa = (n.*W_swa + W)./(n+1); W_dev = W - W_swa;
  * append!(A, W_dev).  `n` is supplied by the caller (it is the EPOCH counter i/c, repeated for every
  * batch of the epoch).  w has N elements of w_dtype.                                                */
@@ -183,6 +187,11 @@ int32_t si_infer_setup_dev(si_ctx* ctx, const si_layer* layers, int32_t L, int64
                            const double* W_swa_dev, const double* P_dev, int64_t ldP, int32_t borrow,
                            const double* X_dev, const double* Y_dev, int32_t in_dim, int32_t out_dim, int64_t B,
                            double sigma_m, int32_t compute_dtype);
+/* NON-DEFAULT option: add the prior term the reference writes AFTER its `return` (dead code,
+ * src/space_inference.jl:95):  + logpdf(MvNormal(zeros(N), sigma_p), new_W).  sigma_p = 0 switches it off again (the
+ * reference's behaviour and the default after every si_infer_setup).  Applies to si_logdensity, its gradient and the
+ * RWMH samplers.                                                                                                   */
+int32_t si_infer_set_prior(si_ctx* ctx, double sigma_p);
 /* :90-95  lp[c] = logpdf(MvNormal(vec(f_{W_swa+P z_c}(X)), sigma_m), vec(Y)),  Z is M x C          */
 int32_t si_logdensity(si_ctx* ctx, const double* Z, int32_t C, double* lp_out /* C */);
 /* lp and its gradient with respect to z: grad_out[m] = d lp / d z_m = (P' * d lp / d w)[m].

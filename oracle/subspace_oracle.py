@@ -69,11 +69,12 @@ def swa_dev_push(w_swa, w, n):
     return new, w64 - new
 
 
-def construct_stream(snapshots, ns):
+def construct_stream(snapshots, ns, w_init=None):
     """src/subspace_construction.jl:31-33,44-52,61: W_swa0 = zeros (Q1), push every snapshot with its
     caller-supplied n (Q2), keep every deviation column (Q3).  Returns (W_swa, A) with A N x K col-major."""
     n_par = len(snapshots[0])
-    w_swa = np.zeros(n_par, dtype=np.float64)
+    # Q1: zeros(...) in the code; `w_init` restates the docs' "W_swa = W_0" (docs/src/nn_example.md:44), the non-default option
+    w_swa = np.zeros(n_par, dtype=np.float64) if w_init is None else np.asarray(w_init).astype(np.float64)
     cols = []
     for w, n in zip(snapshots, ns):
         w_swa, dev = swa_dev_push(w_swa, w, n)
@@ -223,6 +224,13 @@ def mvnormal_logpdf_iso(y, mu, sigma):
 def lp_from_sse(sse, d, sigma):
     c0 = -(d * math.log(2.0 * math.pi) + d * math.log(sigma * sigma)) / 2.0
     return c0 - (sse / (sigma * sigma)) / 2.0
+
+
+def log_prior(new_w, sigma_p):
+    """the expression after the reference's `return` (src/space_inference.jl:95, dead code -- Q4):
+    logpdf(MvNormal(zeros(length(new_W)), sigma_p), new_W); only used by the NON-default include_prior option"""
+    lp, _ = mvnormal_logpdf_iso(new_w, np.zeros_like(new_w), sigma_p)
+    return lp
 
 
 def logdensity(table, w_swa, p, x, y, sigma_m, z):

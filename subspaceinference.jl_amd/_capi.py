@@ -61,6 +61,7 @@ SIGNATURES = {
     "si_reset_stats": (c_int32, [c_void_p]),
     "si_device_name": (c_int32, [c_void_p, c_char_p, c_int32]),
     "si_construct_begin": (c_int32, [c_void_p, c_int64, c_int64, c_int32]),
+    "si_construct_set_mean": (c_int32, [c_void_p, c_void_p, c_int32]),
     "si_construct_push": (c_int32, [c_void_p, c_void_p, c_int32, c_double]),
     "si_construct_push_dev": (c_int32, [c_void_p, c_void_p, c_int32, c_double]),
     "si_construct_push_batch_dev": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
@@ -78,6 +79,7 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_int32, c_int32, c_int64, c_double, c_int32]),
     "si_infer_setup_dev": (c_int32, [c_void_p, POINTER(SiLayer), c_int32, c_int64, c_int32, c_void_p, c_void_p, c_int64,
                                      c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_double, c_int32]),
+    "si_infer_set_prior": (c_int32, [c_void_p, c_double]),
     "si_logdensity": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "si_logdensity_grad": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "si_forward": (c_int32, [c_void_p, c_void_p, c_void_p]),
@@ -241,6 +243,13 @@ class Context:
         self._check(self.lib.si_construct_begin(self.h, int(n), int(k_capacity), int(max_cols)))
         self._n = int(n)
 
+    def construct_set_mean(self, w):
+        """non-default init = :pretrained (Q1): W_swa starts at w instead of zeros"""
+        w = np.ascontiguousarray(w)
+        if w.dtype not in (np.float32, np.float64) or w.size != self._n:
+            raise SubspaceError("DimensionMismatch / dtype: initial mean needs %d Float32 or Float64 values" % self._n)
+        self._check(self.lib.si_construct_set_mean(self.h, _ptr(w), SI_F32 if w.dtype == np.float32 else SI_F64))
+
     def construct_push(self, w, n):
         w = np.ascontiguousarray(w)
         if w.dtype == np.float32:
@@ -401,6 +410,10 @@ class Context:
             c_void_p(int(p_ptr)) if p_ptr else None, int(ld_p), 1 if borrow else 0, c_void_p(int(x_ptr)), c_void_p(int(y_ptr)),
             int(in_dim), int(out_dim), int(b), float(sigma_m), SI_F64))
         self._m, self._in, self._out, self._b, self._ni = int(m), int(in_dim), int(out_dim), int(b), int(n)
+
+    def set_prior(self, sigma_p):
+        """non-default include_prior (Q4): sigma_p > 0 adds logpdf(MvNormal(zeros(N), sigma_p), W_swa + P z); 0 = off"""
+        self._check(self.lib.si_infer_set_prior(self.h, float(sigma_p)))
 
     def logdensity(self, z):
         z = _f64(z)

@@ -28,7 +28,7 @@ def _alg_name(alg):
 
 
 def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, *, device=0, ctx=None,
-                          max_cols=0, verbose=True, keep_on_device=False, device_training="auto"):
+                          max_cols=0, verbose=True, keep_on_device=False, device_training="auto", init="zeros"):
     """src/subspace_construction.jl:26-67.
 
     Per batch the host does `gradient` + `update!` (:39-43, caller side) and hands the flattened weights
@@ -40,6 +40,9 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
     Momentum / ADAM, the training step itself (:39-43) also runs on the GPU (si_train_step: forward, reverse sweep,
     optimiser) and the weights are pushed in place (si_train_push) -- no weight vector crosses PCIe.  The model's
     arrays receive the trained weights at the end, like Flux's in-place `update!`.
+
+    init ("zeros" | "pretrained"): "zeros" is what the reference's CODE does (W_swa = zeros, :31 -- quirk Q1, the default);
+    "pretrained" starts the running mean at the model's weights, as the reference's docs describe (nn_example.md:44).
 
     Under a torch.distributed process group (one process per GPU, dist.init) the device training step is
     data-parallel: every rank must be called with the same model, data and DataLoader seed; each takes its share
@@ -64,6 +67,10 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
     ctx, own = _get_ctx(ctx, device)
     try:
         ctx.construct_begin(n_par, n_push, max_cols)
+        if _alg_name(init) == "pretrained":
+            ctx.construct_set_mean(flux.extract_params(ps))
+        elif _alg_name(init) != "zeros":
+            raise SubspaceError("init must be :zeros (the reference's behaviour) or :pretrained")
         training_loss = 0.0
         dp_rank, dp_world = dist.world() if use_dev else (0, 1)
         if use_dev:
@@ -107,13 +114,14 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
 
 def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=100, M=3, alg="rwmh",
                   backend="forwarddiff", *, sigma_z=None, sigma_m=None, sigma_p=None, device=0, ctx=None,
-                  seed=0, chain_id=0, return_z=False, nchains=1):
+                  seed=0, chain_id=0, return_z=False, nchains=1, include_prior=False):
     """src/space_inference.jl:82-164 for a Chain model and alg = :rwmh.
 
     `density(z)` (:90-95: W_swa + P*z -> model_re -> forward over the FULL data -> Gaussian log-likelihood,
     prior term dead) and the RWMH loop (:111-116) run on the device; the output map (:125) materialises
     `W_swa + P*z` for every sample like the reference unless `return_z=True` (then chn is the M x itr matrix
-    of subspace samples).  σ_p is accepted and unused, exactly as in the reference (quirk Q4).
+    of subspace samples).  σ_p is accepted and unused, exactly as in the reference (quirk Q4), unless
+    `include_prior=True` (non-default) asks for the term the reference's source writes after its `return`.
 
     `nchains > 1` (RWMH only; not in the reference, which runs one chain per call) runs the independent chains
     chain_id .. chain_id+nchains-1 stacked in every launch of the forward pass: chn becomes a list over chains
@@ -121,6 +129,7 @@ def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=10
     """
     σ_z = σ_z if sigma_z is None else sigma_z
     σ_m = σ_m if sigma_m is None else sigma_m
+    σ_p = σ_p if sigma_p is None else sigma_p
     a = _alg_name(alg)
     if a == "advi":
         raise SubspaceError("advi is outside what this build accelerates (SURVEY section 2)")
@@ -141,6 +150,8 @@ def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=10
                 # reference: MvNormal(zeros(M), σ_z) proposal against an N x size(P,2) matrix -> DimensionMismatch in P*z
                 raise SubspaceError("DimensionMismatch: P has %d columns but M = %d" % (P.shape[1], M))
             ctx.infer_setup(table, n_par, M, W_swa, P, x, y, σ_m)
+        # include_prior=True adds the term the reference leaves dead after its `return` (quirk Q4); default: as the reference
+        ctx.set_prior(σ_p if include_prior else 0.0)
         if nchains != 1 and a not in _RWMH_ALGS:
             raise SubspaceError("nchains > 1 is available for alg = :rwmh / :mh only")
         if a in _RWMH_ALGS and nchains > 1:

@@ -120,6 +120,9 @@ static void free_infer(Ctx* c) {
   c->fuse_tail = false;
   dev_free(c->d_Xc);
   dev_free(c->d_wpack);
+  dev_free(c->d_wsq);
+  dev_free(c->d_wsqpart);
+  c->sigma_p = 0.0;
   dev_free(c->g_scratch.bwpart);
   dev_free(c->g_scratch.rspart);
   dev_free(c->g_scratch.wt);
@@ -294,6 +297,31 @@ int32_t si_construct_begin(si_ctx* ctx, int64_t N, int64_t K_capacity, int32_t m
   // W_swa = zeros(N)  (reference :31, quirk Q1: NOT the pretrained weights)
   SI_HIP(ctx, hipMemsetAsync(ctx->d_swa, 0, (size_t)ctx->ldA * sizeof(double), ctx->stream));
   ctx->c_active = true;
+  return SI_OK;
+}
+
+int32_t si_construct_set_mean(si_ctx* ctx, const void* w_host, int32_t w_dtype) {
+  CHECK_CTX(ctx);
+  if (!ctx->c_active || ctx->npush != 0)
+    return fail(ctx, SI_ERR_STATE, "si_construct_set_mean: call it right after si_construct_begin, before the first push");
+  if (!w_host || (w_dtype != SI_F32 && w_dtype != SI_F64)) return fail(ctx, SI_ERR_INVALID, "si_construct_set_mean: bad pointer or dtype");
+  BIND(ctx);
+  if (w_dtype == SI_F64) {
+    SI_HIP(ctx, hipMemcpyAsync(ctx->d_swa, w_host, (size_t)ctx->N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    const size_t bytes = (size_t)ctx->N * 4;
+    if (ctx->wstage_bytes < bytes) {
+      SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      dev_free(ctx->d_wstage);
+      ctx->wstage_bytes = 0;
+      if (hipMalloc(&ctx->d_wstage, bytes) != hipSuccess) return fail(ctx, SI_ERR_NOMEM, "si_construct_set_mean: staging allocation failed");
+      ctx->wstage_bytes = bytes;
+    }
+    SI_HIP(ctx, hipMemcpyAsync(ctx->d_wstage, w_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    launch_widen_f32(ctx->stream, static_cast<const float*>(ctx->d_wstage), ctx->d_swa, ctx->N, ctx->num_cu);
+  }
+  SI_HIP(ctx, hipGetLastError());
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));  // w_host is caller-owned
   return SI_OK;
 }
 
@@ -711,6 +739,9 @@ static bool alloc_forward(si_ctx* ctx, int slots) {
       (ctx->fuse_tail && (dev_alloc(&ctx->d_part, S * (size_t)ctx->fuse_slots * dB) != hipSuccess ||
                           dev_alloc(&ctx->d_yhat, S * dB) != hipSuccess)))
     return false;
+  dev_free(ctx->d_wsqpart);
+  ctx->wsq_blocks = sse_num_blocks(ctx->iN, ctx->num_cu);
+  if (dev_alloc(&ctx->d_wsqpart, S * (size_t)ctx->wsq_blocks) != hipSuccess) return false;
   ctx->fw_slots = slots;
   return true;
 }
@@ -884,8 +915,9 @@ static int32_t ensure_chains(si_ctx* ctx, int32_t C) {
   dev_free(ctx->d_sse);
   dev_free(ctx->d_nacc);
   dev_free(ctx->d_steps);
+  dev_free(ctx->d_wsq);
   ctx->chains_cap = 0;
-  if (dev_alloc(&ctx->d_zcur, (size_t)ctx->iM * C) != hipSuccess || dev_alloc(&ctx->d_zprop, (size_t)ctx->iM * C) != hipSuccess ||
+  if (dev_alloc(&ctx->d_wsq, (size_t)C) != hipSuccess || dev_alloc(&ctx->d_zcur, (size_t)ctx->iM * C) != hipSuccess || dev_alloc(&ctx->d_zprop, (size_t)ctx->iM * C) != hipSuccess ||
       dev_alloc(&ctx->d_lpcur, (size_t)C) != hipSuccess || dev_alloc(&ctx->d_sse, (size_t)C) != hipSuccess ||
       dev_alloc(&ctx->d_nacc, (size_t)C) != hipSuccess || dev_alloc(&ctx->d_steps, (size_t)C) != hipSuccess)
     return fail(ctx, SI_ERR_NOMEM, "sampler state allocation failed");
@@ -905,6 +937,8 @@ static int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out
     launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, ctx->d_zprop + (size_t)c0 * M, nc, ctx->d_w, ldw,
                        ctx->num_cu);
   }
+  if (ctx->sigma_p > 0.0)  // ||new_W||^2 per chain for the optional prior term (same fixed-order reduction as the SSE)
+    launch_sse(ctx->stream, ctx->d_w, nullptr, N, ctx->d_wsqpart, ctx->wsq_blocks, ctx->d_wsq + c0, nc, ldw);
   if (ctx->plan.has_conv) {
     // generic path (capi_net.hip): Conv / MaxPool / flatten / Dense layers one after the other, ping-pong activations
     const size_t nl = ctx->plan.L.size();
@@ -988,6 +1022,18 @@ static double mvnormal_c0(double d, double sigma) {
   return -(d * std::log(2.0 * 3.14159265358979323846) + d * std::log(sigma * sigma)) / 2.0;
 }
 
+// log N(w; 0, sigma_p^2 I) = c0p - ||w||^2 / (2 sigma_p^2): the term the reference writes AFTER its `return` (Q4)
+static double prior_c0(const si_ctx* ctx) { return ctx->sigma_p > 0.0 ? mvnormal_c0((double)ctx->iN, ctx->sigma_p) : 0.0; }
+
+int32_t si_infer_set_prior(si_ctx* ctx, double sigma_p) {
+  CHECK_CTX(ctx);
+  if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_infer_set_prior: call si_infer_setup first");
+  if (ctx->sw_Z) return fail(ctx, SI_ERR_STATE, "si_infer_set_prior: a step-wise RWMH session is open");
+  if (!(sigma_p >= 0.0)) return fail(ctx, SI_ERR_INVALID, "si_infer_set_prior: sigma_p must be >= 0 (0 = off, the reference's behaviour)");
+  ctx->sigma_p = sigma_p;
+  return SI_OK;
+}
+
 int32_t si_logdensity(si_ctx* ctx, const double* Z, int32_t C, double* lp_out) {
   CHECK_CTX(ctx);
   if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_logdensity: call si_infer_setup first");
@@ -998,12 +1044,17 @@ int32_t si_logdensity(si_ctx* ctx, const double* Z, int32_t C, double* lp_out) {
   if (rc != SI_OK) return rc;
   SI_HIP(ctx, hipMemcpyAsync(ctx->d_zprop, Z, (size_t)ctx->iM * C * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   if ((rc = eval_density_all(ctx, C)) != SI_OK) return rc;
-  std::vector<double> sse((size_t)C);
+  std::vector<double> sse((size_t)C), wsq((size_t)C, 0.0);
   SI_HIP(ctx, hipMemcpyAsync(sse.data(), ctx->d_sse, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->sigma_p > 0.0)
+    SI_HIP(ctx, hipMemcpyAsync(wsq.data(), ctx->d_wsq, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const double d = (double)ctx->out_dim * (double)ctx->B;
   const double c0 = mvnormal_c0(d, ctx->sigma_m), s2 = ctx->sigma_m * ctx->sigma_m;
-  for (int c = 0; c < C; ++c) lp_out[c] = c0 - (sse[(size_t)c] / s2) / 2.0;
+  for (int c = 0; c < C; ++c) {
+    lp_out[c] = c0 - (sse[(size_t)c] / s2) / 2.0;
+    if (ctx->sigma_p > 0.0) lp_out[c] += prior_c0(ctx) - (wsq[(size_t)c] / (ctx->sigma_p * ctx->sigma_p)) / 2.0;
+  }
   return SI_OK;
 }
 
@@ -1081,6 +1132,8 @@ int32_t si_logdensity_grad(si_ctx* ctx, const double* z, double* lp_out, double*
     ProfScope ps(ctx, SI_K_RECON, 2.0 * (double)N * M, (double)N * (M + 2) * 8.0);
     launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, ctx->d_zprop, 1, ctx->d_w, pad_ld(N), ctx->num_cu);
   }
+  const bool prior = ctx->sigma_p > 0.0;
+  if (prior) launch_sse(ctx->stream, ctx->d_w, nullptr, N, ctx->d_wsqpart, ctx->wsq_blocks, ctx->d_wsq, 1, pad_ld(N));
   if (ctx->plan.has_conv) {
     // generic path: forward with every output kept, d lp / d yhat = (y - yhat) / sigma^2, reverse sweep, P' g_w
     const NetPlan& p = ctx->plan;
@@ -1100,14 +1153,18 @@ int32_t si_logdensity_grad(si_ctx* ctx, const double* z, double* lp_out, double*
       if ((rc = net_backward(ctx, p, ctx->d_w, xin, B, ctx->d_hs.data(), ctx->d_delta[0], ctx->d_delta[1], ctx->d_gw,
                              ctx->g_scratch)) != SI_OK)
         return rc;
+      if (prior) launch_prior_grad(ctx->stream, ctx->d_gw, ctx->d_w, N, 1.0 / (ctx->sigma_p * ctx->sigma_p), ctx->num_cu);
       launch_ptg(ctx->stream, ctx->i_P, ctx->ldP, N, M, ctx->d_gw, ctx->d_ptgpart, ctx->d_gz);
     }
     SI_HIP(ctx, hipGetLastError());
     double sse = 0.0;
     SI_HIP(ctx, hipMemcpyAsync(&sse, ctx->d_sse, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SI_HIP(ctx, hipMemcpyAsync(grad_out, ctx->d_gz, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    double wsq = 0.0;
+    if (prior) SI_HIP(ctx, hipMemcpyAsync(&wsq, ctx->d_wsq, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *lp_out = mvnormal_c0((double)d, ctx->sigma_m) - (sse / s2) / 2.0;
+    if (prior) *lp_out += prior_c0(ctx) - (wsq / (ctx->sigma_p * ctx->sigma_p)) / 2.0;
     return SI_OK;
   }
   // forward with every layer's output kept for the reverse sweep.  With a narrow head (fuse_tail) the layer in front
@@ -1175,14 +1232,18 @@ int32_t si_logdensity_grad(si_ctx* ctx, const double* z, double* lp_out, double*
         cur ^= 1;
       }
     }
+    if (prior) launch_prior_grad(ctx->stream, ctx->d_gw, ctx->d_w, N, 1.0 / (ctx->sigma_p * ctx->sigma_p), ctx->num_cu);
     launch_ptg(ctx->stream, ctx->i_P, ctx->ldP, N, M, ctx->d_gw, ctx->d_ptgpart, ctx->d_gz);
   }
   SI_HIP(ctx, hipGetLastError());
   double sse = 0.0;
   SI_HIP(ctx, hipMemcpyAsync(&sse, ctx->d_sse, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SI_HIP(ctx, hipMemcpyAsync(grad_out, ctx->d_gz, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  double wsq = 0.0;
+  if (prior) SI_HIP(ctx, hipMemcpyAsync(&wsq, ctx->d_wsq, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *lp_out = mvnormal_c0((double)d, ctx->sigma_m) - (sse / s2) / 2.0;
+  if (prior) *lp_out += prior_c0(ctx) - (wsq / (ctx->sigma_p * ctx->sigma_p)) / 2.0;
   return SI_OK;
 }
 
@@ -1297,7 +1358,8 @@ int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, 
     if (r != SI_OK) return r;
     ProfScope ps(ctx, SI_K_RWMH, 0, 0);
     launch_rwmh_accept(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->d_lpcur, ctx->d_sse, ctx->d_nacc, M, C, c0, s2, seed,
-                       chain_id0, ctx->d_steps, dZ, dlp, itr);
+                       chain_id0, ctx->d_steps, dZ, dlp, itr, ctx->sigma_p > 0.0 ? ctx->d_wsq : nullptr, prior_c0(ctx),
+                       ctx->sigma_p * ctx->sigma_p);
     return SI_OK;
   };
   // Replaying one captured transition as a hipGraph was measured and dropped: the README-toy transition takes 27.8 us
@@ -1390,7 +1452,8 @@ int32_t si_rwmh_step_accept(si_ctx* ctx, const double* sse_total) {
   }
   const double c0 = mvnormal_c0(ctx->sw_d, ctx->sigma_m), s2 = ctx->sigma_m * ctx->sigma_m;
   launch_rwmh_accept(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->d_lpcur, ctx->d_sse, ctx->d_nacc, ctx->iM, C, c0, s2,
-                     ctx->sw_seed, ctx->sw_chain0, ctx->d_steps, ctx->sw_Z, ctx->sw_lp, ctx->sw_itr);
+                     ctx->sw_seed, ctx->sw_chain0, ctx->d_steps, ctx->sw_Z, ctx->sw_lp, ctx->sw_itr,
+                     ctx->sigma_p > 0.0 ? ctx->d_wsq : nullptr, prior_c0(ctx), ctx->sigma_p * ctx->sigma_p);
   SI_HIP(ctx, hipGetLastError());
   ctx->sw_next += 1;
   ctx->sw_evaluated = false;

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void sse_partial_kernel(const double* __restri
   part += (int64_t)blockIdx.y * gridDim.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d; i += stride) {
-    const double r = y[i] - yhat[i];
+    const double r = (y ? y[i] : 0.0) - yhat[i];   // y == nullptr: plain sum of squares (the optional prior term ||w||^2)
     acc += r * r;
   }
   acc = wave_sum(acc);
@@ -336,12 +336,14 @@ __global__ void rwmh_accept_kernel(double* __restrict__ zcur, const double* __re
                                    int64_t* __restrict__ nacc, int32_t M, double c0, double sigma2,
                                    uint64_t seed, int32_t chain_id0, uint64_t* __restrict__ steps,
                                    double* __restrict__ Z_out, double* __restrict__ lp_out,
-                                   int64_t itr) {
+                                   int64_t itr, const double* __restrict__ wsq, double c0p, double sigma_p2) {
   const int c = blockIdx.x;
   const uint64_t step = steps[c];
   const uint32_t chain = (uint32_t)(chain_id0 + c);
   // Distributions.logpdf(MvNormal(mu, sigma), y) = c0 - (sse / sigma^2) / 2
-  const double lp_new = c0 - (sse[c] / sigma2) / 2.0;
+  double lp_new = c0 - (sse[c] / sigma2) / 2.0;
+  // non-default option: + logpdf(MvNormal(zeros(N), sigma_p), new_W) -- the term the reference leaves dead (Q4)
+  if (wsq) lp_new += c0p - (wsq[c] / sigma_p2) / 2.0;
   const double lp_old = lpcur[c];
   bool accept;
   if (step == 0) {
@@ -375,9 +377,26 @@ void launch_rwmh_propose(hipStream_t st, const double* zcur, double* zprop, int3
 void launch_rwmh_accept(hipStream_t st, double* zcur, const double* zprop, double* lpcur,
                         const double* sse, int64_t* nacc, int32_t M, int32_t C, double c0,
                         double sigma2, uint64_t seed, int32_t chain_id0, uint64_t* steps,
-                        double* Z_out, double* lp_out, int64_t itr) {
+                        double* Z_out, double* lp_out, int64_t itr, const double* wsq, double c0p, double sigma_p2) {
   hipLaunchKernelGGL(rwmh_accept_kernel, dim3(C), dim3(64), 0, st, zcur, zprop, lpcur, sse, nacc, M, c0,
-                     sigma2, seed, chain_id0, steps, Z_out, lp_out, itr);
+                     sigma2, seed, chain_id0, steps, Z_out, lp_out, itr, wsq, c0p, sigma_p2);
+}
+
+// g[i] -= w[i] * inv_s2   (gradient of the optional prior term -||w||^2 / (2 sigma_p^2))
+__global__ __launch_bounds__(256) void prior_grad_kernel(double* __restrict__ g, const double* __restrict__ w, int64_t n, double inv_s2) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] -= w[i] * inv_s2;
+}
+void launch_prior_grad(hipStream_t st, double* g, const double* w, int64_t n, double inv_s2, int num_cu) {
+  hipLaunchKernelGGL(prior_grad_kernel, dim3(stream_grid(n, num_cu)), dim3(256), 0, st, g, w, n, inv_s2);
+}
+// dst[i] = (double)src[i]  (initial W_swa from Float32 weights: the non-default init = :pretrained option)
+__global__ __launch_bounds__(256) void widen_f32_kernel(const float* __restrict__ src, double* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (double)src[i];
+}
+void launch_widen_f32(hipStream_t st, const float* src, double* dst, int64_t n, int num_cu) {
+  hipLaunchKernelGGL(widen_f32_kernel, dim3(stream_grid(n, num_cu)), dim3(256), 0, st, src, dst, n);
 }
 
 }  // namespace si

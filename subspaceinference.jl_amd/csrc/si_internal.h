@@ -140,6 +140,10 @@ struct Ctx {
   int32_t in_dim = 0, out_dim = 0;
   int64_t B = 0;
   double sigma_m = 1.0;
+  double sigma_p = 0.0;          // > 0: the prior term the reference leaves dead is added (si_infer_set_prior; non-default)
+  double* d_wsq = nullptr;       // ||W_swa + P z_c||^2 per chain (chains_cap), only with the prior on
+  double* d_wsqpart = nullptr;   // its block partials (fw_slots x wsq_blocks)
+  int wsq_blocks = 0;
   // forward workspace: `fw_slots` chain slots (1 after si_infer_setup; grown by ensure_batch for multi-chain calls)
   int fw_slots = 0;
   double* d_w = nullptr;       // reconstructed weights, fw_slots x pad_ld(N)
@@ -320,7 +324,10 @@ void launch_rwmh_propose(hipStream_t st, const double* zcur, double* zprop, int3
 void launch_rwmh_accept(hipStream_t st, double* zcur, const double* zprop, double* lpcur,
                         const double* sse, int64_t* nacc, int32_t M, int32_t C, double c0,
                         double sigma2, uint64_t seed, int32_t chain_id0, uint64_t* steps,
-                        double* Z_out, double* lp_out, int64_t itr);
+                        double* Z_out, double* lp_out, int64_t itr, const double* wsq = nullptr, double c0p = 0.0,
+                        double sigma_p2 = 1.0);
+void launch_prior_grad(hipStream_t st, double* g, const double* w, int64_t n, double inv_s2, int num_cu);
+void launch_widen_f32(hipStream_t st, const float* src, double* dst, int64_t n, int num_cu);
 
 // host symmetric eigensolver (eig.cpp): a is n x n symmetric col-major, overwritten by eigenvectors
 // (columns), w gets eigenvalues ascending.  Returns 0 on success.

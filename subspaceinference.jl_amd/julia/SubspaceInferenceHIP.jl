@@ -202,13 +202,20 @@ function train_on_device!(ctx::Ctx, model, data, opt, T, c, print_freq)
     end
 end
 
+# init = :zeros is what the reference's code does (W_swa = zeros, :31); :pretrained is what its docs describe (nn_example.md:44)
 function subspace_construction(model, cost, data, opt; T = 10, c = 1, M = 3, print_freq = 1, device = 0,
-                               ctx = Ctx(device), max_cols = 0, keep_on_device = false, device_training = false)
+                               ctx = Ctx(device), max_cols = 0, keep_on_device = false, device_training = false,
+                               init = :zeros)
     training_loss = 0.0
     ps = Flux.params(model)
     N = sum(length, ps)
     npush = count(i -> mod(i, c) == 0, 1:T) * length(data)
     check(ctx, ccall((:si_construct_begin, LIB), Int32, (Ptr{Cvoid}, Int64, Int64, Int32), ctx.h, N, npush, max_cols))
+    if init == :pretrained
+        W0 = extract_params(ps)
+        GC.@preserve W0 check(ctx, ccall((:si_construct_set_mean, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32),
+                                         ctx.h, pointer(W0), eltype(W0) == Float32 ? SI_F32 : SI_F64))
+    end
     if device_training
         train_on_device!(ctx, model, data, opt, T, c, print_freq)
     else
@@ -273,8 +280,9 @@ function reconstruct(ctx::Ctx, Z::Matrix{Float64}, N)
     return [Wm[:, t] for t in 1:size(Z, 2)]
 end
 
+# include_prior = true adds the term the reference writes after its `return` (dead code, :95); default: as the reference
 function sub_inference(in_model, data, W_swa, P; σ_z = 1.0, σ_m = 1.0, σ_p = 1.0, itr = 100, M = 3, alg = :rwmh,
-                       backend = :forwarddiff, device = 0, ctx = Ctx(device), seed = 0, chain_id = 0)
+                       backend = :forwarddiff, device = 0, ctx = Ctx(device), seed = 0, chain_id = 0, include_prior = false)
     alg == :mh && (alg = :rwmh)                                     # README.md:153-154
     alg in (:rwmh, :mala, :hmc, :nuts) || throw("$alg is not available")       # :162 (:advi is outside this build)
     in_model isa Chain || throw("Error: density function is not avaliable for this model")
@@ -286,6 +294,7 @@ function sub_inference(in_model, data, W_swa, P; σ_z = 1.0, σ_m = 1.0, σ_p = 
         (Ptr{Cvoid}, Ptr{SiLayer}, Int32, Int64, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
          Int32, Int32, Int64, Float64, Int32),
         ctx.h, tbl, length(tbl), N, M, Wp, Pp, X, Y, size(X, 1), size(Y, 1), size(X, 2), σ_m, SI_F64))
+    check(ctx, ccall((:si_infer_set_prior, LIB), Int32, (Ptr{Cvoid}, Float64), ctx.h, include_prior ? Float64(σ_p) : 0.0))
     if alg == :rwmh
         # :111-116 on the device: chain state, proposals (Philox) and accept decisions never leave the GPU
         Z = Matrix{Float64}(undef, M, itr); lp = Vector{Float64}(undef, itr); acc = Ref{Float64}(0.0)

@@ -1002,3 +1002,60 @@ def test_random_shape_sweep_construction(gpu_ctx):
         gaps = np.abs(np.diff(np.r_[s_ref[:m], sv[m] if m < sv.size else 0.0])) / s_ref[0]
         if gaps.min() > 1e-6:                                          # individual vectors are defined only away from ties
             assert np.allclose(_align_signs(p, p_ref), p_ref, rtol=1e-5, atol=1e-7 * np.abs(p_ref).max()), tag
+
+
+# ----------------------------------------------------------------------------------------------- non-default options
+def test_option_init_pretrained(si, gpu_ctx):
+    """Q1: the reference's CODE starts W_swa at zeros (default, bit-exact elsewhere); `init=:pretrained` is what its docs
+    describe.  Both against the oracle's recurrence, bit for bit."""
+    n, k = 4099, 6
+    snaps = _snap_stream(n, k, seed=77, dtype=np.float32)
+    ns = [1.0, 1.0, 2.0, 2.0, 3.0, 3.0]
+    for w_init in (None, snaps[0], snaps[0].astype(np.float64) * 0.5):
+        w_ref, a_ref = so.construct_stream(snaps, ns, w_init=w_init)
+        gpu_ctx.construct_begin(n, k)
+        if w_init is not None:
+            gpu_ctx.construct_set_mean(w_init)
+        for w, nn in zip(snaps, ns):
+            gpu_ctx.construct_push(w, nn)
+        assert np.array_equal(gpu_ctx.construct_get_A(0, k), a_ref)
+        assert np.array_equal(gpu_ctx.construct_finish(1, want_p=False)[0], w_ref)
+    with pytest.raises(si.SubspaceError):
+        gpu_ctx.construct_set_mean(snaps[0])      # only right after begin
+    from subspaceinference_jl_amd import flux
+    rng = np.random.default_rng(0)
+    x, y = rng.random((6, 30)), rng.random((1, 30))
+    outs = []
+    for init in ("zeros", ":pretrained"):
+        wr = np.random.default_rng(3)
+        m = flux.Chain(flux.Dense(6, 8, flux.tanh, rng=wr), flux.Dense(8, 1, rng=wr))
+        outs.append(si.subspace_construction(m, flux.mse, flux.DataLoader(x, y, batchsize=10), flux.Descent(0.05), T=3, M=2,
+                                             ctx=gpu_ctx, verbose=False, init=init, device_training=False)[0])
+    assert not np.allclose(outs[0], outs[1])      # zeros: W_swa is pulled towards 0 (first update = W/2)
+
+
+def test_option_include_prior(si, gpu_ctx):
+    """Q4: the prior term is dead code in the reference (default: likelihood only).  With include_prior the density, its
+    gradient and the RWMH chain carry + logpdf(MvNormal(zeros(N), sigma_p), W_swa + P z)."""
+    dims, acts, b, m = [6, 24, 2], [2, 0], 120, 4
+    table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=31)
+    gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=1.5)
+    z = np.asfortranarray(0.3 * np.random.default_rng(5).standard_normal((m, 3)))
+    lp_like = gpu_ctx.logdensity(z)
+    sp = 0.7
+    gpu_ctx.set_prior(sp)
+    lp = gpu_ctx.logdensity(z)
+    ref = [so.logdensity(table, w_swa, p, x, y, 1.5, z[:, c]) + so.log_prior(w_swa + p @ z[:, c], sp) for c in range(3)]
+    assert np.allclose(lp, ref, rtol=1e-11)
+    lpg, g = gpu_ctx.logdensity_grad(z[:, 1])
+    _, g_like, _ = so.logdensity_grad(table, w_swa, p, x, y, 1.5, z[:, 1])
+    g_ref = g_like - p.T @ (w_swa + p @ z[:, 1]) / sp ** 2
+    assert np.isclose(lpg, ref[1], rtol=1e-11) and np.allclose(g, g_ref, rtol=1e-8, atol=1e-10 * np.abs(g_ref).max())
+    dens = lambda zz: so.logdensity(table, w_swa, p, x, y, 1.5, zz) + so.log_prior(w_swa + p @ zz, sp)
+    zs, lps, _ = gpu_ctx.sample_rwmh(40, 0.05, seed=9)
+    zr, lpr, _ = so.rwmh(dens, m, 40, 0.05, seed=9)
+    assert np.allclose(zs[:, :, 0], zr, rtol=1e-9, atol=1e-12) and np.allclose(lps[:, 0], lpr, rtol=1e-10)
+    gpu_ctx.set_prior(0.0)                         # off again: the reference's behaviour
+    assert np.array_equal(gpu_ctx.logdensity(z), lp_like)
+    gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=1.5)
+    assert np.array_equal(gpu_ctx.logdensity(z), lp_like)   # a new set-up starts without the prior

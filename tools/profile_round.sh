@@ -1,0 +1,38 @@
+#!/bin/bash
+# Collects the round's evidence on the GPU box (run through gpurun from the repository root):
+#   kernel-trace statistics of bench.py and of the cfg4 CNN bench, PMC passes for the dominant kernels (separate passes,
+#   --kernel-trace only, as gpurun requires), the bench lines of every mode.  Everything lands in gpurun_out/r2prof/;
+#   the summaries worth judging are copied into profiles/ by hand.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r2prof
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+echo "[1] bench.py under rocprofv3 --kernel-trace --stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_kt -o b -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+python3 $R/tools/kstats.py $O/bench_kt 25 > $O/bench_kernel_stats.txt
+cp $(find $O/bench_kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+echo "[2] PMC passes on bench.py (dense kernels)"
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  tag=$(echo $c | tr ' ' '_')
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$tag -o p -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pmc_$tag.err
+  echo "== --pmc $c" >> $O/pmc_dense_summary.txt
+  python3 $R/tools/pmc_summary.py $O/pmc_$tag dense_f64 >> $O/pmc_dense_summary.txt
+  echo "== --pmc $c" >> $O/pmc_gram_summary.txt
+  python3 $R/tools/pmc_summary.py $O/pmc_$tag gram_ >> $O/pmc_gram_summary.txt
+  rm -rf $O/pmc_$tag
+done
+echo "[3] cfg4 CNN"
+python3 $R/tools/cfg4_cnn_bench.py 4096 > $O/cfg4_cnn.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/cnn_kt -o c -- python3 $R/tools/cfg4_cnn_bench.py 4096 > /dev/null 2>&1
+python3 $R/tools/kstats.py $O/cnn_kt 20 > $O/cfg4_cnn_kernel_stats.txt
+rm -rf $O/cnn_kt $O/bench_kt
+echo "[4] bench lines"
+cd $R
+python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+python3 bench.py --steps 1000 --warmup 10 --no-cpu-baseline > $O/bench_itr1000.json 2>> $O/bench_n1.err
+for m in "construct-sharded --config cfg4" "construct-sharded --config cfg5" "data-sharded"; do
+  SI_BENCH_FORCE_DIST=1 python3 bench.py --mode $m >> $O/bench_modes.json 2>> $O/bench_modes.err
+done
+python3 tools/small_model_steps.py > $O/small_model_steps.log 2>&1
+echo done
