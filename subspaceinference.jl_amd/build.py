@@ -23,6 +23,7 @@ SOURCES = [
     ("kernels_gram_wave.hip", ["-DSI_GW_PART=0"], "kernels_gram_wave0"),   # same source, three slices of the tile counts
     ("kernels_gram_wave.hip", ["-DSI_GW_PART=1"], "kernels_gram_wave1"),
     ("kernels_gram_wave.hip", ["-DSI_GW_PART=2"], "kernels_gram_wave2"),
+    ("kernels_project.hip", []),
     ("kernels_bwd.hip", []),
     ("kernels_conv.hip", []),
     ("capi_net.hip", []),

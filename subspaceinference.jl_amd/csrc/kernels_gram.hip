@@ -399,6 +399,7 @@ static void gram_off_dispatch(hipStream_t st, const double* A, int64_t ldA, int6
 // (The one-stage reduction of round 1 gave a tile to ONE workgroup: 28 workgroups pulling 29 MB at K = 100 took 0.05 ms,
 // a fifth of the Gram kernel itself.)
 // ------------------------------------------------------------------------------------------------
+int gram_wave_blocks_per_cu(int nt);
 bool launch_gram_wave_part0(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks);
 bool launch_gram_wave_part1(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks);
 bool launch_gram_wave_part2(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks);
@@ -473,7 +474,7 @@ size_t launch_gram(hipStream_t st, const double* A, int64_t ldA, int64_t N, int6
   const int npan = (int)((K + 127) / 128);
   const int ntw = (int)((K + 15) / 16);
   const bool wave_path = ntw <= 13 && !gram_force_panels();
-  const int64_t nb_wave = std::min<int64_t>((int64_t)num_cu, nslab_d);   // one 4-wave workgroup per CU
+  const int64_t nb_wave = std::min<int64_t>((int64_t)num_cu * gram_wave_blocks_per_cu(ntw), nslab_d);
   const size_t need = wave_path ? ((size_t)nb_wave + GR2_Y) * (size_t)(ntw * (ntw + 1) / 2) * 256 * sizeof(double)
                                 : (size_t)std::max<int64_t>(nb_diag * 36, npan > 1 ? nb_off * 64 : 0) * 256 * sizeof(double);
   if (Gpart == nullptr) return need;
@@ -531,6 +532,15 @@ __global__ __launch_bounds__(256) void project_kernel(const double* __restrict__
   }
 }
 
+// development knob: SI_PROJECT_GEMM=1 keeps the generic GEMM for wide subspaces (comparison runs)
+static bool project_force_gemm() {
+  static const bool v = [] {
+    const char* e = getenv("SI_PROJECT_GEMM");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+
 int project_mpad(int M) {
   int m0 = 0;
   while (m0 < M) {
@@ -542,9 +552,12 @@ int project_mpad(int M) {
 
 void launch_project(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, const double* V,
                     int32_t M, int32_t Mpad, double* P, int64_t ldP, int num_cu) {
-  if (M > 32 && N < 0x7fffffff) {  // wide subspace: one pass over A on the matrix cores instead of ceil(M/32) VALU passes
-    launch_project_mfma(st, A, ldA, N, K, V, M, Mpad, P, ldP);
-    return;
+  if (M > 32) {  // wide subspace: one pass over A on the matrix cores instead of ceil(M/32) VALU passes
+    if (!project_force_gemm() && launch_project_stream(st, A, ldA, N, K, V, M, Mpad, P, ldP, num_cu)) return;  // K <= 128: slab stream
+    if (N < 0x7fffffff) {
+      launch_project_mfma(st, A, ldA, N, K, V, M, Mpad, P, ldP);
+      return;
+    }
   }
   int64_t blocks = (((N + 1) >> 1) + 255) / 256;
   if (blocks > (int64_t)num_cu * 8) blocks = (int64_t)num_cu * 8;

@@ -16,6 +16,10 @@
 
 #include "si_internal.h"
 
+#ifndef SI_GW_PART
+#error "compile with -DSI_GW_PART=0|1|2"
+#endif
+
 namespace si {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -252,8 +256,8 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
   }
 }
 
-template <int NT, int KS, int NB>
-__global__ __launch_bounds__(64 * GW_WAVES, 1) void gram_glds_kernel(const double* __restrict__ A, int64_t ldA, int64_t N, int K,
+template <int NT, int KS, int NB, int OCC>
+__global__ __launch_bounds__(64 * GW_WAVES, OCC) void gram_glds_kernel(const double* __restrict__ A, int64_t ldA, int64_t N, int K,
                                                                      double* __restrict__ Gpart) {
   extern __shared__ double sA[];  // [NB][NT*16][32]
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
@@ -265,48 +269,72 @@ __global__ __launch_bounds__(64 * GW_WAVES, 1) void gram_glds_kernel(const doubl
 }
 
 
-template <int NT, int KS>
-static void launch_nt(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks) {
+// Up to K = 144 two workgroups per CU (two ring buffers each; 8 * pairs-per-wave + ~90 registers <= 256) are the shipped
+// configuration: 0-6 % faster than one workgroup with a 4-deep ring (K = 100: 0.275 ms either way; K = 128: 2.22 against
+// 2.33 ms at N = 6.4 M; K = 144: 0.411 against 0.437 ms).  Development knob SI_GRAM_OCC1=1 selects the other one.
+static bool gram_two_per_cu() {
+  static const bool v = [] {
+    const char* e = getenv("SI_GRAM_OCC1");
+    return !(e && e[0] == '1');
+  }();
+  return v;
+}
+
+// KS / KS2: k-step split with one / two workgroups per CU (two per CU needs 8 * pairs-per-wave + ~90 registers <= 256)
+template <int NT, int KS, int KS2>
+static void launch_nt(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks, int num_cu) {
+  if constexpr (KS2 > 0) {
+    if (gram_two_per_cu()) {
+      constexpr int NB = 2;
+      constexpr size_t lds = (size_t)NB * NT * 16 * GR * sizeof(double);
+      static LdsOptIn optin;
+      optin.ensure(reinterpret_cast<const void*>(gram_glds_kernel<NT, KS2, NB, 2>), lds);
+      hipLaunchKernelGGL((gram_glds_kernel<NT, KS2, NB, 2>), dim3(nblocks), dim3(64 * GW_WAVES), lds, st, A, ldA, N, K, tiles);
+      return;
+    }
+  }
   // LDS-DMA ring: as many buffers as 150 KB hold, at most 4
   constexpr int NB = (150 * 1024) / (NT * 16 * GR * 8) >= 4 ? 4 : (150 * 1024) / (NT * 16 * GR * 8) >= 3 ? 3 : 2;
   constexpr size_t lds = (size_t)NB * NT * 16 * GR * sizeof(double);
   static LdsOptIn optin;
-  optin.ensure(reinterpret_cast<const void*>(gram_glds_kernel<NT, KS, NB>), lds);
-  hipLaunchKernelGGL((gram_glds_kernel<NT, KS, NB>), dim3(nblocks), dim3(64 * GW_WAVES), lds, st, A, ldA, N, K, tiles);
+  optin.ensure(reinterpret_cast<const void*>(gram_glds_kernel<NT, KS, NB, 1>), lds);
+  hipLaunchKernelGGL((gram_glds_kernel<NT, KS, NB, 1>), dim3(nblocks), dim3(64 * GW_WAVES), lds, st, A, ldA, N, K, tiles);
 }
 
-#ifndef SI_GW_PART
-#error "compile with -DSI_GW_PART=0|1|2"
+// workgroups per CU the launcher of this tile count will use (the caller sizes the grid and the partial-tile workspace)
+#if SI_GW_PART == 0
+int gram_wave_blocks_per_cu(int nt) { return (nt <= 9 && gram_two_per_cu()) ? 2 : 1; }
 #endif
+
 // launches the partial-tile kernel for NT = ceil(K / 16) when this part holds it (tiles: nblocks x NT(NT+1)/2 x 256)
 #if SI_GW_PART == 0
 bool launch_gram_wave_part0(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks) {
   switch ((K + 15) / 16) {
-    case 1: launch_nt<1, 4>(st, A, ldA, N, K, tiles, nblocks); return true;
-    case 2: launch_nt<2, 4>(st, A, ldA, N, K, tiles, nblocks); return true;
-    case 3: launch_nt<3, 4>(st, A, ldA, N, K, tiles, nblocks); return true;
-    case 4: launch_nt<4, 4>(st, A, ldA, N, K, tiles, nblocks); return true;
-    case 5: launch_nt<5, 4>(st, A, ldA, N, K, tiles, nblocks); return true;
-    case 6: launch_nt<6, 4>(st, A, ldA, N, K, tiles, nblocks); return true;
-    case 7: launch_nt<7, 4>(st, A, ldA, N, K, tiles, nblocks); return true;
-    case 8: launch_nt<8, 2>(st, A, ldA, N, K, tiles, nblocks); return true;
+    case 1: launch_nt<1, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
+    case 2: launch_nt<2, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
+    case 3: launch_nt<3, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
+    case 4: launch_nt<4, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
+    case 5: launch_nt<5, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
+    case 6: launch_nt<6, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
+    case 7: launch_nt<7, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
+    case 8: launch_nt<8, 2, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
     default: return false;
   }
 }
 #elif SI_GW_PART == 1
 bool launch_gram_wave_part1(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks) {
   switch ((K + 15) / 16) {
-    case 9: launch_nt<9, 2>(st, A, ldA, N, K, tiles, nblocks); return true;
-    case 10: launch_nt<10, 2>(st, A, ldA, N, K, tiles, nblocks); return true;
-    case 11: launch_nt<11, 1>(st, A, ldA, N, K, tiles, nblocks); return true;
+    case 9: launch_nt<9, 2, 1>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
+    case 10: launch_nt<10, 2, 0>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
+    case 11: launch_nt<11, 1, 0>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
     default: return false;
   }
 }
 #else
 bool launch_gram_wave_part2(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks) {
   switch ((K + 15) / 16) {
-    case 12: launch_nt<12, 1>(st, A, ldA, N, K, tiles, nblocks); return true;
-    case 13: launch_nt<13, 1>(st, A, ldA, N, K, tiles, nblocks); return true;
+    case 12: launch_nt<12, 1, 0>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
+    case 13: launch_nt<13, 1, 0>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
     default: return false;
   }
 }

@@ -239,6 +239,9 @@ void launch_project(hipStream_t st, const double* A, int64_t ldA, int64_t N, int
 // the same product on the matrix cores (kernels_bwd.hip gemm_f64_kernel); launch_project uses it for M > 32
 void launch_project_mfma(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, const double* V, int32_t M,
                          int32_t Mpad, double* P, int64_t ldP);
+// K3 for wide subspaces as a slab stream (kernels_project.hip; K <= 128, else returns false)
+bool launch_project_stream(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, const double* V, int32_t M,
+                           int32_t Mpad, double* P, int64_t ldP, int num_cu);
 // K4: w[c*ldw + r] = swa[r] + sum_m P[r + m*ldP] * Z[m + c*M]
 void launch_reconstruct(hipStream_t st, const double* swa, const double* P, int64_t ldP, int64_t N,
                         int32_t M, const double* Z, int32_t C, double* w, int64_t ldw, int num_cu);

@@ -9,6 +9,7 @@ ProfScope::ProfScope(Ctx*, int, double, double) {}
 ProfScope::~ProfScope() {}
 // the wide-subspace projection lives in kernels_bwd.hip; this harness only exercises M <= 32
 void launch_project_mfma(hipStream_t, const double*, int64_t, int64_t, int64_t, const double*, int32_t, int32_t, double*, int64_t) {}
+bool launch_project_stream(hipStream_t, const double*, int64_t, int64_t, int64_t, const double*, int32_t, int32_t, double*, int64_t, int) { return false; }
 }
 using namespace si;
 __global__ void fill(double* a, size_t n, unsigned long long seed) {
