@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -188,6 +189,7 @@ int32_t si_create(si_ctx** out, int32_t device_id) {
     delete c;
     return fail(nullptr, SI_ERR_NODEVICE, m);
   }
+  if (const char* e = getenv("SI_OVERLAP_HALVES")) c->overlap_halves = e[0] == '1';
   *out = c;
   return SI_OK;
 }
@@ -204,6 +206,9 @@ int32_t si_destroy(si_ctx* ctx) {
   dev_free(ctx->d_wstage);
   dev_free(ctx->d_nvals);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return SI_OK;
@@ -954,6 +959,58 @@ static int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out
     }
     SI_HIP(ctx, hipGetLastError());
     if (yhat_out) *yhat_out = outs[nl - 1];
+    return SI_OK;
+  }
+  const size_t nl_all = ctx->layers.size();
+  if (ctx->overlap_halves && nc == 1 && ctx->fuse_tail && !yhat_out && B >= 4096) {
+    // EXPERIMENT: the batch in two halves on two streams -- layer 1 of half B runs beside layer 2 of
+    // half A, so the output-store drain of one overlaps the MFMAs of the other inside ONE chain.  The halves meet on whole
+    // 128-column tiles, so every tile is computed exactly as in the single launch; the head partials of both halves land
+    // in one buffer with the full-B pitch and ONE tail_sse launch sums them in the usual fixed order: lp is bit-identical.
+    if (!ctx->stream2) {
+      SI_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      SI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      SI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    const int64_t b1 = ((B / 2 + 127) / 128) * 128;
+    SI_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    SI_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    auto run_half = [&](hipStream_t st, int64_t b0, int64_t bh, bool prof) {
+      const double* h = ctx->d_X + (size_t)ctx->in_dim * b0;
+      const size_t nst = nl_all - 2;
+      for (size_t l = 0; l < nst; ++l) {
+        const si_layer& ly = ctx->layers[l];
+        double* o = ctx->d_act[l & 1] + (size_t)ly.out * b0;
+        ProfScope ps(prof ? ctx : nullptr, SI_K_DENSE, 2.0 * (double)ly.in * ly.out * (double)bh, 0.0);
+        launch_dense_f64(st, ctx->d_w + ly.w_off, ctx->d_w + ly.b_off, h, o, ly.out, ly.in, bh, ly.act);
+        h = o;
+      }
+      const si_layer& ly = ctx->layers[nl_all - 2];
+      const si_layer& ll = ctx->layers[nl_all - 1];
+      ChainBatch hb;
+      hb.part_ld = B;
+      const double fl = (2.0 * (double)ly.in * ly.out + 2.0 * (double)ll.in * ll.out) * (double)bh;
+      ProfScope ps(prof ? ctx : nullptr, SI_K_DENSE, fl, 0.0);
+      ProfScope pm(prof ? ctx : nullptr, SI_K_DENSE_MAIN, fl, 0.0);
+      launch_dense_f64_fused(st, ctx->d_w + ly.w_off, ctx->d_w + ly.b_off, h, ly.out, ly.in, bh, ly.act, ctx->d_w + ll.w_off, ll.out,
+                             ctx->d_part + b0, hb);
+    };
+    run_half(ctx->stream2, b1, B - b1, false);
+    run_half(ctx->stream, 0, b1, true);
+    SI_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+    SI_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    const si_layer& ll = ctx->layers[nl_all - 1];
+    const int64_t d = (int64_t)ctx->out_dim * B;
+    ChainBatch cb1;
+    cb1.part = (int64_t)ctx->fuse_slots * ctx->out_dim * B;
+    cb1.w = ldw;
+    {
+      ProfScope ps(ctx, SI_K_SSE, (3.0 + ctx->fuse_slots) * (double)d, (16.0 + 8.0 * ctx->fuse_slots) * (double)d);
+      launch_tail_sse(ctx->stream, ctx->d_part, ctx->fuse_slots, ll.out, B, ctx->d_w + ll.b_off, ll.act, ctx->d_Y, nullptr,
+                      ctx->d_ssepart, ctx->sse_blocks, cb1);
+      launch_sse_final(ctx->stream, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, 1);
+    }
+    SI_HIP(ctx, hipGetLastError());
     return SI_OK;
   }
   ChainBatch cb;

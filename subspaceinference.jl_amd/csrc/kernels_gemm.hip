@@ -349,7 +349,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f64_kernel(
           p += __shfl_xor(p, 2, 16);
           p += __shfl_xor(p, 1, 16);
           const int64_t gb = bw0 + b * 16 + q + 4 * r;
-          if (c == 0 && gb < B) part[(slot * out_last + o) * B + gb] = p;
+          if (c == 0 && gb < B) part[(slot * out_last + o) * (cb.part_ld ? cb.part_ld : B) + gb] = p;
         }
       }
     }

@@ -91,6 +91,10 @@ struct Ctx {
   char devname[256] = {0};
   int num_cu = 256;
 
+  // experiment knob SI_OVERLAP_HALVES=1: the two halves of the batch of ONE chain on two streams
+  bool overlap_halves = false;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // profiling
   // pinned host staging for the small construct-time transfers (G down, V up): pageable copies cost tens of us each
   double* h_pin = nullptr;
@@ -251,6 +255,7 @@ void launch_reconstruct(hipStream_t st, const double* swa, const double* P, int6
 struct ChainBatch {
   int n = 1;
   int64_t w = 0, hin = 0, hout = 0, part = 0;
+  int64_t part_ld = 0;  // column pitch of the fused-tail partials when a launch covers only a column range of B (0 = B)
 };
 // K5: Hout[i + out*b] = act(sum_k W[i + out*k] * Hin[k + in*b] + bias[i])
 void launch_dense_f64(hipStream_t st, const double* W, const double* bias, const double* Hin,
