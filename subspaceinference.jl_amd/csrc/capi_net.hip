@@ -189,7 +189,7 @@ void net_scratch_sizes(const NetPlan& p, int64_t B, int num_cu, size_t* bwpart, 
     }
   }
   *bwpart = part;
-  *rspart = (size_t)rowsum_chunks() * (size_t)p.max_rows;
+  *rspart = (size_t)std::max(rowsum_chunks(), mul_dact_rowsum_chunks()) * (size_t)p.max_rows;
   *wt = p.wt_elems;
   *dbtmp = (size_t)p.max_rows;
 }
@@ -205,8 +205,8 @@ int32_t net_backward(Ctx* c, const NetPlan& p, const double* w, const double* xi
     const double* hout = hs[li];
     switch (q.kind) {
       case SI_LAYER_DENSE: {
-        launch_mul_dact(st, g, hout, (int64_t)q.out_feat * B, q.act, g);                 // Delta = g .* act'(h)
-        launch_rowsum(st, g, q.out_feat, B, s.rspart, gw + q.b_off);                     // db
+        // Delta = g .* act'(h) (in place) and db = its row sums, one pass
+        launch_mul_dact_rowsum(st, g, hout, q.out_feat, B, q.act, g, s.rspart, q.out_feat, gw + q.b_off);
         int64_t ks;
         const int ns = backward_weight_splits(q.out_feat, q.in_feat, B, c->num_cu, &ks);
         launch_backward_weight(st, g, hin, s.bwpart, q.out_feat, q.in_feat, B, ns, ks, c->num_cu);
@@ -222,9 +222,7 @@ int32_t net_backward(Ctx* c, const NetPlan& p, const double* w, const double* xi
         break;
       default: {  // Conv
         const int64_t npos = (int64_t)q.Wo * q.Ho * B;
-        launch_mul_dact(st, g, hout, (int64_t)q.Cop * npos, q.act, g);
-        launch_rowsum(st, g, q.Cop, npos, s.rspart, s.dbtmp);
-        (void)hipMemcpyAsync(gw + q.b_off, s.dbtmp, (size_t)q.Co * sizeof(double), hipMemcpyDeviceToDevice, st);
+        launch_mul_dact_rowsum(st, g, hout, q.Cop, npos, q.act, g, s.rspart, q.Co, gw + q.b_off);
         int64_t ks;
         const int ns = conv_dw_splits(q.Cop, q.Kp, npos, c->num_cu, &ks);
         launch_conv_backward_weight(st, g, hin, s.bwpart, q.g, q.Cop, q.Kp, npos, ns, ks);

@@ -533,4 +533,44 @@ void launch_mul_dact(hipStream_t st, const double* G, const double* H, int64_t n
   hipLaunchKernelGGL(mul_dact_kernel, dim3(idx_grid(n)), dim3(256), 0, st, G, H, n, act, D);
 }
 
+// D = G .* act'(H) and db[i] = sum_b D[i + rows*b] in ONE pass (the reverse sweep of a conv / dense layer needs both; as two
+// kernels the row sum re-read the whole Delta tensor -- 2.1 GB behind the first conv layer of the cfg4 CNN -- with as
+// few as 128 workgroups).  Fixed-order partial sums: chunk partials, then chunks in order (bit-reproducible).
+constexpr int RSF_CHUNKS = 256;
+__global__ __launch_bounds__(256) void mul_dact_rowsum_kernel(const double* __restrict__ G, const double* __restrict__ H, int rows,
+                                                              int64_t ncols, int act, double* __restrict__ D, double* __restrict__ part) {
+  __shared__ double red[4][64];
+  const int il = threadIdx.x & 63, cl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + il;
+  const int64_t per = (ncols + RSF_CHUNKS - 1) / RSF_CHUNKS;
+  const int64_t b0 = (int64_t)blockIdx.y * per;
+  int64_t b1 = b0 + per;
+  if (b1 > ncols) b1 = ncols;
+  double s = 0.0;
+  if (i < rows)
+    for (int64_t b = b0 + cl; b < b1; b += 4) {
+      const int64_t off = i + (int64_t)rows * b;
+      const double d = G[off] * conv_dact(H[off], act);
+      D[off] = d;
+      s += d;
+    }
+  red[cl][il] = s;
+  __syncthreads();
+  if (cl == 0 && i < rows) part[(int64_t)blockIdx.y * rows + i] = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
+}
+__global__ __launch_bounds__(256) void rowsum_chunks_final_kernel(const double* __restrict__ part, int rows, int nout, double* __restrict__ db) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nout) return;
+  double s = 0.0;
+  for (int ch = 0; ch < RSF_CHUNKS; ++ch) s += part[(int64_t)ch * rows + i];
+  db[i] = s;
+}
+int mul_dact_rowsum_chunks() { return RSF_CHUNKS; }
+// D may alias G (in place).  db receives the first `nout` row sums (nout <= rows: pad channels are dropped).
+void launch_mul_dact_rowsum(hipStream_t st, const double* G, const double* H, int rows, int64_t ncols, int act, double* D, double* part,
+                            int nout, double* db) {
+  hipLaunchKernelGGL(mul_dact_rowsum_kernel, dim3((rows + 63) / 64, RSF_CHUNKS), dim3(256), 0, st, G, H, rows, ncols, act, D, part);
+  hipLaunchKernelGGL(rowsum_chunks_final_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, part, rows, nout, db);
+}
+
 }  // namespace si

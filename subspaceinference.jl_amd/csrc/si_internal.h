@@ -315,6 +315,9 @@ void launch_maxpool(hipStream_t st, const double* In, double* Out, int Cp, int W
 void launch_maxpool_bwd(hipStream_t st, const double* In, const double* Out, const double* Gout, double* Gin, int Cp, int Wi, int Hi,
                         int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B);
 void launch_mul_dact(hipStream_t st, const double* G, const double* H, int64_t n, int act, double* D);
+int mul_dact_rowsum_chunks();
+void launch_mul_dact_rowsum(hipStream_t st, const double* G, const double* H, int rows, int64_t ncols, int act, double* D, double* part,
+                            int nout, double* db);
 // capi_net.hip: validation + geometry of a layer table (Dense chains included), and the generic forward / reverse sweep
 int32_t net_plan(Ctx* c, const char* who, const si_layer* layers, int L, int64_t N, int in_dim, int out_dim, NetPlan& out);
 // xin: input in device layout (net_input re-lays a (features x B) matrix when the chain starts on images); outs[l] = where
