@@ -189,7 +189,7 @@ void net_scratch_sizes(const NetPlan& p, int64_t B, int num_cu, size_t* bwpart, 
     }
   }
   *bwpart = part;
-  *rspart = (size_t)std::max(rowsum_chunks(), mul_dact_rowsum_chunks()) * (size_t)p.max_rows;
+  *rspart = std::max((size_t)rowsum_chunks() * (size_t)p.max_rows, dact_rowsum_ws_elems(p.max_rows));
   *wt = p.wt_elems;
   *dbtmp = (size_t)p.max_rows;
 }
@@ -199,6 +199,7 @@ int32_t net_backward(Ctx* c, const NetPlan& p, const double* w, const double* xi
   hipStream_t st = c->stream;
   double* g = g0;      // gradient with respect to the OUTPUT of the layer being processed (device layout)
   double* gn = g1;
+  bool delta_ready = false;  // g already holds Delta = dL/d(pre-activation) of the layer (and its db is written)
   for (size_t li = p.L.size(); li-- > 0;) {
     const LayerPlan& q = p.L[li];
     const double* hin = li > 0 ? hs[li - 1] : xin;
@@ -218,11 +219,21 @@ int32_t net_backward(Ctx* c, const NetPlan& p, const double* w, const double* xi
         launch_whcn_to_cwhn(st, g, gn, q.Wi, q.Hi, q.C, q.Cp, B);   // back to channel-fastest, pad channels zero
         break;
       case SI_LAYER_MAXPOOL:
-        launch_maxpool_bwd(st, hin, hout, g, gn, q.Cp, q.Wi, q.Hi, q.Wo, q.Ho, q.KW, q.KH, q.sw, q.sh, B);
+        if (li > 0 && p.L[li - 1].kind == SI_LAYER_CONV) {
+          // the pool's input is a conv layer's output: route the gradient to the window maxima, multiply by act' and sum
+          // the conv layer's bias gradient in the same pass
+          const LayerPlan& cv = p.L[li - 1];
+          launch_maxpool_bwd_dact_rowsum(st, hin, hout, g, gn, q.Cp, q.Wi, q.Hi, q.Wo, q.Ho, q.KW, q.KH, q.sw, q.sh, B, cv.act,
+                                         s.rspart, cv.Co, gw + cv.b_off);
+          delta_ready = true;
+        } else {
+          launch_maxpool_bwd(st, hin, hout, g, gn, q.Cp, q.Wi, q.Hi, q.Wo, q.Ho, q.KW, q.KH, q.sw, q.sh, B);
+        }
         break;
       default: {  // Conv
         const int64_t npos = (int64_t)q.Wo * q.Ho * B;
-        launch_mul_dact_rowsum(st, g, hout, q.Cop, npos, q.act, g, s.rspart, q.Co, gw + q.b_off);
+        if (!delta_ready) launch_mul_dact_rowsum(st, g, hout, q.Cop, npos, q.act, g, s.rspart, q.Co, gw + q.b_off);
+        delta_ready = false;
         int64_t ks;
         const int ns = conv_dw_splits(q.Cop, q.Kp, npos, c->num_cu, &ks);
         launch_conv_backward_weight(st, g, hin, s.bwpart, q.g, q.Cop, q.Kp, npos, ns, ks);

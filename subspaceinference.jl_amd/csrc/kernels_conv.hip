@@ -127,18 +127,26 @@ struct GatherN {
   static constexpr int NREG = (16 * R + NT * 2 - 1) / (NT * 2);
   static constexpr int RP = R + 16, KP = 18;
   static constexpr int LDS_ELEMS = 16 * RP;
-  int adil[NREG], cdil[NREG], cin[NREG], lds[NREG], kq[NREG];
-  bool live[NREG], rowok[NREG];
+  // per slot: the tap (fixed) and the output pixel (wo, ho, image offset) of the CURRENT k tile.  The mainloop asks for
+  // the k tiles in order, once each, so the pixel is advanced by 16 positions per load() with a mixed-radix carry --
+  // the 64-bit division pos -> (image, ho, wo) per slot and tile made this kernel VALU-bound (half the speed of the
+  // forward convolution) when it was recomputed every time.
+  // (ioff carries the channel too; left = 0 for a tap row past Kvalid)
+  static constexpr bool EXACT = (16 * R) % (NT * 2) == 0;  // every slot is live
+  int aoff[NREG], coff[NREG], lds[NREG], left[NREG], wo[NREG], ho[NREG], ioff[NREG];
+  bool live[NREG];
   double2 reg[NREG];
   const double* T;
   ConvGeom g;
-  int64_t kbase, kend;
+  int dw16, dh16, di16;
 
-  __device__ __forceinline__ void init(const double* T_, const ConvGeom& g_, int64_t n0, int64_t k0, int64_t kend_, int tid) {
+  __device__ __forceinline__ void init(const double* T_, const ConvGeom& g_, int64_t n0, int64_t k0, int64_t kend, int tid) {
     T = T_;
     g = g_;
-    kbase = k0;
-    kend = kend_;
+    const int wh = g.Wo * g.Ho;
+    dw16 = 16 % g.Wo;
+    dh16 = (16 / g.Wo) % g.Ho;
+    di16 = (16 / wh) * (int)g.img_stride;
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
       const int idx = (tid + NT * r) * 2;
@@ -146,35 +154,48 @@ struct GatherN {
       const int kp = (int)n0 + rr;
       const int cell = kp / g.Cp;
       const int c = cell / g.KW, a = cell - c * g.KW;
-      cin[r] = kp - cell * g.Cp;
-      adil[r] = a * g.dil_w;
-      cdil[r] = c * g.dil_h;
-      rowok[r] = kp < g.Kvalid;
-      kq[r] = k;
-      live[r] = k < 16;
+      aoff[r] = a * g.dil_w - g.pad_w;
+      coff[r] = c * g.dil_h - g.pad_h;
+      live[r] = EXACT || k < 16;
       lds[r] = k * RP + rr;
+      const int64_t pos = k0 + k;
+      const int img = (int)(pos / wh), sp = (int)(pos - (int64_t)img * wh);
+      ho[r] = sp / g.Wo;
+      wo[r] = sp - ho[r] * g.Wo;
+      ioff[r] = img * (int)g.img_stride + (kp - cell * g.Cp);
+      const int64_t l = kend - pos;  // positions of this slot's column that remain in the split
+      left[r] = (l > 0 && kp < g.Kvalid) ? (int)(l < 0x7fffffff ? l : 0x7fffffff) : 0;
     }
   }
   __device__ __forceinline__ void load(int kt) {
-    const int wh = g.Wo * g.Ho;
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
-      const int64_t pos = kbase + 16 * (int64_t)kt + kq[r];
-      const int img = (int)(pos / wh), sp = (int)(pos - (int64_t)img * wh);
-      const int ho = sp / g.Wo, wo = sp - ho * g.Wo;
-      const int wi = wo * g.snum_w - g.pad_w + adil[r], hi = ho * g.snum_h - g.pad_h + cdil[r];
-      const bool ok = rowok[r] && pos < kend && wi >= 0 && hi >= 0 && wi < g.Wi && hi < g.Hi;
-      const int off = ok ? img * (int)g.img_stride + g.Cp * (wi + g.Wi * hi) + cin[r] : 0;
+      const int wi = wo[r] * g.snum_w + aoff[r], hi = ho[r] * g.snum_h + coff[r];
+      const bool ok = 16 * kt < left[r] && wi >= 0 && hi >= 0 && wi < g.Wi && hi < g.Hi;
+      const int off = ok ? ioff[r] + g.Cp * (wi + g.Wi * hi) : 0;
       const double2 v = *reinterpret_cast<const double2*>(T + off);
       reg[r] = ok ? v : make_double2(0.0, 0.0);
+      // advance the pixel by 16 positions: each digit overflows at most once (wo + dw16 < 2 Wo, ho + dh16 + 1 < 2 Ho)
+      int w = wo[r] + dw16, h = ho[r] + dh16, im = ioff[r] + di16;
+      if (w >= g.Wo) {
+        w -= g.Wo;
+        ++h;
+      }
+      if (h >= g.Ho) {
+        h -= g.Ho;
+        im += (int)g.img_stride;
+      }
+      wo[r] = w;
+      ho[r] = h;
+      ioff[r] = im;
     }
   }
   __device__ __forceinline__ void store(double* dst) const {
 #pragma unroll
     for (int r = 0; r < NREG; ++r)
-      if (live[r]) *reinterpret_cast<double2*>(dst + lds[r]) = reg[r];
+      if (EXACT || live[r]) *reinterpret_cast<double2*>(dst + lds[r]) = reg[r];
   }
-  __device__ __forceinline__ void load_edge(int kt, int64_t) { load(kt); }  // positions past kend are masked in load()
+  __device__ __forceinline__ void load_edge(int kt, int64_t) { load(kt); }  // positions past the split's end are masked in load()
   __device__ __forceinline__ void store_edge(double* dst, int, int64_t) const { store(dst); }
 };
 
@@ -319,7 +340,9 @@ void launch_conv_backward_data(hipStream_t st, const double* Wt, const double* D
 int conv_dw_splits(int COUTp, int Kp, int64_t npos, int num_cu, int64_t* ksplit_out) {
   const int bm = conv_pick_bm(COUTp);
   const int64_t tiles = (int64_t)((COUTp + bm - 1) / bm) * ((Kp + 127) / 128);
-  int64_t ns = ((int64_t)num_cu * 2 + tiles - 1) / tiles;
+  // two workgroups per CU are resident: round DOWN so that tiles * splits fits one residency round (rounding up left
+  // 3..28 workgroups for a second round that ran almost alone -- 515 / 522 / 540 workgroups on 512 slots at cfg4)
+  int64_t ns = ((int64_t)num_cu * 2) / tiles;
   const int64_t maxsplit = (npos + 255) / 256;
   ns = std::max<int64_t>(1, std::min(ns, maxsplit));
   const int64_t ks = ((npos + ns - 1) / ns + 15) / 16 * 16;
@@ -533,44 +556,121 @@ void launch_mul_dact(hipStream_t st, const double* G, const double* H, int64_t n
   hipLaunchKernelGGL(mul_dact_kernel, dim3(idx_grid(n)), dim3(256), 0, st, G, H, n, act, D);
 }
 
-// D = G .* act'(H) and db[i] = sum_b D[i + rows*b] in ONE pass (the reverse sweep of a conv / dense layer needs both; as two
-// kernels the row sum re-read the whole Delta tensor -- 2.1 GB behind the first conv layer of the cfg4 CNN -- with as
-// few as 128 workgroups).  Fixed-order partial sums: chunk partials, then chunks in order (bit-reproducible).
-constexpr int RSF_CHUNKS = 256;
-__global__ __launch_bounds__(256) void mul_dact_rowsum_kernel(const double* __restrict__ G, const double* __restrict__ H, int rows,
-                                                              int64_t ncols, int act, double* __restrict__ D, double* __restrict__ part) {
+// D = G .* act'(H) and db[i] = sum_b D[i + rows*b] in ONE pass (the reverse sweep of a conv / dense layer needs both; as
+// separate kernels the row sum re-read the whole Delta tensor -- 2.1 GB behind the first conv layer of the cfg4 CNN).
+// POOL = true additionally folds the MaxPool gradient in front of it: G is then the gradient of the POOLED tensor and the
+// kernel routes it to the window maxima itself (H is the pool's input = the conv layer's output, already being read for
+// act'), which saves writing and re-reading the un-pooled gradient.  rows = channels (fastest index), columns = pixels.
+// Fixed-order sums: 4 column phases per chunk, then the chunks in 16 strided groups, each in order (bit-reproducible).
+template <bool POOL>
+__global__ __launch_bounds__(256) void dact_rowsum_kernel(const double* __restrict__ G, const double* __restrict__ H,
+                                                          const double* __restrict__ PoolOut, int rows, int64_t ncols, int64_t per,
+                                                          int act, double* __restrict__ D, double* __restrict__ part, int Wi, int Hi,
+                                                          int Wo, int Ho, int PW, int PH, int sw, int sh) {
   __shared__ double red[4][64];
   const int il = threadIdx.x & 63, cl = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + il;
-  const int64_t per = (ncols + RSF_CHUNKS - 1) / RSF_CHUNKS;
   const int64_t b0 = (int64_t)blockIdx.y * per;
   int64_t b1 = b0 + per;
   if (b1 > ncols) b1 = ncols;
   double s = 0.0;
-  if (i < rows)
-    for (int64_t b = b0 + cl; b < b1; b += 4) {
+  if (i < rows) {
+    int64_t b = b0 + cl;
+    int wi = 0, hi = 0, dw = 0, dh = 0;
+    int64_t n = 0, dn = 0;
+    if constexpr (POOL) {  // pixel (wi, hi, image n) of column b, advanced by 4 columns per iteration (one carry per digit)
+      wi = (int)(b % Wi);
+      const int64_t t = b / Wi;
+      hi = (int)(t % Hi);
+      n = t / Hi;
+      dw = 4 % Wi;
+      dh = (4 / Wi) % Hi;
+      dn = 4 / (Wi * Hi);
+    }
+#pragma unroll 4
+    for (; b < b1; b += 4) {
       const int64_t off = i + (int64_t)rows * b;
-      const double d = G[off] * conv_dact(H[off], act);
+      const double x = H[off];
+      double g;
+      if constexpr (POOL) {
+        g = 0.0;  // every input equal to the maximum of a window it belongs to receives that window's gradient [upstream NNlib]
+        for (int ho = hi / sh; ho >= 0 && ho * sh + PH > hi; --ho) {
+          if (ho >= Ho) continue;
+          for (int wo = wi / sw; wo >= 0 && wo * sw + PW > wi; --wo) {
+            if (wo >= Wo) continue;
+            const int64_t o = i + (int64_t)rows * (wo + (int64_t)Wo * (ho + (int64_t)Ho * n));
+            if (PoolOut[o] == x) g += G[o];
+          }
+        }
+        wi += dw;
+        hi += dh;
+        n += dn;
+        if (wi >= Wi) {
+          wi -= Wi;
+          ++hi;
+        }
+        if (hi >= Hi) {
+          hi -= Hi;
+          ++n;
+        }
+      } else {
+        g = G[off];
+      }
+      const double d = g * conv_dact(x, act);
       D[off] = d;
       s += d;
     }
+  }
   red[cl][il] = s;
   __syncthreads();
   if (cl == 0 && i < rows) part[(int64_t)blockIdx.y * rows + i] = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
 }
-__global__ __launch_bounds__(256) void rowsum_chunks_final_kernel(const double* __restrict__ part, int rows, int nout, double* __restrict__ db) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nout) return;
+__global__ __launch_bounds__(1024) void rowsum_chunks_final_kernel(const double* __restrict__ part, int rows, int nchunks, int nout,
+                                                                   double* __restrict__ db) {
+  __shared__ double red[16][64];
+  const int il = threadIdx.x & 63, cl = threadIdx.x >> 6;  // 16 strided groups of chunks, each summed in order
+  const int i = blockIdx.x * 64 + il;
   double s = 0.0;
-  for (int ch = 0; ch < RSF_CHUNKS; ++ch) s += part[(int64_t)ch * rows + i];
-  db[i] = s;
+  if (i < nout) {
+#pragma unroll 8
+    for (int ch = cl; ch < nchunks; ch += 16) s += part[(int64_t)ch * rows + i];
+  }
+  red[cl][il] = s;
+  __syncthreads();
+  if (cl == 0 && i < nout) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][il];
+    db[i] = t;
+  }
 }
-int mul_dact_rowsum_chunks() { return RSF_CHUNKS; }
+// chunks: enough workgroups (>= ~4096 of 4 waves) to run the stream at HBM speed whatever the row count is
+static int dact_rowsum_chunks(int rows, int64_t ncols) {
+  const int rb = (rows + 63) / 64;
+  int64_t ch = std::max<int64_t>(64, (4096 + rb - 1) / rb);
+  ch = std::min<int64_t>(ch, std::max<int64_t>(1, ncols / 16));
+  return (int)ch;
+}
+size_t dact_rowsum_ws_elems(int max_rows) { return (size_t)4096 * 64 + (size_t)128 * (size_t)max_rows + 64; }
 // D may alias G (in place).  db receives the first `nout` row sums (nout <= rows: pad channels are dropped).
 void launch_mul_dact_rowsum(hipStream_t st, const double* G, const double* H, int rows, int64_t ncols, int act, double* D, double* part,
                             int nout, double* db) {
-  hipLaunchKernelGGL(mul_dact_rowsum_kernel, dim3((rows + 63) / 64, RSF_CHUNKS), dim3(256), 0, st, G, H, rows, ncols, act, D, part);
-  hipLaunchKernelGGL(rowsum_chunks_final_kernel, dim3((nout + 255) / 256), dim3(256), 0, st, part, rows, nout, db);
+  const int nch = dact_rowsum_chunks(rows, ncols);
+  const int64_t per = (ncols + nch - 1) / nch;
+  hipLaunchKernelGGL(dact_rowsum_kernel<false>, dim3((rows + 63) / 64, nch), dim3(256), 0, st, G, H, nullptr, rows, ncols, per, act, D,
+                     part, 0, 0, 0, 0, 0, 0, 0, 0);
+  hipLaunchKernelGGL(rowsum_chunks_final_kernel, dim3((nout + 63) / 64), dim3(1024), 0, st, part, rows, nch, nout, db);
+}
+// MaxPool gradient + act' + bias row sum of the conv layer in front of the pool, one pass (D must not alias anything).
+void launch_maxpool_bwd_dact_rowsum(hipStream_t st, const double* In, const double* Out, const double* Gout, double* D, int Cp, int Wi,
+                                    int Hi, int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B, int act, double* part, int nout,
+                                    double* db) {
+  const int64_t ncols = (int64_t)Wi * Hi * B;
+  const int nch = dact_rowsum_chunks(Cp, ncols);
+  const int64_t per = (ncols + nch - 1) / nch;
+  hipLaunchKernelGGL(dact_rowsum_kernel<true>, dim3((Cp + 63) / 64, nch), dim3(256), 0, st, Gout, In, Out, Cp, ncols, per, act, D,
+                     part, Wi, Hi, Wo, Ho, PW, PH, sw, sh);
+  hipLaunchKernelGGL(rowsum_chunks_final_kernel, dim3((nout + 63) / 64), dim3(1024), 0, st, part, Cp, nch, nout, db);
 }
 
 }  // namespace si

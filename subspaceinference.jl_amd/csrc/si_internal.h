@@ -315,7 +315,10 @@ void launch_maxpool(hipStream_t st, const double* In, double* Out, int Cp, int W
 void launch_maxpool_bwd(hipStream_t st, const double* In, const double* Out, const double* Gout, double* Gin, int Cp, int Wi, int Hi,
                         int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B);
 void launch_mul_dact(hipStream_t st, const double* G, const double* H, int64_t n, int act, double* D);
-int mul_dact_rowsum_chunks();
+size_t dact_rowsum_ws_elems(int max_rows);
+void launch_maxpool_bwd_dact_rowsum(hipStream_t st, const double* In, const double* Out, const double* Gout, double* D, int Cp, int Wi,
+                                    int Hi, int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B, int act, double* part, int nout,
+                                    double* db);
 void launch_mul_dact_rowsum(hipStream_t st, const double* G, const double* H, int rows, int64_t ncols, int act, double* D, double* part,
                             int nout, double* db);
 // capi_net.hip: validation + geometry of a layer table (Dense chains included), and the generic forward / reverse sweep

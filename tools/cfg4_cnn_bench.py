@@ -49,34 +49,35 @@ x = np.asfortranarray(rng.standard_normal((32 * 32 * 3, B)))
 y = np.asfortranarray(rng.standard_normal((10, B)))
 ctx = si.Context(0)
 ctx.infer_setup(table, N, M, w_swa, p, x, y, 1.0)
-ctx.sample_rwmh(3, 0.01, seed=1)
-ctx.set_profiling(True)
-ctx.reset_stats()
-steps = 10
-t0 = time.perf_counter()
-z, lp, acc = ctx.sample_rwmh(steps, 0.01, seed=1)
-dt = (time.perf_counter() - t0) / steps
-st = ctx.stats()
-print("cfg4 CNN, B = %d images: %.2f ms per RWMH transition, %.1f GFLOP per forward -> %.1f TFLOP/s overall" %
-      (B, dt * 1e3, flops * B / 1e9, flops * B / dt / 1e12))
-for k in ("reconstruct", "conv", "conv_aux", "dense", "sse", "rwmh"):
-    v = st[k]
-    print("  %-12s %8.3f ms per step  %7.2f TFLOP/s  %7.2f TB/s algorithmic" %
-          (k, v["ms"] / steps, v["flops"] / max(v["ms"], 1e-9) / 1e9, v["bytes"] / max(v["ms"], 1e-9) / 1e9))
-ctx.set_profiling(False)
-zz = np.ascontiguousarray(z[:, -1, 0])
-ctx.logdensity_grad(zz)
-t0 = time.perf_counter()
-for _ in range(3):
+if not os.environ.get("CFG4_SETUP_ONLY"):   # tools/cfg4_cnn_grad_profile.py imports the set-up only
+    ctx.sample_rwmh(3, 0.01, seed=1)
+    ctx.set_profiling(True)
+    ctx.reset_stats()
+    steps = 10
+    t0 = time.perf_counter()
+    z, lp, acc = ctx.sample_rwmh(steps, 0.01, seed=1)
+    dt = (time.perf_counter() - t0) / steps
+    st = ctx.stats()
+    print("cfg4 CNN, B = %d images: %.2f ms per RWMH transition, %.1f GFLOP per forward -> %.1f TFLOP/s overall" %
+          (B, dt * 1e3, flops * B / 1e9, flops * B / dt / 1e12))
+    for k in ("reconstruct", "conv", "conv_aux", "dense", "sse", "rwmh"):
+        v = st[k]
+        print("  %-12s %8.3f ms per step  %7.2f TFLOP/s  %7.2f TB/s algorithmic" %
+              (k, v["ms"] / steps, v["flops"] / max(v["ms"], 1e-9) / 1e9, v["bytes"] / max(v["ms"], 1e-9) / 1e9))
+    ctx.set_profiling(False)
+    zz = np.ascontiguousarray(z[:, -1, 0])
     ctx.logdensity_grad(zz)
-print("  value + gradient of the log-density: %.2f ms (%.1f TFLOP/s on 3x the forward flops)" %
-      ((time.perf_counter() - t0) / 3 * 1e3, 3 * flops * B / ((time.perf_counter() - t0) / 3) / 1e12))
-bt = min(B, 1024)
-ctx.train_setup(table, N, w_swa.astype(np.float32), x, y, bt, 2, 1e-3, 0.9, 0.999)
-ids = np.arange(bt)
-ctx.train_step(ids)
-t0 = time.perf_counter()
-for _ in range(5):
-    ctx.train_step(ids, want_loss=False)
-ctx.synchronize()
-print("  ADAM training step on %d images: %.2f ms" % (bt, (time.perf_counter() - t0) / 5 * 1e3))
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ctx.logdensity_grad(zz)
+    print("  value + gradient of the log-density: %.2f ms (%.1f TFLOP/s on 3x the forward flops)" %
+          ((time.perf_counter() - t0) / 3 * 1e3, 3 * flops * B / ((time.perf_counter() - t0) / 3) / 1e12))
+    bt = min(B, 1024)
+    ctx.train_setup(table, N, w_swa.astype(np.float32), x, y, bt, 2, 1e-3, 0.9, 0.999)
+    ids = np.arange(bt)
+    ctx.train_step(ids)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.train_step(ids, want_loss=False)
+    ctx.synchronize()
+    print("  ADAM training step on %d images: %.2f ms" % (bt, (time.perf_counter() - t0) / 5 * 1e3))
