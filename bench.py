@@ -143,7 +143,7 @@ def pmc_traffic(profile, kernel_sources):
     want = rec.get("kernel_source_sha16", {})
     have = {s: _sha16(os.path.join(ROOT, "subspaceinference.jl_amd", "csrc", s)) for s in kernel_sources}
     if not want or any(want.get(s) != have[s] for s in kernel_sources):
-        return None, "profiles/%s was taken on other kernel sources (sha mismatch): re-run tools/pmc_traffic.sh" % profile
+        return None, "profiles/%s was taken on other kernel sources (sha mismatch): re-run tools/profile_round.sh + tools/make_pmc_json.py" % profile
     return rec.get("hbm_bytes_per_launch"), "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same kernel sources by sha256)" % profile
 
 

@@ -26,7 +26,9 @@ echo "[3] cfg4 CNN"
 python3 $R/tools/cfg4_cnn_bench.py 4096 > $O/cfg4_cnn.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cnn_kt -o c -- python3 $R/tools/cfg4_cnn_bench.py 4096 > /dev/null 2>&1
 python3 $R/tools/kstats.py $O/cnn_kt 20 > $O/cfg4_cnn_kernel_stats.txt
-rm -rf $O/cnn_kt $O/bench_kt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/cnng_kt -o g -- python3 $R/tools/cfg4_cnn_grad_profile.py > /dev/null 2>&1
+python3 $R/tools/kstats.py $O/cnng_kt 20 > $O/cfg4_cnn_grad_kernel_stats.txt
+rm -rf $O/cnn_kt $O/cnng_kt $O/bench_kt
 echo "[4] bench lines"
 cd $R
 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err
