@@ -269,6 +269,256 @@ __global__ __launch_bounds__(64 * GW_WAVES, OCC) void gram_glds_kernel(const dou
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised variant: the 4 MFMA waves (one per SIMD) issue NOTHING but LDS reads and MFMAs; NP extra PRODUCER
+// waves issue every LDS-DMA piece of the ring.  Why: a global_load_lds instruction holds the issuing wave for 60-190
+// cycles, and with one wave per SIMD the matrix pipe drains behind it wherever the piece is placed in the MFMA stream
+// (measured: 73-75 % MFMA-busy in every single-role structure).  A producer wave blocked in issue costs nothing -- the
+// MFMA wave of its SIMD keeps the issue port.  Protocol per slab t (every wave executes exactly one s_barrier per slab):
+//   consumer: ... k steps of slab t, all LDS reads of buffer t % NB issued and returned -> barrier -> first fragments of
+//             slab t + 1 (buffer (t + 1) % NB, landed by the producers' promise) ...
+//   producer: s_waitcnt vmcnt((NB - 2) * PP)  [slab t + 1 has landed; slabs t + 2 .. t + NB - 1 may still fly]
+//             -> barrier -> issue its PP pieces of slab t + NB into buffer t % NB (free: every consumer passed the barrier).
+// PP = 4 NT / NP pieces per producer and slab; (NB - 1) * PP <= 63 (the vmcnt field).
+// ------------------------------------------------------------------------------------------------
+#ifdef SI_GRAM_TS
+__device__ unsigned long long g_gram_ts[8][1024];   // development: s_memrealtime at every slab barrier of 8 sampled workgroups
+void gram_spec_dump_ts(unsigned long long* host) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gram_ts), sizeof(g_gram_ts)); }
+#endif
+template <int NT, int KS, int NB>
+struct GSpec {
+  static constexpr int NC = NT * 16;
+  static constexpr int BUF = NC * GR;
+  static constexpr int P = NT * (NT + 1) / 2;
+  static constexpr int PS = GW_WAVES / KS;
+  static constexpr int CMAX = (P + PS - 1) / PS;
+  static constexpr int R = KS == 1 ? 1 : ((NB * BUF) / (256 * GW_WAVES) > 0 ? (NB * BUF) / (256 * GW_WAVES) : 1);
+  static constexpr int ROUNDS = KS == 1 ? 0 : (CMAX + R - 1) / R;
+};
+
+template <int NT, int KS, int NB, int NP, int J>
+__device__ __forceinline__ void gram_spec_producer(const double* __restrict__ A, int64_t ldA, int64_t N, int K, double* sA, int dbg) {
+  using S = GSpec<NT, KS, NB>;
+  constexpr int PIECES = 4 * NT;                      // 1 KiB pieces (4 columns x 32 rows) of a slab
+  constexpr int PP = (PIECES - J + NP - 1) / NP;      // pieces J, J + NP, ... of every slab are this wave's
+  constexpr int PPMAX = (PIECES + NP - 1) / NP;
+  static_assert((NB - 1) * PPMAX <= 63, "vmcnt field");
+  const int lane = threadIdx.x & 63;
+  const double* src[PP];
+#pragma unroll
+  for (int i = 0; i < PP; ++i) {
+    const int col = 4 * (J + NP * i) + (lane >> 4);
+    const int rp = (lane & 15) ^ (col & 15);
+    src[i] = A + (int64_t)(col < K ? col : K - 1) * ldA + 2 * rp;
+  }
+  const int64_t nslab = (N + GR - 1) / GR;
+  const int64_t stride = gridDim.x;
+  int64_t slab = blockIdx.x;
+  if (slab >= nslab) return;   // (block-uniform; the consumers leave the same way before any barrier)
+  const int64_t last = nslab - 1;
+  auto clamp = [&](int64_t sl) { return sl < last ? sl : last; };
+  auto issue = [&](int64_t sl, int buf) {
+    if (dbg & 2) return;                       // development: no DMA at all (consumers multiply whatever LDS holds)
+    if (dbg & 1) sl = sl & 7;                  // development: every workgroup re-reads 8 slabs (cache-resident source)
+    const int64_t roff = sl * GR;
+    double* dst = sA + buf * S::BUF;
+    static_for<PP>([&](auto IC) {
+      constexpr int i = decltype(IC)::value;
+      __builtin_amdgcn_global_load_lds(src[i] + roff, (lds_void_ptr)(dst + 4 * (J + NP * i) * GR), 16, 0, 0);
+    });
+  };
+#pragma unroll
+  for (int b = 0; b < NB; ++b) issue(clamp(slab + b * stride), b);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * PP) : "memory");
+  __builtin_amdgcn_s_barrier();
+  int ring = 0;
+  while (slab < nslab) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PP) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(clamp(slab + (int64_t)NB * stride), ring);
+    ring = ring + 1 == NB ? 0 : ring + 1;
+    slab += stride;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail fetches must land before the buffers are reused
+  if constexpr (KS > 1) {
+    __syncthreads();
+#pragma unroll
+    for (int rd = 0; rd < S::ROUNDS; ++rd) {
+      __syncthreads();
+      __syncthreads();
+    }
+  }
+}
+
+template <int NT, int KS, int KG, int G, int NB>
+__device__ __forceinline__ void gram_spec_consumer(int64_t N, double* __restrict__ Gpart, double* sA, int dbg) {
+  using GW = GWave<NT, KS, G>;
+  using S = GSpec<NT, KS, NB>;
+  constexpr int BUF = S::BUF;
+  constexpr int H = (GR / 4) / KS;
+  constexpr int CNT = GW::CNT > 0 ? GW::CNT : 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, c = lane & 15;
+  int fb[H];
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const int s = KG + KS * i;
+    fb[i] = c * GR + 2 * ((2 * s + (q >> 1)) ^ c) + (q & 1);
+    asm volatile("" : "+v"(fb[i]));
+  }
+  const int64_t nslab = (N + GR - 1) / GR;
+  const int64_t stride = gridDim.x;
+  int64_t slab = blockIdx.x;
+  double f0[NT], f1[NT];
+  double* out = Gpart + (int64_t)blockIdx.x * GW::P * 256;
+  if (slab >= nslab) {
+    for (int e = tid; e < GW::P * 256; e += 64 * GW_WAVES) out[e] = 0.0;
+    return;
+  }
+  __builtin_amdgcn_s_barrier();   // the first slab has landed
+  auto load_frags = [&](const double* buf, int b, double(&f)[NT]) {
+    static_for<NT>([&](auto TC) {
+      constexpr int T = decltype(TC)::value;
+      constexpr unsigned M = GW::mask();
+      if constexpr ((M >> T) & 1u) f[T] = buf[b + T * 16 * GR];
+    });
+  };
+  load_frags(sA, fb[0], f0);
+  d4 acc[CNT];
+  int ring = 0;
+  auto one_slab = [&](auto FIRSTSLAB) {
+    constexpr bool first_slab = decltype(FIRSTSLAB)::value;
+    const double* cur = sA + ring * BUF;
+    const int nxt = ring + 1 == NB ? 0 : ring + 1;
+    static_for<H>([&](auto IC) {
+      constexpr int i = decltype(IC)::value;
+      double(&fc)[NT] = (i & 1) ? f1 : f0;
+      double(&fn)[NT] = (i & 1) ? f0 : f1;
+      if constexpr (i == H - 1) {
+        // every LDS read of this buffer has been issued: retire them, meet the producers (next slab landed, this buffer free)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef SI_GRAM_TS
+        const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+#endif
+        __builtin_amdgcn_s_barrier();
+#ifdef SI_GRAM_TS
+        if (KG == 0 && G == 0 && (blockIdx.x & 31) == 0 && lane == 0) {
+          const int64_t it = (slab - blockIdx.x) / stride;
+          if (it < 512) {
+            g_gram_ts[blockIdx.x >> 5][2 * it] = t_in;
+            g_gram_ts[blockIdx.x >> 5][2 * it + 1] = __builtin_amdgcn_s_memrealtime();
+          }
+        }
+#endif
+      }
+      constexpr int FRAG_AT = GW::CNT > 1 ? 1 : 0;
+      auto hook = [&](auto MC) {
+        constexpr int I = decltype(MC)::value;
+        if constexpr (I == FRAG_AT) {
+          if constexpr (i + 1 < H)
+            load_frags(cur, fb[i + 1], fn);
+          else
+            load_frags(sA + nxt * BUF, fb[0], fn);
+        }
+      };
+      if (dbg & 4) {   // development: memory side alone (no MFMA, no fragment reads; the barriers stay)
+        if constexpr (first_slab && i == 0) {
+#pragma unroll
+          for (int z = 0; z < CNT; ++z) acc[z] = (d4){0.0, 0.0, 0.0, 0.0};
+        }
+      } else {
+        if constexpr (first_slab && i == 0)
+          GW::template mfma<0, true>(fc, acc, hook);
+        else
+          GW::template mfma<0, false>(fc, acc, hook);
+        if constexpr (GW::CNT == 0) {
+          if constexpr (i + 1 < H)
+            load_frags(cur, fb[i + 1], fn);
+          else
+            load_frags(sA + nxt * BUF, fb[0], fn);
+        }
+      }
+    });
+    if constexpr ((H & 1) == 1) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) f0[t] = f1[t];
+    }
+    ring = nxt;
+    slab += stride;
+  };
+  one_slab(std::true_type{});
+  while (slab < nslab) one_slab(std::false_type{});
+  if constexpr (KS == 1) {
+#pragma unroll
+    for (int i = 0; i < GW::CNT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(GW::LO + i) * 256 + (q + 4 * r) + 16 * c] = acc[i][r];
+  } else {
+    constexpr int PS = GW::PS;
+    constexpr int R = S::R;
+    __syncthreads();
+#pragma unroll
+    for (int rd = 0; rd < S::ROUNDS; ++rd) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int i = rd * R + j;
+        if (i < GW::CNT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sA[(wave * R + j) * 256 + (q + 4 * r) + 16 * c] = acc[i < CNT ? i : 0][r];
+        }
+      }
+      __syncthreads();
+      for (int e = tid; e < PS * R * 256; e += 64 * GW_WAVES) {
+        const int g2 = e / (R * 256), rem = e - g2 * (R * 256);
+        const int j = rem >> 8, el = rem & 255;
+        const int lo2 = g2 * GW::P / PS, cnt2 = (g2 + 1) * GW::P / PS - lo2;
+        const int i = rd * R + j;
+        if (i < cnt2) {
+          double sum = 0.0;
+#pragma unroll
+          for (int kg2 = 0; kg2 < KS; ++kg2) sum += sA[((g2 * KS + kg2) * R + j) * 256 + el];
+          out[(lo2 + i) * 256 + el] = sum;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int NT, int KS, int NB, int NP>
+__global__ __launch_bounds__(64 * (GW_WAVES + NP), 1) void gram_spec_kernel(const double* __restrict__ A, int64_t ldA, int64_t N, int K,
+                                                                          double* __restrict__ Gpart, int dbg) {
+  extern __shared__ double sA[];  // [NB][NT*16][32]
+  static_assert(NP == 1 || NP == 2, "one or two producer waves");
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+    case 0: gram_spec_consumer<NT, KS, 0 % KS, 0 / KS, NB>(N, Gpart, sA, dbg); break;
+    case 1: gram_spec_consumer<NT, KS, 1 % KS, 1 / KS, NB>(N, Gpart, sA, dbg); break;
+    case 2: gram_spec_consumer<NT, KS, 2 % KS, 2 / KS, NB>(N, Gpart, sA, dbg); break;
+    case 3: gram_spec_consumer<NT, KS, 3 % KS, 3 / KS, NB>(N, Gpart, sA, dbg); break;
+    case 4: gram_spec_producer<NT, KS, NB, NP, 0>(A, ldA, N, K, sA, dbg); break;
+    default:
+      if constexpr (NP == 2) gram_spec_producer<NT, KS, NB, NP, 1>(A, ldA, N, K, sA, dbg);
+      break;
+  }
+}
+
+static bool gram_spec_enabled() {
+  static const bool v = [] {
+    const char* e = getenv("SI_GRAM_SPEC");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+template <int NT, int KS, int NB, int NP>
+static void launch_spec(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks) {
+  constexpr size_t lds = (size_t)NB * NT * 16 * GR * sizeof(double);
+  static LdsOptIn optin;
+  optin.ensure(reinterpret_cast<const void*>(gram_spec_kernel<NT, KS, NB, NP>), lds);
+  static const int dbg = getenv("SI_GRAM_SPEC_DBG") ? atoi(getenv("SI_GRAM_SPEC_DBG")) : 0;
+  hipLaunchKernelGGL((gram_spec_kernel<NT, KS, NB, NP>), dim3(nblocks), dim3(64 * (GW_WAVES + NP)), lds, st, A, ldA, N, K, tiles, dbg);
+}
+
 // Up to K = 144 two workgroups per CU (two ring buffers each; 8 * pairs-per-wave + ~90 registers <= 256) are the shipped
 // configuration: 0-6 % faster than one workgroup with a 4-deep ring (K = 100: 0.275 ms either way; K = 128: 2.22 against
 // 2.33 ms at N = 6.4 M; K = 144: 0.411 against 0.437 ms).  Development knob SI_GRAM_OCC1=1 selects the other one.
@@ -303,7 +553,10 @@ static void launch_nt(hipStream_t st, const double* A, int64_t ldA, int64_t N, i
 
 // workgroups per CU the launcher of this tile count will use (the caller sizes the grid and the partial-tile workspace)
 #if SI_GW_PART == 0
-int gram_wave_blocks_per_cu(int nt) { return (nt <= 9 && gram_two_per_cu()) ? 2 : 1; }
+int gram_wave_blocks_per_cu(int nt) {
+  if (gram_spec_enabled() && (nt == 7 || nt == 8)) return 1;
+  return (nt <= 9 && gram_two_per_cu()) ? 2 : 1;
+}
 #endif
 
 // launches the partial-tile kernel for NT = ceil(K / 16) when this part holds it (tiles: nblocks x NT(NT+1)/2 x 256)
@@ -316,8 +569,20 @@ bool launch_gram_wave_part0(hipStream_t st, const double* A, int64_t ldA, int64_
     case 4: launch_nt<4, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
     case 5: launch_nt<5, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
     case 6: launch_nt<6, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
-    case 7: launch_nt<7, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
-    case 8: launch_nt<8, 2, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
+    case 7:
+      if (gram_spec_enabled()) {
+        launch_spec<7, 2, 5, 2>(st, A, ldA, N, K, tiles, nblocks);
+        return true;
+      }
+      launch_nt<7, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0);
+      return true;
+    case 8:
+      if (gram_spec_enabled()) {
+        launch_spec<8, 2, 4, 2>(st, A, ldA, N, K, tiles, nblocks);
+        return true;
+      }
+      launch_nt<8, 2, 2>(st, A, ldA, N, K, tiles, nblocks, 0);
+      return true;
     default: return false;
   }
 }

@@ -12,6 +12,9 @@ void launch_project_mfma(hipStream_t, const double*, int64_t, int64_t, int64_t, 
 bool launch_project_stream(hipStream_t, const double*, int64_t, int64_t, int64_t, const double*, int32_t, int32_t, double*, int64_t, int) { return false; }
 }
 using namespace si;
+#ifdef SI_GRAM_TS
+namespace si { void gram_spec_dump_ts(unsigned long long* host); }
+#endif
 __global__ void fill(double* a, size_t n, unsigned long long seed) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     unsigned long long s = (i + 1) * 6364136223846793005ull + seed; s ^= s >> 29; s *= 0xBF58476D1CE4E5B9ull; s ^= s >> 32;
@@ -26,24 +29,38 @@ int main(int argc, char** argv) {
   hipMalloc(&A, (size_t)ldA * K * 8); hipMemset(A, 0, (size_t)ldA * K * 8);
   for (int k = 0; k < K; ++k) hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, A + (size_t)k * ldA, (size_t)N, 1000ull + k);
   hipMalloc(&G, (size_t)K * K * 8);
-  const size_t need = launch_gram(0, A, ldA, N, K, nullptr, nullptr, 256, nullptr);
+  const int NCU = getenv("SI_BENCH_CUS") ? atoi(getenv("SI_BENCH_CUS")) : 256;   // development: fewer workgroups than CUs
+  const size_t need = launch_gram(0, A, ldA, N, K, nullptr, nullptr, NCU, nullptr);
   hipMalloc(&Gp, need); hipMemset(Gp, 0, need);
   const int Mpad = project_mpad(M);
   hipMalloc(&V, (size_t)K * Mpad * 8); hipLaunchKernelGGL(fill, dim3(64), dim3(256), 0, 0, V, (size_t)K * Mpad, 7ull);
   hipMalloc(&P, (size_t)ldA * M * 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int rep = 0; rep < 4; ++rep) {
+  const int REPS = getenv("SI_BENCH_REPS") ? atoi(getenv("SI_BENCH_REPS")) : 4;   // development: long runs for rocm-smi sampling
+  for (int rep = 0; rep < REPS; ++rep) {
     hipEventRecord(e0, 0);
-    for (int it = 0; it < 5; ++it) launch_gram(0, A, ldA, N, K, Gp, G, 256, nullptr);
+    for (int it = 0; it < 5; ++it) launch_gram(0, A, ldA, N, K, Gp, G, NCU, nullptr);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
     hipEventRecord(e0, 0);
     launch_project(0, A, ldA, N, K, V, M, Mpad, P, ldA, 256);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms2; hipEventElapsedTime(&ms2, e0, e1);
-    printf("N=%lld K=%d M=%d: gram+reduce %.3f ms (%.2f TFLOP/s useful, %.2f TB/s of A), project %.3f ms (%.2f TB/s)\n", (long long)N, K, M, ms,
+    if (rep < 4 || rep == REPS - 1) printf("N=%lld K=%d M=%d: gram+reduce %.3f ms (%.2f TFLOP/s useful, %.2f TB/s of A), project %.3f ms (%.2f TB/s)\n", (long long)N, K, M, ms,
            (double)N * K * (K + 1) / (ms * 1e-3) / 1e12, (double)N * K * 8 / (ms * 1e-3) / 1e12, ms2, (double)N * (K + M) * 8 / (ms2 * 1e-3) / 1e12);
   }
+#ifdef SI_GRAM_TS
+  {  // wave-specialised kernel only (SI_GRAM_SPEC=1): per-slab barrier wait and slab period of 8 sampled workgroups, 10 ns ticks
+    std::vector<unsigned long long> ts(8 * 1024);
+    gram_spec_dump_ts(ts.data());
+    for (int b = 0; b < 8; b += 3) {
+      printf("block %d: [period wait] in 10 ns ticks per slab:", 32 * b);
+      for (int it = 1; it < 140 && ts[b * 1024 + 2 * it]; ++it)
+        printf(" %llu/%llu", ts[b * 1024 + 2 * it + 1] - ts[b * 1024 + 2 * it - 1], ts[b * 1024 + 2 * it + 1] - ts[b * 1024 + 2 * it]);
+      printf("\n");
+    }
+  }
+#endif
   std::vector<double> g((size_t)K * K); hipMemcpy(g.data(), G, g.size() * 8, hipMemcpyDeviceToHost);
   printf("G[0,0]=%.6f G[1,0]=%.6f G[K-1,K-1]=%.6f (expect ~N/12=%.1f on the diagonal)\n", g[0], g[1], g[(size_t)K * K - 1], N / 12.0);
   return 0;
