@@ -387,7 +387,7 @@ def run_chains(args, rk, real_stdout):
         t0 = time.perf_counter()
         ctx.reconstruct(zz)
         extras["output_map_ms_per_sample"] = (time.perf_counter() - t0) / nmap * 1e3
-        extras["output_map_note"] = ("a13: one K4 pass + %d-byte D2H per sample into pageable host memory (%d samples timed); "
+        extras["output_map_note"] = ("a13: one K4 pass + %d-byte D2H per sample into a fresh pageable array, pipelined through pinned staging (%d samples timed); "
                                      "excluded from `value`, which times the chain itself" % (8 * n_par, nmap))
         # the "next" rows at the same workload (outside every timed region above)
         ctx.reset_stats()

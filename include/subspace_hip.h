@@ -226,7 +226,8 @@ int32_t si_rwmh_end(si_ctx* ctx, double* Z_out, double* lp_out, double* accept_r
 /* drop an open session.  While a session is open, si_logdensity / _grad / si_forward / si_predict / si_sample_rwmh
  * return SI_ERR_STATE (they share the session's proposal and SSE buffers); si_rwmh_begin restarts it.              */
 int32_t si_rwmh_abort(si_ctx* ctx);
-/* :91 / :125  W_out[:, c] = W_swa + P * Z[:, c]   (N x C col-major)                                  */
+/* :91 / :125  W_out[:, c] = W_swa + P * Z[:, c]   (N x C col-major).  Pipelined: K4 -> pinned staging (second stream) ->
+ * host threads (SI_HOST_COPY_THREADS, default min(8, cpus / 2)) copy into W_out, which may be pageable and untouched.  */
 int32_t si_reconstruct(si_ctx* ctx, const double* Z /* M x C */, int64_t C, double* W_out);
 
 /* ---- on-device training step for Dense chains with the mse cost ----------------------------------

@@ -497,11 +497,18 @@ class Context:
         self._check(self.lib.si_rwmh_end(self.h, _ptr(z), _ptr(lp), _ptr(acc)))
         return z, lp, acc
 
-    def reconstruct(self, z):
+    def reconstruct(self, z, out=None):
+        """W_swa + P z for every column of z (space_inference.jl:125); `out` (N x C, Fortran order, float64) is filled in
+        place when given (e.g. a buffer the caller reuses), else a new array is returned."""
         z = _f64(z)
         if z.ndim == 1:
             z = z.reshape(-1, 1, order="F")
-        w = np.empty((self._ni, z.shape[1]), dtype=np.float64, order="F")
+        if out is None:
+            w = np.empty((self._ni, z.shape[1]), dtype=np.float64, order="F")
+        else:
+            w = out
+            if w.dtype != np.float64 or w.shape != (self._ni, z.shape[1]) or not w.flags.f_contiguous:
+                raise ValueError("reconstruct: `out` must be a Fortran-ordered float64 array of shape (N, C)")
         self._check(self.lib.si_reconstruct(self.h, _ptr(z), z.shape[1], _ptr(w)))
         return w
 

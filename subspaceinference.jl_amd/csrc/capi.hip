@@ -8,6 +8,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <sched.h>
+#include <sys/mman.h>
+#include <thread>
+#include <vector>
 
 #include "si_internal.h"
 
@@ -206,6 +210,11 @@ int32_t si_destroy(si_ctx* ctx) {
   dev_free(ctx->d_wstage);
   dev_free(ctx->d_nvals);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+  for (int b = 0; b < 2; ++b) {
+    if (ctx->h_stage[b]) (void)hipHostFree(ctx->h_stage[b]);
+    dev_free(ctx->d_stage[b]);
+    dev_free(ctx->d_zstage[b]);
+  }
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -1555,6 +1564,37 @@ int32_t si_rwmh_end(si_ctx* ctx, double* Z_out, double* lp_out, double* accept_r
   return SI_OK;
 }
 
+// Output map a13 (space_inference.jl:125: one W_swa + P z per sample, itr x N doubles on the host -- 8.4 GB at cfg2).
+// A three-stage pipeline so that the PCIe link, not a single host thread, sets the pace: K4 writes a group of samples
+// into one of two device buffers (compute stream) -> DMA into one of two PINNED staging buffers (copy stream) -> a few
+// host threads move the previous group from the staging buffer into the caller's (pageable, usually never-touched)
+// array.  A plain hipMemcpy into pageable memory does the last two steps on one thread: 0.79 ms per 8.4 MB sample.
+static void host_copy_parallel(double* dst, const double* src, size_t elems, int nthreads) {
+  if (nthreads <= 1 || elems < ((size_t)1 << 18)) {
+    std::memcpy(dst, src, elems * sizeof(double));
+    return;
+  }
+  std::vector<std::thread> th;
+  const size_t per = ((elems + nthreads - 1) / nthreads + 511) & ~(size_t)511;   // 4 KiB-granular slices
+  for (int t = 1; t < nthreads; ++t) {
+    const size_t lo = std::min(elems, per * t), hi = std::min(elems, per * (t + 1));
+    if (hi > lo) th.emplace_back([=] { std::memcpy(dst + lo, src + lo, (hi - lo) * sizeof(double)); });
+  }
+  std::memcpy(dst, src, std::min(elems, per) * sizeof(double));
+  for (auto& t : th) t.join();
+}
+
+static int host_copy_threads() {
+  static const int n = [] {
+    int avail = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) avail = CPU_COUNT(&set);
+    if (const char* e = getenv("SI_HOST_COPY_THREADS")) return std::max(1, atoi(e));
+    return std::max(1, std::min(8, avail / 2));
+  }();
+  return n;
+}
+
 int32_t si_reconstruct(si_ctx* ctx, const double* Z, int64_t C, double* W_out) {
   CHECK_CTX(ctx);
   if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_reconstruct: call si_infer_setup first");
@@ -1562,30 +1602,87 @@ int32_t si_reconstruct(si_ctx* ctx, const double* Z, int64_t C, double* W_out) {
   BIND(ctx);
   const int64_t N = ctx->iN, ldw = pad_ld(N);
   const int32_t M = ctx->iM;
-  const int64_t chunk = std::min<int64_t>(C, 64);
-  double *dZ = nullptr, *dW = nullptr;
-  if (dev_alloc(&dZ, (size_t)M * chunk) != hipSuccess || dev_alloc(&dW, (size_t)ldw * chunk) != hipSuccess) {
-    dev_free(dZ);
-    dev_free(dW);
-    return fail(ctx, SI_ERR_NOMEM, "si_reconstruct: allocation failed");
-  }
+  // samples per pipeline stage: ~32 MB of output, at most 64 samples, and at least four stages when C allows it
+  const int64_t group_cap = std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)32 << 20) / (N * 8)));   // sizes the buffers once per N
+  const int64_t group = std::max<int64_t>(1, std::min<int64_t>((C + 3) / 4, group_cap));
+  const int nthreads = host_copy_threads();
+  hipEvent_t ev_comp[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
   hipError_t e = hipSuccess;
-  for (int64_t c0 = 0; c0 < C && e == hipSuccess; c0 += chunk) {
-    const int64_t nc = std::min(chunk, C - c0);
-    e = hipMemcpyAsync(dZ, Z + c0 * M, (size_t)M * nc * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  {  // a never-touched destination is faulted in while it is written: ask for huge pages on its aligned interior (a hint;
+     // without THP the call fails and nothing changes) -- 4 KiB faults cap the copy-out near 14 GB/s whatever the threads
+    const uintptr_t lo = (reinterpret_cast<uintptr_t>(W_out) + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1);
+    const uintptr_t hi = (reinterpret_cast<uintptr_t>(W_out) + (uintptr_t)N * (uintptr_t)C * sizeof(double)) & ~(((uintptr_t)2 << 20) - 1);
+    if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
+  }
+  if (!ctx->stream2) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+  if (e == hipSuccess && (ctx->d_stage_cap < (size_t)ldw * (size_t)group_cap || ctx->d_zstage_cap < (size_t)M * (size_t)group_cap)) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int b = 0; b < 2; ++b) {
+      dev_free(ctx->d_stage[b]);
+      dev_free(ctx->d_zstage[b]);
+      ctx->d_stage[b] = ctx->d_zstage[b] = nullptr;
+    }
+    ctx->d_stage_cap = ctx->d_zstage_cap = 0;
+    for (int b = 0; b < 2 && e == hipSuccess; ++b)
+      if (dev_alloc(&ctx->d_stage[b], (size_t)ldw * group_cap) != hipSuccess || dev_alloc(&ctx->d_zstage[b], (size_t)M * group_cap) != hipSuccess)
+        e = hipErrorOutOfMemory;
+    if (e == hipSuccess) {
+      ctx->d_stage_cap = (size_t)ldw * (size_t)group_cap;
+      ctx->d_zstage_cap = (size_t)M * (size_t)group_cap;
+    }
+  }
+  double* const* dW = ctx->d_stage;
+  double* const* dZ = ctx->d_zstage;
+  if (e == hipSuccess && ctx->h_stage_cap < (size_t)N * (size_t)group_cap) {   // the staging buffers stay with the context
+    for (int b = 0; b < 2; ++b) {
+      if (ctx->h_stage[b]) (void)hipHostFree(ctx->h_stage[b]);
+      ctx->h_stage[b] = nullptr;
+    }
+    ctx->h_stage_cap = 0;
+    for (int b = 0; b < 2 && e == hipSuccess; ++b)
+      e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage[b]), (size_t)N * group_cap * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) ctx->h_stage_cap = (size_t)N * (size_t)group_cap;
+  }
+  double* const* hp = ctx->h_stage;
+  for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+    e = hipEventCreateWithFlags(&ev_comp[b], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_copy[b], hipEventDisableTiming);
+  }
+  auto drain = [&](int64_t g) {   // group g has been DMA'd into its staging buffer: move it into the caller's array
+    const int b = (int)(g & 1);
+    const int64_t c0 = g * group, nc = std::min(group, C - c0);
+    hipError_t w = hipEventSynchronize(ev_copy[b]);
+    if (w == hipSuccess) host_copy_parallel(W_out + c0 * N, hp[b], (size_t)N * (size_t)nc, nthreads);
+    return w;
+  };
+  const int64_t ngroups = (C + group - 1) / group;
+  for (int64_t g = 0; g < ngroups && e == hipSuccess; ++g) {
+    const int b = (int)(g & 1);
+    const int64_t c0 = g * group, nc = std::min(group, C - c0);
+    // dW[b] / dZ[b] are free once the DMA of group g - 2 has read them; hp[b] once that group has been drained (below)
+    if (g >= 2) e = hipStreamWaitEvent(ctx->stream, ev_copy[b], 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(dZ[b], Z + c0 * M, (size_t)M * nc * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) break;
     {
       ProfScope ps(ctx, SI_K_RECON, 2.0 * (double)N * M * nc, (double)N * (M + 1 + nc) * 8.0);
-      launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, dZ, (int32_t)nc, dW, ldw, ctx->num_cu);
+      launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, dZ[b], (int32_t)nc, dW[b], ldw, ctx->num_cu);
     }
-    e = hipMemcpy2DAsync(W_out + c0 * N, (size_t)N * sizeof(double), dW, (size_t)ldw * sizeof(double),
-                         (size_t)N * sizeof(double), (size_t)nc, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    e = hipEventRecord(ev_comp[b], ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream2, ev_comp[b], 0);
+    if (e == hipSuccess)
+      e = hipMemcpy2DAsync(hp[b], (size_t)N * sizeof(double), dW[b], (size_t)ldw * sizeof(double), (size_t)N * sizeof(double), (size_t)nc,
+                           hipMemcpyDeviceToHost, ctx->stream2);
+    if (e == hipSuccess) e = hipEventRecord(ev_copy[b], ctx->stream2);
+    if (e == hipSuccess && g >= 1) e = drain(g - 1);   // overlaps the DMA of group g
   }
+  if (e == hipSuccess) e = drain(ngroups - 1);
+  (void)hipStreamSynchronize(ctx->stream2);
   (void)hipStreamSynchronize(ctx->stream);
-  dev_free(dZ);
-  dev_free(dW);
-  if (e != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string("si_reconstruct: ") + hipGetErrorString(e));
+  for (int b = 0; b < 2; ++b) {
+    if (ev_comp[b]) (void)hipEventDestroy(ev_comp[b]);
+    if (ev_copy[b]) (void)hipEventDestroy(ev_copy[b]);
+  }
+  if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? SI_ERR_NOMEM : SI_ERR_HIP, std::string("si_reconstruct: ") + hipGetErrorString(e));
   return SI_OK;
 }
 

@@ -99,6 +99,10 @@ struct Ctx {
   // pinned host staging for the small construct-time transfers (G down, V up): pageable copies cost tens of us each
   double* h_pin = nullptr;
   size_t h_pin_cap = 0;
+  double* h_stage[2] = {nullptr, nullptr};   // pinned staging of si_reconstruct's output pipeline (kept between calls)
+  size_t h_stage_cap = 0;
+  double *d_stage[2] = {nullptr, nullptr}, *d_zstage[2] = {nullptr, nullptr};   // its device-side double buffer
+  size_t d_stage_cap = 0, d_zstage_cap = 0;
   bool profiling = false;
   uint32_t prof_mask = 0xffffffffu;  // classes that get event pairs while profiling is on
   std::vector<EventPair> pending;
