@@ -25,6 +25,9 @@ CASES = [
                    ("flatten",), ("dense", 10, I)], 50),
     ((4, 4, 2), [("maxpool", (2, 2)), ("conv", (2, 2), 3, T), ("flatten",), ("dense", 2, I)], 5),      # chain starting on a pool
     ((3, 3, 2), [("flatten",), ("dense", 4, T), ("dense", 2, I)], 9),                                   # flatten only
+    # a pool behind a pool (the second one takes the un-fused MaxPool gradient; the first one the pass fused with the
+    # conv layer's act' and bias sum), 70 channels (two 64-row blocks of the fused pass), sigmoid (act'(pad channel) != 0)
+    ((8, 8, 3), [("conv", (3, 3), 70, S, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("maxpool", (2, 2)), ("flatten",), ("dense", 3, I)], 19),
 ]
 
 

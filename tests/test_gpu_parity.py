@@ -741,6 +741,28 @@ def test_edge_shapes_construct(si, gpu_ctx):
         gpu_ctx.construct_push(np.zeros(10, dtype=np.int32), 1.0)   # unsupported dtype
 
 
+def test_output_map_pipeline_many_groups(si, gpu_ctx):
+    """a13 (space_inference.jl:125) through si_reconstruct's staged pipeline: more samples than one group holds (64), a
+    ragged last group, odd N, a caller-provided output array, and a second call that reuses the staging buffers."""
+    table, n, w_swa, p, x, y = _random_problem([7, 32, 3], [1, 0], 4, 6, seed=5)   # N = 355 (odd)
+    gpu_ctx.infer_setup(table, n, 6, w_swa, p, x, y, 1.0)
+    rng = np.random.default_rng(2)
+    for c in (1, 3, 64, 65, 333):
+        z = np.asfortranarray(rng.standard_normal((6, c)))
+        ref = w_swa[:, None] + p @ z
+        assert np.allclose(gpu_ctx.reconstruct(z), ref, rtol=1e-13, atol=1e-14)
+        out = np.full((n, c), np.nan, order="F")
+        assert gpu_ctx.reconstruct(z, out=out) is out
+        assert np.allclose(out, ref, rtol=1e-13, atol=1e-14)
+    with pytest.raises(ValueError):
+        gpu_ctx.reconstruct(z, out=np.zeros((n, c)))          # C-ordered
+    # a large-N context afterwards: the staging buffers grow
+    table, n, w_swa, p, x, y = _random_problem([128, 960, 960, 1], [1, 1, 0], 8, 3, seed=9)
+    gpu_ctx.infer_setup(table, n, 3, w_swa, p, x, y, 1.0)
+    z = np.asfortranarray(rng.standard_normal((3, 9)))                   # group = 3 samples: three groups
+    assert np.allclose(gpu_ctx.reconstruct(z), w_swa[:, None] + p @ z, rtol=1e-13, atol=1e-14)
+
+
 def test_edge_shapes_density(si, gpu_ctx):
     # M = 1; M = 64 with 5 chains (4 + 1 reconstruct passes); B = 1; out = 5 (unfused head, one above the fuse limit)
     for dims, acts, b, m, c in (([3, 4, 1], [1, 0], 1, 1, 1), ([9, 70, 5], [2, 0], 129, 64, 5), ([2, 2], [0], 3, 2, 3)):
