@@ -955,19 +955,17 @@ static int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out
     launch_sse(ctx->stream, ctx->d_w, nullptr, N, ctx->d_wsqpart, ctx->wsq_blocks, ctx->d_wsq + c0, nc, ldw);
   if (ctx->plan.has_conv) {
     // generic path (capi_net.hip): Conv / MaxPool / flatten / Dense layers one after the other, ping-pong activations
-    const size_t nl = ctx->plan.L.size();
-    std::vector<double*> outs(nl);
-    for (size_t l = 0; l < nl; ++l) outs[l] = ctx->d_act[l & 1];
-    const int32_t rc = net_forward(ctx, ctx->plan, ctx->d_w, ctx->plan.input_spatial ? ctx->d_Xc : ctx->d_X, B, outs.data(),
-                                   ctx->d_wpack);
+    double* last = nullptr;
+    const int32_t rc = net_forward(ctx, ctx->plan, ctx->d_w, ctx->plan.input_spatial ? ctx->d_Xc : ctx->d_X, B, ctx->d_act,
+                                   ctx->d_wpack, /*pingpong=*/true, &last);
     if (rc != SI_OK) return rc;
     const int64_t d = (int64_t)ctx->out_dim * B;
     {
       ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d, 16.0 * (double)d);
-      launch_sse(ctx->stream, outs[nl - 1], ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, 1, ctx->act_elems);
+      launch_sse(ctx->stream, last, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, 1, ctx->act_elems);
     }
     SI_HIP(ctx, hipGetLastError());
-    if (yhat_out) *yhat_out = outs[nl - 1];
+    if (yhat_out) *yhat_out = last;
     return SI_OK;
   }
   const size_t nl_all = ctx->layers.size();

@@ -132,12 +132,16 @@ void net_input(Ctx* c, const NetPlan& p, const double* X, double* Xc, int64_t B)
   launch_whcn_to_cwhn(c->stream, X, Xc, p.in_W, p.in_H, p.in_C, p.in_Cp, B);
 }
 
-int32_t net_forward(Ctx* c, const NetPlan& p, const double* w, const double* xin, int64_t B, double* const* outs, double* wpack) {
+int32_t net_forward(Ctx* c, const NetPlan& p, const double* w, const double* xin, int64_t B, double* const* outs, double* wpack,
+                    bool pingpong, double** final_out) {
   hipStream_t st = c->stream;
   const double* h = xin;
+  size_t executed = 0;
   for (size_t l = 0; l < p.L.size(); ++l) {
     const LayerPlan& q = p.L[l];
-    double* o = outs[l];
+    double* o = pingpong ? outs[executed & 1] : outs[l];
+    ++executed;
+    if (final_out) *final_out = o;
     if ((double)std::max(q.in_elems, q.out_elems) * (double)B >= 2147483648.0)
       return fail(c, SI_ERR_INVALID, "activation tensors of 2^31 elements or more are not supported by the conv kernels");
     switch (q.kind) {
@@ -152,6 +156,15 @@ int32_t net_forward(Ctx* c, const NetPlan& p, const double* w, const double* xin
         {
           ProfScope ps(c, SI_K_CONV_AUX, 0.0, ((double)q.KW * q.KH * q.C * q.Co + (double)q.Cop * q.Kp) * 8.0);
           launch_conv_pack(st, w + q.w_off, w + q.b_off, wpack + q.wp_off, wpack + q.bp_off, q.KW, q.KH, q.C, q.Co, q.Cp, q.Cop, q.Kp);
+        }
+        const bool fuse_pool = pingpong && l + 1 < p.L.size() && p.L[l + 1].kind == SI_LAYER_MAXPOOL && p.L[l + 1].KW == 2 &&
+                               p.L[l + 1].KH == 2 && p.L[l + 1].sw == 2 && p.L[l + 1].sh == 2 && q.Wo % 2 == 0 && q.Ho % 2 == 0;
+        if (fuse_pool) {   // the pooled tensor is all the next layer reads: skip the MaxPool layer
+          ProfScope ps(c, SI_K_CONV, 2.0 * (double)q.KW * q.KH * q.C * q.Co * (double)npos,
+                       ((double)q.in_elems + (double)p.L[l + 1].out_elems) * (double)B * 8.0 + (double)q.Cop * q.Kp * 8.0);
+          launch_conv_forward_pool2(st, wpack + q.wp_off, wpack + q.bp_off, h, o, q.g, q.Cop, q.Kp, npos, q.act);
+          ++l;
+          break;
         }
         ProfScope ps(c, SI_K_CONV, 2.0 * (double)q.KW * q.KH * q.C * q.Co * (double)npos,
                      ((double)q.in_elems + (double)q.out_elems) * (double)B * 8.0 + (double)q.Cop * q.Kp * 8.0);

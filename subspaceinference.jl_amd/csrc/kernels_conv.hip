@@ -47,7 +47,9 @@ __device__ __forceinline__ double conv_dact(double h, int act) {
 //   (wi, hi) = ((wo, ho) * snum - pad + (a, c) * dil) / sden   (zero when out of range or not divisible by sden).
 // LDS image "k-fast" [pos][18] like Stager<.., LAY = 1>.  Each thread owns NREG (position, k-pair) slots; the position
 // part of the address is fixed per slot, the tap part changes per k tile -- block-uniform when Cp % 16 == 0 (CELLU).
-template <int R, int NT, bool CELLU, bool DEN>
+// POOLP: the position index runs window-major over 2 x 2 / stride-2 pooling windows -- pos = 4 * (pooled pixel) + (dx + 2 dy)
+// -- so that the four inputs of a window sit in four lanes of one accumulator register (conv_gemm_pool_kernel).
+template <int R, int NT, bool CELLU, bool DEN, bool POOLP = false>
 struct GatherK {
   static constexpr int LAY = 1;
   static constexpr int NREG = (16 * R + NT * 2 - 1) / (NT * 2);
@@ -69,8 +71,21 @@ struct GatherK {
       const int k = idx & 15, rr = idx >> 4;
       int64_t pos = n0 + (rr < R ? rr : 0);
       if (pos > npos - 1) pos = npos - 1;  // clamped positions only feed outputs that are never stored
-      const int img = (int)(pos / wh), sp = (int)(pos - (int64_t)img * wh);
-      const int ho = sp / g.Wo, wo = sp - ho * g.Wo;
+      int img, ho, wo;
+      if constexpr (POOLP) {
+        const int64_t win = pos >> 2;
+        const int e = (int)(pos & 3), W2 = g.Wo >> 1, wh2 = W2 * (g.Ho >> 1);
+        img = (int)(win / wh2);
+        const int sp = (int)(win - (int64_t)img * wh2);
+        const int ho2 = sp / W2, wo2 = sp - ho2 * W2;
+        wo = 2 * wo2 + (e & 1);
+        ho = 2 * ho2 + (e >> 1);
+      } else {
+        img = (int)(pos / wh);
+        const int sp = (int)(pos - (int64_t)img * wh);
+        ho = sp / g.Wo;
+        wo = sp - ho * g.Wo;
+      }
       pb[r] = img * (int)g.img_stride;
       wb[r] = wo * g.snum_w - g.pad_w;
       hb[r] = ho * g.snum_h - g.pad_h;
@@ -245,6 +260,71 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_kernel(const dou
       });
 }
 
+// Forward convolution + bias + activation + MaxPool((2, 2)) in one kernel (sampling path: the un-pooled activation is
+// never needed).  Positions run window-major (GatherK<POOLP>), so in the MFMA output D[n = q + 4r][m = c] the four inputs
+// of pooling window r of a 16-position slice are the four lane groups q = 0..3 of accumulator register r: two cross-lane
+// maxima, then lane group q stores window q -- Out[m + Mp * window] is the pooled CWHN tensor (4x fewer bytes written,
+// and the MaxPool pass with its read of the full activation disappears: 2.1 + 2.7 GB at the first layer of the cfg4 CNN).
+template <int BM, int BN, int WM, int WN, int MINW, bool CELLU>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_pool_kernel(const double* __restrict__ Wp, int Mp,
+                                                                            const double* __restrict__ T, double* __restrict__ Out,
+                                                                            const double* __restrict__ bias, ConvGeom g, int64_t npos,
+                                                                            int Kp, int act, int nMt, int64_t nNt) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  using SA = Stager<BM, 0, NT, true>;
+  using SB = GatherK<BN, NT, CELLU, false, true>;
+  extern __shared__ double smem[];
+  const int64_t bid = blockIdx.x;
+  int mt;
+  int64_t nt;
+  if (nNt >= 8) {
+    const int xcd = (int)(bid & 7);
+    const int64_t j = bid >> 3;
+    mt = (int)(j % nMt);
+    nt = (j / nMt) * 8 + xcd;
+  } else {
+    mt = (int)(bid % nMt);
+    nt = bid / nMt;
+  }
+  if (nt >= nNt) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int m0 = mt * BM;
+  const int64_t n0 = nt * BN;
+  d4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  SA sa;
+  SB sb;
+  sa.init(Wp, Mp, m0, Mp, 0, tid);
+  sb.init(T, g, n0, npos, tid);
+  gemm_mainloop<BM, BN, WM, WN>(sa, sb, smem, Kp / 16, (int64_t)Kp, wm, wn, lane, acc, 0);
+  const int q = lane >> 4, c = lane & 15;
+  const int64_t nwin = npos >> 2;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int gm = m0 + wm * (BM / WM) + a * 16 + c;
+    const double bv = gm < Mp ? bias[gm] : 0.0;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      double v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double t = conv_act(acc[a][b][r] + bv, act);
+        t = fmax(t, __shfl_xor(t, 16));
+        t = fmax(t, __shfl_xor(t, 32));
+        v[r] = t;
+      }
+      const double o = q == 0 ? v[0] : q == 1 ? v[1] : q == 2 ? v[2] : v[3];
+      const int64_t win = ((n0 + wn * (BN / WN) + b * 16) >> 2) + q;
+      if (gm < Mp && win < nwin) Out[gm + (int64_t)Mp * win] = o;
+    }
+  }
+}
+
 // part[split][m + Mp*k'] = sum over the split's positions of Delta[m + Mp*pos] * patch[k', pos]
 template <int BM, int BN, int WM, int WN, int MINW>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_dw_kernel(const double* __restrict__ Delta, int Mp,
@@ -327,6 +407,41 @@ static void launch_conv_gemm(hipStream_t st, const double* Wp, int Mp, const dou
 void launch_conv_forward(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, const ConvGeom& g,
                          int COUTp, int Kp, int64_t npos, int act) {
   launch_conv_gemm<false, true>(st, Wp, COUTp, In, Out, bp, g, npos, Kp, act);
+}
+
+template <int BM, bool CELLU>
+static void launch_conv_pool_bm(hipStream_t st, const double* Wp, int Mp, const double* T, double* Out, const double* bias,
+                                const ConvGeom& g, int64_t npos, int Kp, int act) {
+  constexpr int BN = 128, WM = 2, WN = 4, NT = 512;
+  using SA = Stager<BM, 0, NT, true>;
+  using SB = GatherK<BN, NT, CELLU, false, true>;
+  constexpr size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(double);
+  const int nMt = (Mp + BM - 1) / BM;
+  const int64_t nNt = (npos + BN - 1) / BN;
+  const int64_t grid = nNt >= 8 ? (nNt + 7) / 8 * nMt * 8 : nNt * nMt;
+  auto kern = conv_gemm_pool_kernel<BM, BN, WM, WN, 4, CELLU>;
+  static LdsOptIn optin;
+  optin.ensure(reinterpret_cast<const void*>(kern), lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, Wp, Mp, T, Out, bias, g, npos, Kp, act, nMt, nNt);
+}
+// conv + bias + act + MaxPool((2, 2), stride 2) -> pooled CWHN tensor; needs even Wo and Ho (the caller checks)
+void launch_conv_forward_pool2(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, const ConvGeom& g,
+                               int COUTp, int Kp, int64_t npos, int act) {
+  const bool cellu = g.Cp % 16 == 0;
+  const int bm = conv_pick_bm(COUTp);
+#define SI_POOL_CASE(BM)                                                              \
+  if (cellu)                                                                          \
+    launch_conv_pool_bm<BM, true>(st, Wp, COUTp, In, Out, bp, g, npos, Kp, act);     \
+  else                                                                                \
+    launch_conv_pool_bm<BM, false>(st, Wp, COUTp, In, Out, bp, g, npos, Kp, act)
+  if (bm == 64) {
+    SI_POOL_CASE(64);
+  } else if (bm == 96) {
+    SI_POOL_CASE(96);
+  } else {
+    SI_POOL_CASE(128);
+  }
+#undef SI_POOL_CASE
 }
 
 void launch_conv_backward_data(hipStream_t st, const double* Wt, const double* Delta, double* dX, const ConvGeom& gT, int CINp,

@@ -305,6 +305,8 @@ void launch_conv_pack(hipStream_t st, const double* w, const double* b, double* 
 void launch_conv_pack_t(hipStream_t st, const double* w, double* Wt, int KW, int KH, int CIN, int COUT, int CINp, int COUTp, int KpT);
 void launch_conv_forward(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, const ConvGeom& g,
                          int COUTp, int Kp, int64_t npos, int act);
+void launch_conv_forward_pool2(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, const ConvGeom& g,
+                         int COUTp, int Kp, int64_t npos, int act);
 void launch_conv_backward_data(hipStream_t st, const double* Wt, const double* Delta, double* dX, const ConvGeom& gT, int CINp,
                                int KpT, int64_t npos_in);
 int conv_dw_splits(int COUTp, int Kp, int64_t npos, int num_cu, int64_t* ksplit_out);
@@ -330,7 +332,11 @@ int32_t net_plan(Ctx* c, const char* who, const si_layer* layers, int L, int64_t
 // xin: input in device layout (net_input re-lays a (features x B) matrix when the chain starts on images); outs[l] = where
 // layer l writes (out_elems * B doubles each); wpack: plan.wpack_elems doubles
 void net_input(Ctx* c, const NetPlan& p, const double* X, double* Xc, int64_t B);
-int32_t net_forward(Ctx* c, const NetPlan& p, const double* w, const double* xin, int64_t B, double* const* outs, double* wpack);
+// `outs[l]` receives layer l's output.  pingpong = true (density path: nothing but the last output is needed): `outs` holds TWO
+// buffers used alternately per EXECUTED layer, a Conv directly followed by MaxPool((2, 2)) on even sizes runs as one fused
+// kernel, and *final_out is the buffer that holds the last layer's output.
+int32_t net_forward(Ctx* c, const NetPlan& p, const double* w, const double* xin, int64_t B, double* const* outs, double* wpack,
+                    bool pingpong = false, double** final_out = nullptr);
 void net_scratch_sizes(const NetPlan& p, int64_t B, int num_cu, size_t* bwpart, size_t* rspart, size_t* wt, size_t* dbtmp);
 // g0 holds d / d(output of the last layer) (out_feat x B) on entry; g0 / g1: max_elems * B doubles each; hs[l]: kept outputs
 int32_t net_backward(Ctx* c, const NetPlan& p, const double* w, const double* xin, int64_t B, double* const* hs, double* g0,
