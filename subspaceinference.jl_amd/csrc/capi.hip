@@ -9,7 +9,6 @@
 #include <cstring>
 #include <new>
 #include <sched.h>
-#include <sys/mman.h>
 #include <thread>
 #include <vector>
 
@@ -1566,7 +1565,7 @@ int32_t si_rwmh_end(si_ctx* ctx, double* Z_out, double* lp_out, double* accept_r
 // A three-stage pipeline so that the PCIe link, not a single host thread, sets the pace: K4 writes a group of samples
 // into one of two device buffers (compute stream) -> DMA into one of two PINNED staging buffers (copy stream) -> a few
 // host threads move the previous group from the staging buffer into the caller's (pageable, usually never-touched)
-// array.  A plain hipMemcpy into pageable memory does the last two steps on one thread: 0.79 ms per 8.4 MB sample.
+// array (its first-touch page faults are spread over those threads too; a MADV_HUGEPAGE hint was tried and gained nothing).  A plain hipMemcpy into pageable memory does the last two steps on one thread: 0.79 ms per 8.4 MB sample.
 static void host_copy_parallel(double* dst, const double* src, size_t elems, int nthreads) {
   if (nthreads <= 1 || elems < ((size_t)1 << 18)) {
     std::memcpy(dst, src, elems * sizeof(double));
@@ -1606,12 +1605,6 @@ int32_t si_reconstruct(si_ctx* ctx, const double* Z, int64_t C, double* W_out) {
   const int nthreads = host_copy_threads();
   hipEvent_t ev_comp[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
   hipError_t e = hipSuccess;
-  {  // a never-touched destination is faulted in while it is written: ask for huge pages on its aligned interior (a hint;
-     // without THP the call fails and nothing changes) -- 4 KiB faults cap the copy-out near 14 GB/s whatever the threads
-    const uintptr_t lo = (reinterpret_cast<uintptr_t>(W_out) + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1);
-    const uintptr_t hi = (reinterpret_cast<uintptr_t>(W_out) + (uintptr_t)N * (uintptr_t)C * sizeof(double)) & ~(((uintptr_t)2 << 20) - 1);
-    if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
-  }
   if (!ctx->stream2) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
   if (e == hipSuccess && (ctx->d_stage_cap < (size_t)ldw * (size_t)group_cap || ctx->d_zstage_cap < (size_t)M * (size_t)group_cap)) {
     (void)hipStreamSynchronize(ctx->stream);

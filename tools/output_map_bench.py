@@ -4,6 +4,10 @@ import os
 import sys
 import time
 
+# NumPy's BLAS would start one spinning thread per visible CPU (256 on the GPU box) for the reference product below and burn
+# the container's CPU quota: the cgroup then throttles the whole process for ~80 ms at a time, inside the timed calls
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "4")
+
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,20 +15,33 @@ import subspaceinference_jl_amd as si  # noqa: E402
 from subspaceinference_jl_amd import _capi  # noqa: E402
 
 N, M = 1047361, 20
+if os.environ.get("TORCH_INIT"):   # development: does an initialised torch runtime in the process change the copy-out?
+    import torch
+    torch.zeros(1, device="cuda")
+BX = int(os.environ.get("BX", "64"))
 rng = np.random.default_rng(0)
 ctx = si.Context(0)
 table = [(128, 960, 1, 0, 128 * 960), (960, 960, 1, 128 * 960 + 960, 128 * 960 + 960 + 960 * 960),
          (960, 1, 0, 128 * 960 + 960 + 960 * 960 + 960, 128 * 960 + 960 + 960 * 960 + 960 + 960)]
 w = rng.standard_normal(N)
 p = np.asfortranarray(rng.standard_normal((N, M)))
-x = np.asfortranarray(rng.standard_normal((128, 64)))
-y = np.asfortranarray(rng.standard_normal((1, 64)))
+x = np.asfortranarray(rng.standard_normal((128, BX)))
+y = np.asfortranarray(rng.standard_normal((1, BX)))
 ctx.infer_setup(table, N, M, w, p, x, y, 1.0)
-for c in (1, 8, 32, 64, 256):
+if os.environ.get("SAMPLE"):       # development: a chain first, as bench.py does
+    ctx.sample_rwmh(int(os.environ["SAMPLE"]), 0.1, seed=1)
+if os.environ.get("PROF"):
+    ctx.set_profiling(True)
+    ctx.reset_stats()
+    ctx.sample_rwmh(5, 0.1, seed=1)
+    ctx.synchronize()
+    ctx.stats()
+    ctx.set_profiling(False)
+for c in [int(a) for a in sys.argv[1:]] or (1, 8, 32, 64, 256):
     z = np.asfortranarray(rng.standard_normal((M, c)))
     ctx.reconstruct(z[:, :1])
     fresh, touched, ok = [], [], True
-    for rep in range(5):
+    for rep in range(int(os.environ.get('REPS', '5'))):
         t0 = time.perf_counter()
         out = ctx.reconstruct(z)
         fresh.append((time.perf_counter() - t0) / c * 1e3)
