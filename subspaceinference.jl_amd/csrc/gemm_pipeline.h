@@ -114,7 +114,8 @@ struct Stager {
 
 // acc[a][b] += sum over the nk k tiles the two stagers deliver (klen = k values of this block's range; only the last tile
 // may be ragged).  smem: [2][SA::LDS_ELEMS] then [2][SB::LDS_ELEMS].  wm / wn: this wave's position in the WM x WN grid.
-template <int BM, int BN, int WM, int WN, class SA, class SB>
+// NOEDGE: the caller guarantees klen % 16 == 0 (no ragged tile): the edge variants of the stagers are not even compiled in.
+template <int BM, int BN, int WM, int WN, bool NOEDGE = false, class SA, class SB>
 __device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, double* smem, int nk, int64_t klen, int wm, int wn, int lane,
                                               d4 (&acc)[BM / WM / 16][BN / WN / 16], int dbg) {
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -151,9 +152,9 @@ __device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, double* smem, int 
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
   // only the last tile of a split can be ragged; the choice is block-uniform (a scalar branch)
-  const int edge_kt = (klen & 15) ? nk - 1 : -1;
+  const int edge_kt = (!NOEDGE && (klen & 15)) ? nk - 1 : -1;
   auto load_tile = [&](int kt) {
-    if (kt == edge_kt) {
+    if (!NOEDGE && kt == edge_kt) {
       sa.load_edge(kt, klen);
       sb.load_edge(kt, klen);
     } else {
@@ -163,7 +164,7 @@ __device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, double* smem, int 
   };
   auto store_tile = [&](auto BUF, int kt) {
     constexpr int buf = decltype(BUF)::value;
-    if (kt == edge_kt) {
+    if (!NOEDGE && kt == edge_kt) {
       sa.store_edge(sAbuf + buf * SA::LDS_ELEMS, kt, klen);
       sb.store_edge(sBbuf + buf * SB::LDS_ELEMS, kt, klen);
     } else {

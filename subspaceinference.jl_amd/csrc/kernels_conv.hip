@@ -55,8 +55,12 @@ struct GatherK {
   static constexpr int NREG = (16 * R + NT * 2 - 1) / (NT * 2);
   static constexpr int RP = R + 16, KP = 18;
   static constexpr int LDS_ELEMS = R * KP;
-  int pb[NREG], wb[NREG], hb[NREG], lds[NREG], kk[NREG];
-  bool live[NREG];
+  // every slot is live and slot r sits NT / 8 positions behind slot 0 at the same k pair (keeps the per-slot state small:
+  // the 128 x 128 kernels run at a 128-register budget and spilled into their k loop with per-slot copies of these)
+  static_assert((16 * R) % (NT * 2) == 0 && (NT * 2) % 16 == 0, "GatherK: R * 16 must be a multiple of 2 NT");
+  int pb[NREG], wb[NREG], hb[NREG];
+  int kk, lds0;
+  int t_cin, t_adil, t_cdil;   // CELLU: the (block-uniform) tap of the NEXT k tile; the mainloop asks for the tiles in order
   double2 reg[NREG];
   const double* T;
   ConvGeom g;
@@ -65,11 +69,15 @@ struct GatherK {
     T = T_;
     g = g_;
     const int wh = g.Wo * g.Ho;
+    kk = (tid * 2) & 15;
+    lds0 = (tid >> 3) * KP + kk;
+    t_cin = 0;
+    t_adil = 0;
+    t_cdil = 0;
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
-      const int idx = (tid + NT * r) * 2;
-      const int k = idx & 15, rr = idx >> 4;
-      int64_t pos = n0 + (rr < R ? rr : 0);
+      const int rr = (tid >> 3) + (NT / 8) * r;
+      int64_t pos = n0 + rr;
       if (pos > npos - 1) pos = npos - 1;  // clamped positions only feed outputs that are never stored
       int img, ho, wo;
       if constexpr (POOLP) {
@@ -89,9 +97,6 @@ struct GatherK {
       pb[r] = img * (int)g.img_stride;
       wb[r] = wo * g.snum_w - g.pad_w;
       hb[r] = ho * g.snum_h - g.pad_h;
-      kk[r] = k;
-      live[r] = rr < R;
-      lds[r] = rr * KP + k;
     }
   }
   __device__ __forceinline__ void fetch(int r, int a_dil, int c_dil, int cin, bool kvalid) {
@@ -109,15 +114,22 @@ struct GatherK {
   }
   __device__ __forceinline__ void load(int kt) {
     if constexpr (CELLU) {
-      const int k0 = 16 * kt;                       // block-uniform tap of this k tile
-      const int cell = k0 / g.Cp, cin0 = k0 - cell * g.Cp;
-      const int c = cell / g.KW, a = cell - c * g.KW;
+      // Cp % 16 == 0: a k tile lies inside one tap; the tap advances by a carry instead of two divisions per tile
 #pragma unroll
-      for (int r = 0; r < NREG; ++r) fetch(r, a * g.dil_w, c * g.dil_h, cin0 + kk[r], true);
+      for (int r = 0; r < NREG; ++r) fetch(r, t_adil, t_cdil, t_cin + kk, true);
+      t_cin += 16;
+      if (t_cin >= g.Cp) {
+        t_cin = 0;
+        t_adil += g.dil_w;
+        if (t_adil >= g.KW * g.dil_w) {
+          t_adil = 0;
+          t_cdil += g.dil_h;
+        }
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < NREG; ++r) {
-        const int kp = 16 * kt + kk[r];
+        const int kp = 16 * kt + kk;
         const int cell = kp / g.Cp, cin = kp - cell * g.Cp;
         const int c = cell / g.KW, a = cell - c * g.KW;
         fetch(r, a * g.dil_w, c * g.dil_h, cin, kp < g.Kvalid);
@@ -126,8 +138,7 @@ struct GatherK {
   }
   __device__ __forceinline__ void store(double* dst) const {
 #pragma unroll
-    for (int r = 0; r < NREG; ++r)
-      if (live[r]) *reinterpret_cast<double2*>(dst + lds[r]) = reg[r];
+    for (int r = 0; r < NREG; ++r) *reinterpret_cast<double2*>(dst + lds0 + r * (NT / 8) * KP) = reg[r];
   }
   // k is padded to whole tiles (Kp % 16 == 0, taps past Kvalid read as zero): there is no ragged tile
   __device__ __forceinline__ void load_edge(int kt, int64_t) { load(kt); }
@@ -142,14 +153,16 @@ struct GatherN {
   static constexpr int NREG = (16 * R + NT * 2 - 1) / (NT * 2);
   static constexpr int RP = R + 16, KP = 18;
   static constexpr int LDS_ELEMS = 16 * RP;
-  // per slot: the tap (fixed) and the output pixel (wo, ho, image offset) of the CURRENT k tile.  The mainloop asks for
-  // the k tiles in order, once each, so the pixel is advanced by 16 positions per load() with a mixed-radix carry --
-  // the 64-bit division pos -> (image, ho, wo) per slot and tile made this kernel VALU-bound (half the speed of the
-  // forward convolution) when it was recomputed every time.
-  // (ioff carries the channel too; left = 0 for a tap row past Kvalid)
-  static constexpr bool EXACT = (16 * R) % (NT * 2) == 0;  // every slot is live
-  int aoff[NREG], coff[NREG], lds[NREG], left[NREG], wo[NREG], ho[NREG], ioff[NREG];
-  bool live[NREG];
+  // every slot is live; all slots of a thread share the tap row rr = (2 tid) % R and sit (2 NT / R) positions apart
+  static_assert((16 * R) % (NT * 2) == 0 && (NT * 2) % R == 0, "GatherN: 2 NT must be a multiple of R and divide 16 R");
+  static constexpr int KSTEP = NT * 2 / R;
+  // per slot: the output pixel (wo, ho, image offset + channel) of the CURRENT k tile.  The mainloop asks for the k tiles
+  // in order, once each, so the pixel is advanced by 16 positions per load() with a mixed-radix carry -- the 64-bit
+  // division pos -> (image, ho, wo) per slot and tile made this kernel VALU-bound (half the speed of the forward
+  // convolution) when it was recomputed every time.  left = positions of the slot's column that remain in the split
+  // (0 for a tap row past Kvalid).
+  int aoff, coff, lds0;
+  int left[NREG], wo[NREG], ho[NREG], ioff[NREG];
   double2 reg[NREG];
   const double* T;
   ConvGeom g;
@@ -162,30 +175,28 @@ struct GatherN {
     dw16 = 16 % g.Wo;
     dh16 = (16 / g.Wo) % g.Ho;
     di16 = (16 / wh) * (int)g.img_stride;
+    const int rr = (tid * 2) % R, kq0 = (tid * 2) / R;
+    const int kp = (int)n0 + rr;
+    const int cell = kp / g.Cp;
+    const int c = cell / g.KW, a = cell - c * g.KW;
+    aoff = a * g.dil_w - g.pad_w;
+    coff = c * g.dil_h - g.pad_h;
+    lds0 = kq0 * RP + rr;
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
-      const int idx = (tid + NT * r) * 2;
-      const int rr = idx % R, k = idx / R;
-      const int kp = (int)n0 + rr;
-      const int cell = kp / g.Cp;
-      const int c = cell / g.KW, a = cell - c * g.KW;
-      aoff[r] = a * g.dil_w - g.pad_w;
-      coff[r] = c * g.dil_h - g.pad_h;
-      live[r] = EXACT || k < 16;
-      lds[r] = k * RP + rr;
-      const int64_t pos = k0 + k;
+      const int64_t pos = k0 + kq0 + KSTEP * r;
       const int img = (int)(pos / wh), sp = (int)(pos - (int64_t)img * wh);
       ho[r] = sp / g.Wo;
       wo[r] = sp - ho[r] * g.Wo;
       ioff[r] = img * (int)g.img_stride + (kp - cell * g.Cp);
-      const int64_t l = kend - pos;  // positions of this slot's column that remain in the split
+      const int64_t l = kend - pos;
       left[r] = (l > 0 && kp < g.Kvalid) ? (int)(l < 0x7fffffff ? l : 0x7fffffff) : 0;
     }
   }
   __device__ __forceinline__ void load(int kt) {
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
-      const int wi = wo[r] * g.snum_w + aoff[r], hi = ho[r] * g.snum_h + coff[r];
+      const int wi = wo[r] * g.snum_w + aoff, hi = ho[r] * g.snum_h + coff;
       const bool ok = 16 * kt < left[r] && wi >= 0 && hi >= 0 && wi < g.Wi && hi < g.Hi;
       const int off = ok ? ioff[r] + g.Cp * (wi + g.Wi * hi) : 0;
       const double2 v = *reinterpret_cast<const double2*>(T + off);
@@ -207,8 +218,7 @@ struct GatherN {
   }
   __device__ __forceinline__ void store(double* dst) const {
 #pragma unroll
-    for (int r = 0; r < NREG; ++r)
-      if (EXACT || live[r]) *reinterpret_cast<double2*>(dst + lds[r]) = reg[r];
+    for (int r = 0; r < NREG; ++r) *reinterpret_cast<double2*>(dst + lds0 + r * KSTEP * RP) = reg[r];
   }
   __device__ __forceinline__ void load_edge(int kt, int64_t) { load(kt); }  // positions past the split's end are masked in load()
   __device__ __forceinline__ void store_edge(double* dst, int, int64_t) const { store(dst); }
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_kernel(const dou
   SB sb;
   sa.init(Wp, Mp, m0, Mp, 0, tid);
   sb.init(T, g, n0, npos, tid);
-  gemm_mainloop<BM, BN, WM, WN>(sa, sb, smem, Kp / 16, (int64_t)Kp, wm, wn, lane, acc, 0);
+  gemm_mainloop<BM, BN, WM, WN, true>(sa, sb, smem, Kp / 16, (int64_t)Kp, wm, wn, lane, acc, 0);
   gemm_epilogue<BM, BN, WM, WN, true, 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS)>(
       acc, smem, Out, (int64_t)Mp, m0, n0, Mp, npos, wm, wn, lane, wave, [&](double v, int64_t, int gm) {
         if constexpr (BIASACT) v = conv_act(v + bias[gm], act);
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_pool_kernel(cons
   SB sb;
   sa.init(Wp, Mp, m0, Mp, 0, tid);
   sb.init(T, g, n0, npos, tid);
-  gemm_mainloop<BM, BN, WM, WN>(sa, sb, smem, Kp / 16, (int64_t)Kp, wm, wn, lane, acc, 0);
+  gemm_mainloop<BM, BN, WM, WN, true>(sa, sb, smem, Kp / 16, (int64_t)Kp, wm, wn, lane, acc, 0);
   const int q = lane >> 4, c = lane & 15;
   const int64_t nwin = npos >> 2;
 #pragma unroll

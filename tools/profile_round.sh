@@ -28,7 +28,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/cnn_kt -o c -- python
 python3 $R/tools/kstats.py $O/cnn_kt 20 > $O/cfg4_cnn_kernel_stats.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cnng_kt -o g -- python3 $R/tools/cfg4_cnn_grad_profile.py > /dev/null 2>&1
 python3 $R/tools/kstats.py $O/cnng_kt 20 > $O/cfg4_cnn_grad_kernel_stats.txt
-rm -rf $O/cnn_kt $O/cnng_kt $O/bench_kt
+# transitions alone at B = 4096 (the mixed run above also holds the B = 1024 training launches): per-layer times
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/cnns_kt -o s -- python3 $R/tools/cfg4_cnn_sample_profile.py > /dev/null 2>&1
+python3 $R/tools/kstats.py $O/cnns_kt 12 > $O/cfg4_cnn_sample_kernel_stats.txt
+python3 $R/tools/per_layer.py $O/cnns_kt 14 15 >> $O/cfg4_cnn_sample_kernel_stats.txt
+rm -rf $O/cnn_kt $O/cnng_kt $O/cnns_kt $O/bench_kt
 echo "[4] bench lines"
 cd $R
 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err
