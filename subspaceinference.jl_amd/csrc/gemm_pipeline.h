@@ -22,14 +22,40 @@ struct Stager {
   static constexpr int NREG = (16 * R + NT * E - 1) / (NT * E);
   static constexpr int RP = R + 16, KP = 18;
   static constexpr int LDS_ELEMS = LAY == 0 ? 16 * RP : R * KP;
-  int go[NREG], lds[NREG], kk[NREG];
-  bool live[NREG];
+  // EXACT: the tile is a whole number of thread sweeps and consecutive slots of a thread differ by a constant step (in k for
+  // LAY 0, in rows for LAY 1).  Then every slot is live and lds / kk (and go for LAY 0) of slot r follow from slot 0 --
+  // the 128 x 128 kernels run on a 128-register budget and spilled into their k loop with per-slot copies of all of these.
+  static constexpr bool EXACT = (16 * R) % (NT * E) == 0 && (LAY == 0 ? (NT * E) % R == 0 : (NT * E) % 16 == 0);
+  static constexpr int STEP = LAY == 0 ? (NT * E) / R : (NT * E) / 16;   // k step (LAY 0) / row step (LAY 1) between slots
+  static constexpr int NS = EXACT ? 1 : NREG;                           // per-slot copies actually kept
+  static constexpr int NGO = (EXACT && LAY == 0) ? 1 : NREG;
+  int go_[NGO], lds_[NS], kk_[NS];
+  bool live_[NS];
+  int ldi;
   double reg[NREG][E];
   const double* base;
   int64_t ld;
 
+  __device__ __forceinline__ int go(int r) const {
+    if constexpr (EXACT && LAY == 0) return go_[0] + r * STEP * ldi;
+    else return go_[r];
+  }
+  __device__ __forceinline__ int lds(int r) const {
+    if constexpr (EXACT) return lds_[0] + r * STEP * (LAY == 0 ? RP : KP);
+    else return lds_[r];
+  }
+  __device__ __forceinline__ int kk(int r) const {
+    if constexpr (EXACT) return kk_[0] + (LAY == 0 ? r * STEP : 0);
+    else return kk_[r];
+  }
+  __device__ __forceinline__ bool live(int r) const {
+    if constexpr (EXACT) return true;
+    else return live_[r];
+  }
+
   __device__ __forceinline__ void init(const double* X, int64_t ld_, int64_t r0, int64_t rmax, int64_t k0, int tid) {
     ld = ld_;
+    ldi = (int)ld_;
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
       const int idx = (tid + NT * r) * E;
@@ -38,18 +64,22 @@ struct Stager {
         int64_t g = r0 + rr;
         if (g > rmax - E) g = rmax - E;  // clamped rows only feed outputs that are never stored
         if (g < 0) g = 0;
-        kk[r] = k;
-        live[r] = k < 16;
-        go[r] = (int)(g - r0) + (int)ld * (k < 16 ? k : 0);
-        lds[r] = k * RP + rr;
+        if (r < NS) {
+          kk_[r < NS ? r : 0] = k;
+          live_[r < NS ? r : 0] = k < 16;
+          lds_[r < NS ? r : 0] = k * RP + rr;
+        }
+        if (r < NGO) go_[r < NGO ? r : 0] = (int)(g - r0) + (int)ld * (k < 16 ? k : 0);
       } else {
         const int k = idx & 15, rr = idx >> 4;
         int64_t g = r0 + (rr < R ? rr : 0);
         if (g > rmax - 1) g = rmax - 1;
-        kk[r] = k;
-        live[r] = rr < R;
-        go[r] = (int)(g - r0) * (int)ld + k;
-        lds[r] = rr * KP + k;
+        if (r < NS) {
+          kk_[r < NS ? r : 0] = k;
+          live_[r < NS ? r : 0] = rr < R;
+          lds_[r < NS ? r : 0] = rr * KP + k;
+        }
+        go_[r] = (int)(g - r0) * (int)ld + k;
       }
     }
     base = LAY == 0 ? X + r0 + ld * k0 : X + ld * r0 + k0;
@@ -63,22 +93,22 @@ struct Stager {
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
       if constexpr (VEC) {
-        const double2 v = *reinterpret_cast<const double2*>(p + go[r]);
+        const double2 v = *reinterpret_cast<const double2*>(p + go(r));
         reg[r][0] = v.x;
         reg[r][1] = v.y;
       } else {
-        reg[r][0] = p[go[r]];
+        reg[r][0] = p[go(r)];
       }
     }
   }
   __device__ __forceinline__ void store(double* dst) const {
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
-      if (!live[r]) continue;
+      if (!live(r)) continue;
       if constexpr (VEC)
-        *reinterpret_cast<double2*>(dst + lds[r]) = make_double2(reg[r][0], reg[r][1]);
+        *reinterpret_cast<double2*>(dst + lds(r)) = make_double2(reg[r][0], reg[r][1]);
       else
-        dst[lds[r]] = reg[r][0];
+        dst[lds(r)] = reg[r][0];
     }
   }
   // Ragged last tile (klen % 16 != 0): k indices past the end are clamped to a legal address and zero-filled in LDS
@@ -88,8 +118,8 @@ struct Stager {
     const int64_t kmax = klen_total - (LAY == 1 ? E : 1) - (int64_t)kt * 16;  // last legal k (pair start) in this tile
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
-      int o = go[r];
-      if (kk[r] > kmax) o -= (int)(LAY == 0 ? ld : 1) * (int)(kk[r] - (kmax > 0 ? kmax : 0));
+      int o = go(r);
+      if (kk(r) > kmax) o -= (int)(LAY == 0 ? ld : 1) * (int)(kk(r) - (kmax > 0 ? kmax : 0));
       if constexpr (VEC) {
         const double2 v = *reinterpret_cast<const double2*>(p + o);
         reg[r][0] = v.x;
@@ -102,12 +132,12 @@ struct Stager {
   __device__ __forceinline__ void store_edge(double* dst, int kt, int64_t klen_total) const {
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
-      if (!live[r]) continue;
-      const bool ok = (int64_t)kt * 16 + kk[r] < klen_total;
+      if (!live(r)) continue;
+      const bool ok = (int64_t)kt * 16 + kk(r) < klen_total;
       if constexpr (VEC)
-        *reinterpret_cast<double2*>(dst + lds[r]) = make_double2(ok ? reg[r][0] : 0.0, ok ? reg[r][1] : 0.0);
+        *reinterpret_cast<double2*>(dst + lds(r)) = make_double2(ok ? reg[r][0] : 0.0, ok ? reg[r][1] : 0.0);
       else
-        dst[lds[r]] = ok ? reg[r][0] : 0.0;
+        dst[lds(r)] = ok ? reg[r][0] : 0.0;
     }
   }
 };
