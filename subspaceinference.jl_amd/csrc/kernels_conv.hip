@@ -161,20 +161,25 @@ struct GatherN {
   // division pos -> (image, ho, wo) per slot and tile made this kernel VALU-bound (half the speed of the forward
   // convolution) when it was recomputed every time.  left = positions of the slot's column that remain in the split
   // (0 for a tap row past Kvalid).
+  // Only slot 0's pixel is kept; slot r's is KSTEP * r positions further (a carry per digit, like the advance per tile).
   int aoff, coff, lds0;
-  int left[NREG], wo[NREG], ho[NREG], ioff[NREG];
+  int left0, wo0, ho0, ioff0;
   double2 reg[NREG];
   const double* T;
   ConvGeom g;
-  int dw16, dh16, di16;
+  int dw16, dh16, di16, dws, dhs, dis;
 
   __device__ __forceinline__ void init(const double* T_, const ConvGeom& g_, int64_t n0, int64_t k0, int64_t kend, int tid) {
+    static_assert(KSTEP <= 16, "slots of a thread lie inside one k tile");
     T = T_;
     g = g_;
     const int wh = g.Wo * g.Ho;
     dw16 = 16 % g.Wo;
     dh16 = (16 / g.Wo) % g.Ho;
     di16 = (16 / wh) * (int)g.img_stride;
+    dws = KSTEP % g.Wo;
+    dhs = (KSTEP / g.Wo) % g.Ho;
+    dis = (KSTEP / wh) * (int)g.img_stride;
     const int rr = (tid * 2) % R, kq0 = (tid * 2) / R;
     const int kp = (int)n0 + rr;
     const int cell = kp / g.Cp;
@@ -182,39 +187,39 @@ struct GatherN {
     aoff = a * g.dil_w - g.pad_w;
     coff = c * g.dil_h - g.pad_h;
     lds0 = kq0 * RP + rr;
-#pragma unroll
-    for (int r = 0; r < NREG; ++r) {
-      const int64_t pos = k0 + kq0 + KSTEP * r;
-      const int img = (int)(pos / wh), sp = (int)(pos - (int64_t)img * wh);
-      ho[r] = sp / g.Wo;
-      wo[r] = sp - ho[r] * g.Wo;
-      ioff[r] = img * (int)g.img_stride + (kp - cell * g.Cp);
-      const int64_t l = kend - pos;
-      left[r] = (l > 0 && kp < g.Kvalid) ? (int)(l < 0x7fffffff ? l : 0x7fffffff) : 0;
+    const int64_t pos = k0 + kq0;
+    const int img = (int)(pos / wh), sp = (int)(pos - (int64_t)img * wh);
+    ho0 = sp / g.Wo;
+    wo0 = sp - ho0 * g.Wo;
+    ioff0 = img * (int)g.img_stride + (kp - cell * g.Cp);
+    const int64_t l = kend - pos;
+    left0 = (l > 0 && kp < g.Kvalid) ? (int)(l < 0x7fffffff ? l : 0x7fffffff) : 0;
+  }
+  __device__ __forceinline__ static void step(int& w, int& h, int& im, int dw, int dh, int di, const ConvGeom& g) {
+    w += dw;   // each digit overflows at most once (w + dw < 2 Wo, h + dh + 1 < 2 Ho)
+    h += dh;
+    im += di;
+    if (w >= g.Wo) {
+      w -= g.Wo;
+      ++h;
+    }
+    if (h >= g.Ho) {
+      h -= g.Ho;
+      im += (int)g.img_stride;
     }
   }
   __device__ __forceinline__ void load(int kt) {
+    int w = wo0, h = ho0, im = ioff0;
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
-      const int wi = wo[r] * g.snum_w + aoff, hi = ho[r] * g.snum_h + coff;
-      const bool ok = 16 * kt < left[r] && wi >= 0 && hi >= 0 && wi < g.Wi && hi < g.Hi;
-      const int off = ok ? ioff[r] + g.Cp * (wi + g.Wi * hi) : 0;
+      const int wi = w * g.snum_w + aoff, hi = h * g.snum_h + coff;
+      const bool ok = 16 * kt + KSTEP * r < left0 && wi >= 0 && hi >= 0 && wi < g.Wi && hi < g.Hi;
+      const int off = ok ? im + g.Cp * (wi + g.Wi * hi) : 0;
       const double2 v = *reinterpret_cast<const double2*>(T + off);
       reg[r] = ok ? v : make_double2(0.0, 0.0);
-      // advance the pixel by 16 positions: each digit overflows at most once (wo + dw16 < 2 Wo, ho + dh16 + 1 < 2 Ho)
-      int w = wo[r] + dw16, h = ho[r] + dh16, im = ioff[r] + di16;
-      if (w >= g.Wo) {
-        w -= g.Wo;
-        ++h;
-      }
-      if (h >= g.Ho) {
-        h -= g.Ho;
-        im += (int)g.img_stride;
-      }
-      wo[r] = w;
-      ho[r] = h;
-      ioff[r] = im;
+      if (r + 1 < NREG) step(w, h, im, dws, dhs, dis, g);
     }
+    step(wo0, ho0, ioff0, dw16, dh16, di16, g);   // the next k tile: 16 positions further
   }
   __device__ __forceinline__ void store(double* dst) const {
 #pragma unroll
@@ -336,7 +341,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_pool_kernel(cons
 }
 
 // part[split][m + Mp*k'] = sum over the split's positions of Delta[m + Mp*pos] * patch[k', pos]
-template <int BM, int BN, int WM, int WN, int MINW>
+// NOEDGE: npos % 16 == 0, so every split is a whole number of k tiles (the ragged-tile code is not compiled in)
+template <int BM, int BN, int WM, int WN, int MINW, bool NOEDGE>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_dw_kernel(const double* __restrict__ Delta, int Mp,
                                                                      const double* __restrict__ T, double* __restrict__ part,
                                                                      ConvGeom g, int64_t npos, int Kp, int64_t ksplit, int nMt,
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_dw_kernel(const doubl
   SB sb;
   sa.init(Delta, Mp, m0, Mp, k0, tid);
   sb.init(T, g, n0, k0, k0 + klen, tid);
-  gemm_mainloop<BM, BN, WM, WN>(sa, sb, smem, (int)((klen + 15) / 16), klen, wm, wn, lane, acc, 0);
+  gemm_mainloop<BM, BN, WM, WN, NOEDGE>(sa, sb, smem, (int)((klen + 15) / 16), klen, wm, wn, lane, acc, 0);
   gemm_epilogue<BM, BN, WM, WN, true, 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS)>(
       acc, smem, part + split * (int64_t)Mp * Kp, (int64_t)Mp, m0, (int64_t)n0, Mp, (int64_t)Kp, wm, wn, lane, wave,
       [&](double v, int64_t, int) { return v; });
@@ -483,11 +489,19 @@ static void launch_conv_dw_bm(hipStream_t st, const double* Delta, int Mp, const
   using SB = GatherN<BN, NT>;
   constexpr size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(double);
   const int nMt = (Mp + BM - 1) / BM, nNt = (Kp + BN - 1) / BN;
-  auto kern = conv_dw_kernel<BM, BN, WM, WN, 4>;
-  static LdsOptIn optin;
-  optin.ensure(reinterpret_cast<const void*>(kern), lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(nMt * nNt), (unsigned)nsplit), dim3(NT), lds, st, Delta, Mp, In, part, g, npos, Kp,
-                     ksplit, nMt, nNt);
+  if (npos % 16 == 0) {   // (ksplit is a multiple of 16 by construction)
+    auto kern = conv_dw_kernel<BM, BN, WM, WN, 4, true>;
+    static LdsOptIn optin;
+    optin.ensure(reinterpret_cast<const void*>(kern), lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nMt * nNt), (unsigned)nsplit), dim3(NT), lds, st, Delta, Mp, In, part, g, npos, Kp,
+                       ksplit, nMt, nNt);
+  } else {
+    auto kern = conv_dw_kernel<BM, BN, WM, WN, 4, false>;
+    static LdsOptIn optin;
+    optin.ensure(reinterpret_cast<const void*>(kern), lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nMt * nNt), (unsigned)nsplit), dim3(NT), lds, st, Delta, Mp, In, part, g, npos, Kp,
+                       ksplit, nMt, nNt);
+  }
 }
 
 void launch_conv_backward_weight(hipStream_t st, const double* Delta, const double* In, double* part, const ConvGeom& g,
