@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <sched.h>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -1573,11 +1574,19 @@ static void host_copy_parallel(double* dst, const double* src, size_t elems, int
   }
   std::vector<std::thread> th;
   const size_t per = ((elems + nthreads - 1) / nthreads + 511) & ~(size_t)511;   // 4 KiB-granular slices
+  size_t done_to = std::min(elems, per);   // slices [per, done_to) are in the hands of helper threads
   for (int t = 1; t < nthreads; ++t) {
     const size_t lo = std::min(elems, per * t), hi = std::min(elems, per * (t + 1));
-    if (hi > lo) th.emplace_back([=] { std::memcpy(dst + lo, src + lo, (hi - lo) * sizeof(double)); });
+    if (hi <= lo) break;
+    try {
+      th.emplace_back([=] { std::memcpy(dst + lo, src + lo, (hi - lo) * sizeof(double)); });
+      done_to = hi;
+    } catch (const std::system_error&) {   // no more threads to be had (process limit): this thread copies the rest
+      break;
+    }
   }
   std::memcpy(dst, src, std::min(elems, per) * sizeof(double));
+  if (done_to < elems) std::memcpy(dst + done_to, src + done_to, (elems - done_to) * sizeof(double));
   for (auto& t : th) t.join();
 }
 
