@@ -28,6 +28,11 @@ CASES = [
     # a pool behind a pool (the second one takes the un-fused MaxPool gradient; the first one the pass fused with the
     # conv layer's act' and bias sum), 70 channels (two 64-row blocks of the fused pass), sigmoid (act'(pad channel) != 0)
     ((8, 8, 3), [("conv", (3, 3), 70, S, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("maxpool", (2, 2)), ("flatten",), ("dense", 3, I)], 19),
+    # MaxPool((2, 2)) on ODD sizes (7 x 5 -> 3 x 2: the last row / column is dropped): the sampling path must not take the
+    # fused conv + pool kernel here, the reverse sweep routes no gradient to the dropped pixels
+    ((7, 5, 2), [("conv", (3, 3), 5, R, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("flatten",), ("dense", 2, I)], 13),
+    # ... and on even sizes with a batch that leaves the last 128-position tile ragged (6 * 4 * 37 = 888 positions)
+    ((6, 4, 3), [("conv", (3, 3), 18, T, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("flatten",), ("dense", 2, I)], 37),
 ]
 
 
