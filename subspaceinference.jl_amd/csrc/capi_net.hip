@@ -148,7 +148,10 @@ int32_t net_forward(Ctx* c, const NetPlan& p, const double* w, const double* xin
       case SI_LAYER_DENSE: {
         ProfScope ps(c, SI_K_DENSE, 2.0 * (double)q.in_feat * q.out_feat * (double)B,
                      ((double)q.in_feat * q.out_feat + q.out_feat + (double)(q.in_feat + q.out_feat) * (double)B) * 8.0);
-        launch_dense_f64(st, w + q.w_off, w + q.b_off, h, o, q.out_feat, q.in_feat, B, q.act);
+        if (dense_narrow_applies(q.out_feat, q.in_feat, B, c->num_cu))
+          launch_dense_narrow(st, w + q.w_off, w + q.b_off, h, o, q.out_feat, q.in_feat, B, q.act);
+        else
+          launch_dense_f64(st, w + q.w_off, w + q.b_off, h, o, q.out_feat, q.in_feat, B, q.act);
         break;
       }
       case SI_LAYER_CONV: {

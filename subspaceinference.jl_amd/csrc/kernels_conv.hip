@@ -812,4 +812,65 @@ void launch_maxpool_bwd_dact_rowsum(hipStream_t st, const double* In, const doub
   hipLaunchKernelGGL(rowsum_chunks_final_kernel, dim3((nout + 63) / 64), dim3(1024), 0, st, part, Cp, nch, nout, db);
 }
 
+// Dense layer with a NARROW output (out <= 16: the 10-class head of a CNN) on a small batch.  The MFMA kernel gives such a
+// layer one 32-row tile per 128 columns -- 32 workgroups at B = 4096, each walking all of `in` as one dependent chain of k
+// tiles (0.22 ms for 4096 -> 10 at B = 4096, 0.6 TB/s).  Here a WAVE owns CW columns: lanes stride over k (coalesced reads
+// of the activation column and of W's 8*out-byte rows), out * CW accumulators per lane, one butterfly reduction at the end.
+// Fixed summation order (k = lane, lane + 64, ... then the xor butterfly): bit-reproducible.
+template <int CW>
+__global__ __launch_bounds__(256) void dense_narrow_kernel(const double* __restrict__ W, const double* __restrict__ bias,
+                                                           const double* __restrict__ Hin, double* __restrict__ Hout, int out, int in,
+                                                           int64_t B, int act) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * CW;
+  if (b0 >= B) return;
+  double acc[CW][16];
+#pragma unroll
+  for (int c = 0; c < CW; ++c)
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[c][o] = 0.0;
+  const double* hcol[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) hcol[c] = Hin + (int64_t)in * (b0 + c < B ? b0 + c : B - 1);
+  for (int k = lane; k < in; k += 64) {
+    double h[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) h[c] = hcol[c][k];
+    const double* wk = W + (int64_t)out * k;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      const double wv = o < out ? wk[o] : 0.0;
+#pragma unroll
+      for (int c = 0; c < CW; ++c) acc[c][o] = fma(wv, h[c], acc[c][o]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CW; ++c)
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      double v = acc[c][o];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      acc[c][o] = v;
+    }
+  if (lane < 16 * CW) {
+    const int c = lane >> 4, o = lane & 15;
+    double v = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < CW; ++cc)
+#pragma unroll
+      for (int oo = 0; oo < 16; ++oo)
+        if (cc == c && oo == o) v = acc[cc][oo];
+    if (o < out && b0 + c < B) Hout[o + (int64_t)out * (b0 + c)] = conv_act(v + bias[o], act);
+  }
+}
+// true when the narrow kernel is the better choice: few MFMA workgroups and a long k chain
+bool dense_narrow_applies(int out, int in, int64_t B, int num_cu) { return out <= 16 && in >= 256 && (B + 127) / 128 < 2 * (int64_t)num_cu; }
+void launch_dense_narrow(hipStream_t st, const double* W, const double* bias, const double* Hin, double* Hout, int out, int in, int64_t B,
+                         int act) {
+  constexpr int CW = 2;
+  const int64_t blocks = (B + 4 * CW - 1) / (4 * CW);
+  hipLaunchKernelGGL(dense_narrow_kernel<CW>, dim3((unsigned)blocks), dim3(256), 0, st, W, bias, Hin, Hout, out, in, B, act);
+}
+
 }  // namespace si

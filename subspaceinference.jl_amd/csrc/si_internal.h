@@ -322,6 +322,9 @@ void launch_maxpool_bwd(hipStream_t st, const double* In, const double* Out, con
                         int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B);
 void launch_mul_dact(hipStream_t st, const double* G, const double* H, int64_t n, int act, double* D);
 size_t dact_rowsum_ws_elems(int max_rows);
+bool dense_narrow_applies(int out, int in, int64_t B, int num_cu);
+void launch_dense_narrow(hipStream_t st, const double* W, const double* bias, const double* Hin, double* Hout, int out, int in, int64_t B,
+                         int act);
 void launch_maxpool_bwd_dact_rowsum(hipStream_t st, const double* In, const double* Out, const double* Gout, double* D, int Cp, int Wi,
                                     int Hi, int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B, int act, double* part, int nout,
                                     double* db);
