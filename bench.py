@@ -257,8 +257,17 @@ class Rank:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.args = args
+        self.backend = None
+        # rehearsal knob: N ranks over gloo on however many GPUs are visible (ranks share devices) -- exercises the whole
+        # N-rank flow of this file and of dist.py's host-staged collectives on a 1-GPU box; the timings mean nothing
+        self.share_gpu = os.environ.get("SI_BENCH_SHARE_GPU") == "1"
+
+    def cdev(self, device):
+        """device of the small tensors handed to the collective backend"""
+        return "cpu" if self.backend == "gloo" else device
 
     def init(self, backend):
+        self.backend = backend
         if self.world > 1 or os.environ.get("SI_BENCH_FORCE_DIST") == "1":  # the env knob rehearses RCCL on one GPU
             import torch
             import torch.distributed as dist
@@ -275,7 +284,7 @@ class Rank:
         if self.dist is None:
             return 1
         import torch
-        t = torch.ones(1, dtype=torch.int64, device=device)
+        t = torch.ones(1, dtype=torch.int64, device=self.cdev(device))
         self.dist.all_reduce(t)
         return int(t.item())
 
@@ -283,7 +292,7 @@ class Rank:
         if self.dist is None:
             return v
         import torch
-        t = torch.tensor([v], device=device, dtype=torch.float64)
+        t = torch.tensor([v], device=self.cdev(device), dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -291,7 +300,7 @@ class Rank:
         if self.dist is None:
             return [v]
         import torch
-        t = torch.tensor([v], device=device, dtype=torch.float64)
+        t = torch.tensor([v], device=self.cdev(device), dtype=torch.float64)
         outs = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(outs, t)
         return [float(o.item()) for o in outs]
@@ -303,6 +312,8 @@ class Rank:
 
 
 def emit(real_stdout, out):
+    if os.environ.get("SI_BENCH_SHARE_GPU") == "1":
+        out["rehearsal"] = "SI_BENCH_SHARE_GPU=1: the ranks share the visible GPU(s) over gloo -- flow check, NOT a measurement"
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
@@ -689,10 +700,13 @@ def main(argv=None):
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    if rk.share_gpu:
+        rk.local_rank %= torch.cuda.device_count()
+        log("bench.py: SI_BENCH_SHARE_GPU=1 -- rank %d uses GPU %d over gloo (rehearsal: timings are not a result)" % (rk.rank, rk.local_rank))
     if rk.local_rank >= torch.cuda.device_count():
         raise SystemExit("bench.py: --gpus %d exceeds the %d visible GPUs" % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(rk.local_rank)
-    rk.init("nccl")
+    rk.init("gloo" if rk.share_gpu else "nccl")
     {"chains": run_chains, "construct-sharded": run_construct_sharded, "data-sharded": run_data_sharded}[args.mode](args, rk, real_stdout)
 
 
