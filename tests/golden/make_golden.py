@@ -16,6 +16,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import subspace_oracle as so  # noqa: E402
 
 TOY_DIMS, TOY_ACTS = [10, 20, 20, 2], [0, 0, 0]  # README.md:62 Chain(Dense(10,20),Dense(20,20),Dense(20,2))
+CNN_WHC = (6, 6, 2)
+CNN_SPEC = [("conv", (3, 3), 4, so.ACT_RELU, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("conv", (2, 2), 3, so.ACT_TANH, (2, 2)),
+            ("flatten",), ("dense", 3, so.ACT_IDENTITY)]
 
 
 def glorot(rng, dims):
@@ -55,6 +58,24 @@ def main():
     np.savez_compressed(os.path.join(HERE, "toy_density_rwmh.npz"), X=x, Y=y, W_swa=w_swa, P=p, Z=zs, lp=lps,
                         Yhat0=yhat0, Z_chain=z_chain, lp_chain=lp_chain, W_chain=w_chain, nacc=np.array(nacc),
                         seed=np.array(1234), sigma_z=np.array(1.0), sigma_m=np.array(1.0))
+    # ---- a small Conv chain (Flux 0.11.2 / NNlib 0.7.23 semantics as restated in the oracle): log-density,
+    # forward, gradient with respect to z and an RWMH chain.  conv 3x3 pad 1 (relu) -> MaxPool 2 -> conv 2x2 stride 2 (tanh)
+    # -> flatten -> Dense 3
+    spec = CNN_SPEC
+    ctab, cn = so.conv_table(spec, CNN_WHC)
+    rng = np.random.default_rng(11)
+    cw = 0.3 * rng.standard_normal(cn)
+    cp = np.asfortranarray(0.1 * rng.standard_normal((cn, 4)))
+    cx = rng.standard_normal((CNN_WHC[0] * CNN_WHC[1] * CNN_WHC[2], 9))
+    cy = rng.standard_normal((3, 9))
+    czs = np.asfortranarray(rng.standard_normal((4, 5)))
+    clps = np.array([so.logdensity(ctab, cw, cp, cx, cy, 0.7, czs[:, j]) for j in range(5)])
+    cyhat0 = so.forward(ctab, so.reconstruct(cw, cp, czs[:, 0]), cx)
+    _, cgrad, _ = so.logdensity_grad(ctab, cw, cp, cx, cy, 0.7, czs[:, 1])
+    cz_chain, clp_chain, _, cnacc = so.sub_inference(ctab, cx, cy, cw, cp, 0.05, 0.7, 12, seed=77, chain=0)
+    np.savez_compressed(os.path.join(HERE, "cnn_density_rwmh.npz"), X=cx, Y=cy, W_swa=cw, P=cp, Z=czs, lp=clps, Yhat0=cyhat0,
+                        grad1=cgrad, Z_chain=cz_chain, lp_chain=clp_chain, nacc=np.array(cnacc), seed=np.array(77),
+                        sigma_z=np.array(0.05), sigma_m=np.array(0.7))
     print("wrote golden fixtures to", HERE)
 
 

@@ -36,6 +36,23 @@ CASES = [
 ]
 
 
+def test_golden_cnn_fixture(gpu_ctx):
+    """the committed CNN vectors (tests/golden/cnn_density_rwmh.npz, generated from the oracle by make_golden.py): log-density
+    rtol 1e-11, forward rtol 1e-10, gradient rtol 1e-8, the RWMH chain on the shared Philox stream rtol 1e-10."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "cnn_density_rwmh.npz"))
+    spec = [("conv", (3, 3), 4, R, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("conv", (2, 2), 3, T, (2, 2)), ("flatten",), ("dense", 3, I)]
+    table, n = so.conv_table(spec, (6, 6, 2))
+    x, y = np.asfortranarray(d["X"]), np.asfortranarray(d["Y"])
+    gpu_ctx.infer_setup(table, n, 4, d["W_swa"], np.asfortranarray(d["P"]), x, y, 0.7)
+    assert np.allclose(gpu_ctx.logdensity(np.asfortranarray(d["Z"])), d["lp"], rtol=1e-11)
+    assert np.allclose(gpu_ctx.forward(np.ascontiguousarray(d["Z"][:, 0])), d["Yhat0"], rtol=1e-10, atol=1e-12)
+    lp1, g1 = gpu_ctx.logdensity_grad(np.ascontiguousarray(d["Z"][:, 1]))
+    assert np.isclose(lp1, d["lp"][1], rtol=1e-11) and np.allclose(g1, d["grad1"], rtol=1e-8)
+    z, lp, acc = gpu_ctx.sample_rwmh(12, 0.05, seed=77)
+    assert np.allclose(z[:, :, 0], d["Z_chain"], rtol=1e-10, atol=1e-13) and np.allclose(lp[:, 0], d["lp_chain"], rtol=1e-10)
+
+
 def _problem(whc, spec, b, m, seed):
     rng = np.random.default_rng(seed)
     table, n = so.conv_table(spec, whc)

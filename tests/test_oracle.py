@@ -134,6 +134,24 @@ def test_golden_vectors_match_oracle():
     assert nacc == int(d["nacc"])
 
 
+GOLD_CNN_WHC = (6, 6, 2)   # tests/golden/make_golden.py CNN_WHC / CNN_SPEC
+GOLD_CNN_SPEC = [("conv", (3, 3), 4, so.ACT_RELU, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("conv", (2, 2), 3, so.ACT_TANH, (2, 2)),
+                 ("flatten",), ("dense", 3, so.ACT_IDENTITY)]
+
+
+def test_golden_cnn_vectors_match_oracle():
+    d = np.load(os.path.join(GOLD, "cnn_density_rwmh.npz"))
+    table, n = so.conv_table(GOLD_CNN_SPEC, GOLD_CNN_WHC)
+    assert n == d["W_swa"].shape[0]
+    lps = [so.logdensity(table, d["W_swa"], d["P"], d["X"], d["Y"], 0.7, d["Z"][:, j]) for j in range(5)]
+    assert np.allclose(lps, d["lp"], rtol=1e-12)
+    assert np.allclose(so.forward(table, so.reconstruct(d["W_swa"], d["P"], d["Z"][:, 0]), d["X"]), d["Yhat0"], rtol=1e-12, atol=1e-14)
+    _, gz, _ = so.logdensity_grad(table, d["W_swa"], d["P"], d["X"], d["Y"], 0.7, d["Z"][:, 1])
+    assert np.allclose(gz, d["grad1"], rtol=1e-11)
+    z, lp, _, nacc = so.sub_inference(table, d["X"], d["Y"], d["W_swa"], d["P"], 0.05, 0.7, 12, seed=77)
+    assert np.allclose(z, d["Z_chain"], rtol=1e-12) and np.allclose(lp, d["lp_chain"], rtol=1e-12) and nacc == int(d["nacc"])
+
+
 def test_c_port_equals_numpy_port():
     """oracle/subspace_oracle_c.c (the compiled CPU-baseline leg of bench.py) against the NumPy restatement: forward and
     log-density on ragged shapes (row / column edges of the 16x12 and 8x6 micro-kernels, out = 1 heads, every activation)."""
