@@ -41,7 +41,11 @@ enum {
 };
 
 enum { SI_F32 = 0, SI_F64 = 1 };                                  /* dtype of a weight snapshot */
-enum { SI_ACT_IDENTITY = 0, SI_ACT_RELU = 1, SI_ACT_TANH = 2, SI_ACT_SIGMOID = 3 };
+/* Flux 0.11.2 / NNlib 0.7.23 definitions [upstream]: leakyrelu(x) = max(0.01 x, x); elu(x) = x >= 0 ? x : exp(x) - 1;
+ * softplus(x) = log(1 + exp(x)); selu(x) = 1.0507009873554805 * (x > 0 ? x : 1.6732632423543772 * (exp(x) - 1)).
+ * (gelu / swish are not monotone: their derivative cannot be rebuilt from the stored output, so they are not offered.) */
+enum { SI_ACT_IDENTITY = 0, SI_ACT_RELU = 1, SI_ACT_TANH = 2, SI_ACT_SIGMOID = 3, SI_ACT_LEAKYRELU = 4, SI_ACT_ELU = 5,
+       SI_ACT_SOFTPLUS = 6, SI_ACT_SELU = 7, SI_ACT_COUNT = 8 };
 enum { SI_LAYER_DENSE = 0, SI_LAYER_CONV = 1, SI_LAYER_MAXPOOL = 2, SI_LAYER_FLATTEN = 3 };
 
 /* One layer of a Flux Chain.  Layout contract of the whole path inside the flat weight vector (src/libs.jl:19-22

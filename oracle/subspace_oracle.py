@@ -26,6 +26,11 @@ import numpy as np
 from . import philox
 
 ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+# [upstream Flux 0.11.2 / NNlib 0.7.23 src/activation.jl]: leakyrelu(x, a = 0.01) = max(a x, x); elu(x, alpha = 1) =
+# ifelse(x >= 0, x, alpha (exp(x) - 1)); softplus(x) = ifelse(x > 0, x + log1p(exp(-x)), log1p(exp(x)));
+# selu(x) = lambda ifelse(x > 0, x, alpha (exp(x) - 1))   -- `exp(x) - 1` as written there, not expm1
+ACT_LEAKYRELU, ACT_ELU, ACT_SOFTPLUS, ACT_SELU = 4, 5, 6, 7
+SELU_LAMBDA, SELU_ALPHA = 1.0507009873554805, 1.6732632423543772
 
 
 # --------------------------------------------------------------------------- layout
@@ -105,6 +110,14 @@ def _act(a, kind):
         return np.tanh(a)
     if kind == ACT_SIGMOID:
         return 1.0 / (1.0 + np.exp(-a))
+    if kind == ACT_LEAKYRELU:
+        return np.maximum(0.01 * a, a)
+    if kind == ACT_ELU:
+        return np.where(a >= 0.0, a, (np.exp(np.minimum(a, 0.0)) - 1.0))
+    if kind == ACT_SOFTPLUS:
+        return np.maximum(a, 0.0) + np.log1p(np.exp(-np.abs(a)))
+    if kind == ACT_SELU:
+        return SELU_LAMBDA * np.where(a > 0.0, a, SELU_ALPHA * (np.exp(np.minimum(a, 0.0)) - 1.0))
     raise ValueError(kind)
 
 
@@ -252,6 +265,14 @@ def _dact(h, kind):
         return 1.0 - h * h
     if kind == ACT_SIGMOID:
         return h * (1.0 - h)
+    if kind == ACT_LEAKYRELU:
+        return np.where(h > 0.0, 1.0, 0.01)
+    if kind == ACT_ELU:
+        return np.where(h >= 0.0, 1.0, h + 1.0)
+    if kind == ACT_SOFTPLUS:
+        return -np.expm1(-h)
+    if kind == ACT_SELU:
+        return np.where(h > 0.0, SELU_LAMBDA, h + SELU_LAMBDA * SELU_ALPHA)
     raise ValueError(kind)
 
 

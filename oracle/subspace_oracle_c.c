@@ -23,7 +23,7 @@
 #include <string.h>
 
 typedef struct {
-  int32_t in, out, act; /* act: 0 identity, 1 relu, 2 tanh, 3 sigmoid (oracle/subspace_oracle.py ACT_*) */
+  int32_t in, out, act; /* act: 0 identity, 1 relu, 2 tanh, 3 sigmoid, 4 leakyrelu, 5 elu, 6 softplus, 7 selu (oracle/subspace_oracle.py ACT_*) */
   int64_t w_off, b_off;
 } so_layer;
 
@@ -32,6 +32,10 @@ static inline double act_apply(double a, int act) {
     case 1: return a > 0.0 ? a : 0.0;
     case 2: return tanh(a);
     case 3: return 1.0 / (1.0 + exp(-a));
+    case 4: return a > 0.01 * a ? a : 0.01 * a;
+    case 5: return a >= 0.0 ? a : exp(a) - 1.0;   /* NNlib: alpha * (exp(x) - one(x)) */
+    case 6: return a > 0.0 ? a + log1p(exp(-a)) : log1p(exp(a));
+    case 7: return 1.0507009873554805 * (a > 0.0 ? a : 1.6732632423543772 * (exp(a) - 1.0));
     default: return a;
   }
 }

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(HERE, "libsubspace_hip.so")
 SI_OK, SI_ERR_INVALID, SI_ERR_STATE, SI_ERR_HIP, SI_ERR_NOMEM, SI_ERR_BOUNDS, SI_ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 SI_F32, SI_F64 = 0, 1
 ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+ACT_LEAKYRELU, ACT_ELU, ACT_SOFTPLUS, ACT_SELU = 4, 5, 6, 7
 K_NAMES = ["push", "gram", "gram_reduce", "project", "reconstruct", "dense", "sse", "rwmh", "dense_main", "eig_host", "backward",
            "conv", "conv_aux"]
 LAYER_DENSE, LAYER_CONV, LAYER_MAXPOOL, LAYER_FLATTEN = 0, 1, 2, 3

@@ -836,7 +836,8 @@ static int32_t infer_setup_common(si_ctx* ctx, const si_layer* layers, int32_t L
   ctx->main_layer = main_layer;
   // fused tail: a narrow last layer (regression heads: out = 1) is folded into the epilogue of the layer before it
   ctx->plan = plan;
-  ctx->fuse_tail = !plan.has_conv && (L >= 2) && layers[L - 1].out <= SI_FUSE_MAX_OUT;
+  ctx->fuse_tail = !plan.has_conv && (L >= 2) && layers[L - 1].out <= SI_FUSE_MAX_OUT &&
+                   layers[L - 1].act < SI_ACT_LEAKYRELU && layers[L - 2].act < SI_ACT_LEAKYRELU;   // (kernels_gemm.h)
   ctx->fuse_slots = ctx->fuse_tail ? dense_fused_slots(layers[L - 2].out) : 0;
   int64_t maxstored = 1;
   for (int l = 0; l < (ctx->fuse_tail ? L - 2 : L); ++l) maxstored = std::max<int64_t>(maxstored, plan.L[(size_t)l].out_elems);

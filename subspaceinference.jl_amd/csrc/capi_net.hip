@@ -33,7 +33,7 @@ int32_t net_plan(Ctx* c, const char* who, const si_layer* layers, int L, int64_t
     if (ly.kind == SI_LAYER_DENSE) {
       // a Dense layer on image-shaped activations without a flatten in between fails in Flux too (DimensionMismatch)
       if (spatial) return bad("DimensionMismatch: Dense layer applied to (W, H, C, N) activations (flatten missing)");
-      if (ly.act < 0 || ly.act > SI_ACT_SIGMOID) return bad("unknown activation");
+      if (ly.act < 0 || ly.act >= SI_ACT_COUNT) return bad("unknown activation");
       if (ly.w_off < 0 || ly.b_off < 0 || ly.w_off + (int64_t)ly.in * ly.out > N || ly.b_off + ly.out > N)
         return bad("layer offsets outside the flat weight vector");
       q.in_elems = ly.in;
@@ -80,7 +80,7 @@ int32_t net_plan(Ctx* c, const char* who, const si_layer* layers, int L, int64_t
           q.Wo = (W - ly.kw) / ly.sw + 1;
           q.Ho = (H - ly.kh) / ly.sh + 1;
         } else {
-          if (ly.act < 0 || ly.act > SI_ACT_SIGMOID) return bad("unknown activation");
+          if (ly.act < 0 || ly.act >= SI_ACT_COUNT) return bad("unknown activation");
           if (ly.cout <= 0 || ly.pw < 0 || ly.ph < 0 || ly.dw <= 0 || ly.dh <= 0) return bad("Conv: bad cout / pad / dilation");
           const int64_t nw = (int64_t)ly.kw * ly.kh * C * ly.cout;
           if (ly.w_off < 0 || ly.b_off < 0 || ly.w_off + nw > N || ly.b_off + ly.cout > N)

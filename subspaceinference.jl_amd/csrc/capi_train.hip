@@ -113,7 +113,8 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
       maxpart = std::max(maxpart, (size_t)ns * ly.out * ly.in);
     }
   }
-  const bool fuse_tail = !plan.has_conv && (L >= 2) && layers[L - 1].out <= SI_FUSE_MAX_OUT;
+  const bool fuse_tail = !plan.has_conv && (L >= 2) && layers[L - 1].out <= SI_FUSE_MAX_OUT &&
+                         layers[L - 1].act < SI_ACT_LEAKYRELU && layers[L - 2].act < SI_ACT_LEAKYRELU;
   if (fuse_tail) maxpart = std::max(maxpart, tail_bwd_part_elems(layers[L - 1].out, layers[L - 1].in));
   SI_HIP(ctx, hipSetDevice(ctx->device));
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -33,7 +33,7 @@ __device__ __forceinline__ double dact_from_output(double h, int act) {
     case SI_ACT_RELU: return h > 0.0 ? 1.0 : 0.0;       // relu'(z) = [z > 0] = [relu(z) > 0]
     case SI_ACT_TANH: return 1.0 - h * h;
     case SI_ACT_SIGMOID: return h * (1.0 - h);
-    default: return 1.0;
+    default: return 1.0;   // (the later activations never reach the GEMM epilogue: launch_backward_data)
   }
 }
 
@@ -150,6 +150,11 @@ static int pick_bm_bwd(int32_t rows) {
 // Delta_prev[in x B] = (W' * Delta) .* act_prev'(Hprev);  W is out x in (column-major) inside the flat vector
 void launch_backward_data(hipStream_t st, const double* W, const double* Delta, const double* Hprev, double* DeltaPrev,
                           int32_t out, int32_t in, int64_t B, int32_t act_prev) {
+  if (act_is_extra(act_prev)) {   // W' Delta by the GEMM, the act' factor of a later activation by one elementwise pass
+    launch_backward_data(st, W, Delta, Hprev, DeltaPrev, out, in, B, SI_ACT_IDENTITY);
+    launch_mul_dact(st, DeltaPrev, Hprev, (int64_t)in * B, act_prev, DeltaPrev);
+    return;
+  }
   // A(m = in idx, k = out idx) = W[k + out*m]: k-fast;  B(k, n = b) = Delta[k + out*n]: k-fast
   const int64_t ks = ((int64_t)out + 15) / 16 * 16;
   switch (pick_bm_bwd(in)) {
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256) void delta_out_kernel(const double* __restrict
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < d; e += stride) {
     const double yh = Yhat[e];
-    delta[e] = scale * (Y[e] - yh) * dact_from_output(yh, act);
+    delta[e] = scale * (Y[e] - yh) * dact_full(yh, act);
   }
 }
 void launch_delta_out(hipStream_t st, const double* Y, const double* Yhat, int64_t d, double scale, int act, double* delta) {

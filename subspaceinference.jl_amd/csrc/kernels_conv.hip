@@ -30,7 +30,7 @@ __device__ __forceinline__ double conv_act(double v, int act) {
     case SI_ACT_RELU: return v > 0.0 ? v : 0.0;
     case SI_ACT_TANH: return tanh(v);
     case SI_ACT_SIGMOID: return 1.0 / (1.0 + exp(-v));
-    default: return v;
+    default: return v;   // (GEMM epilogues only see the first four: launch_conv_forward finishes the later ones elementwise)
   }
 }
 __device__ __forceinline__ double conv_dact(double h, int act) {
@@ -420,8 +420,24 @@ static void launch_conv_gemm(hipStream_t st, const double* Wp, int Mp, const dou
 #undef SI_CONV_CASE
 }
 
+// H[e] = act(H[e]) for the activations the GEMM epilogues do not carry (kernels_gemm.h)
+__global__ __launch_bounds__(256) void act_inplace_kernel(double* __restrict__ H, int64_t n, int act) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) H[e] = act_full(H[e], act);
+}
+void launch_act_inplace(hipStream_t st, double* H, int64_t n, int act) {
+  int64_t b = (n + 255) / 256;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(act_inplace_kernel, dim3((unsigned)(b < 1 ? 1 : b)), dim3(256), 0, st, H, n, act);
+}
+
 void launch_conv_forward(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, const ConvGeom& g,
                          int COUTp, int Kp, int64_t npos, int act) {
+  if (act_is_extra(act)) {   // bias in the GEMM epilogue, the later activation elementwise (pad channels: act(0), as in the fused case)
+    launch_conv_gemm<false, true>(st, Wp, COUTp, In, Out, bp, g, npos, Kp, SI_ACT_IDENTITY);
+    launch_act_inplace(st, Out, (int64_t)COUTp * npos, act);
+    return;
+  }
   launch_conv_gemm<false, true>(st, Wp, COUTp, In, Out, bp, g, npos, Kp, act);
 }
 
@@ -443,6 +459,11 @@ static void launch_conv_pool_bm(hipStream_t st, const double* Wp, int Mp, const 
 // conv + bias + act + MaxPool((2, 2), stride 2) -> pooled CWHN tensor; needs even Wo and Ho (the caller checks)
 void launch_conv_forward_pool2(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, const ConvGeom& g,
                                int COUTp, int Kp, int64_t npos, int act) {
+  if (act_is_extra(act)) {   // increasing activations commute with the maximum: pool the pre-activations, finish on the pooled tensor
+    launch_conv_forward_pool2(st, Wp, bp, In, Out, g, COUTp, Kp, npos, SI_ACT_IDENTITY);
+    launch_act_inplace(st, Out, (int64_t)COUTp * (npos / 4), act);
+    return;
+  }
   const bool cellu = g.Cp % 16 == 0;
   const int bm = conv_pick_bm(COUTp);
 #define SI_POOL_CASE(BM)                                                              \
@@ -689,7 +710,7 @@ void launch_maxpool_bwd(hipStream_t st, const double* In, const double* Out, con
 __global__ __launch_bounds__(256) void mul_dact_kernel(const double* __restrict__ G, const double* __restrict__ H, int64_t n, int act,
                                                        double* __restrict__ D) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) D[e] = G[e] * conv_dact(H[e], act);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) D[e] = G[e] * dact_full(H[e], act);
 }
 void launch_mul_dact(hipStream_t st, const double* G, const double* H, int64_t n, int act, double* D) {
   hipLaunchKernelGGL(mul_dact_kernel, dim3(idx_grid(n)), dim3(256), 0, st, G, H, n, act, D);
@@ -755,7 +776,7 @@ __global__ __launch_bounds__(256) void dact_rowsum_kernel(const double* __restri
       } else {
         g = G[off];
       }
-      const double d = g * conv_dact(x, act);
+      const double d = g * dact_full(x, act);
       D[off] = d;
       s += d;
     }
@@ -861,7 +882,7 @@ __global__ __launch_bounds__(256) void dense_narrow_kernel(const double* __restr
 #pragma unroll
       for (int oo = 0; oo < 16; ++oo)
         if (cc == c && oo == o) v = acc[cc][oo];
-    if (o < out && b0 + c < B) Hout[o + (int64_t)out * (b0 + c)] = conv_act(v + bias[o], act);
+    if (o < out && b0 + c < B) Hout[o + (int64_t)out * (b0 + c)] = act_full(v + bias[o], act);
   }
 }
 // true when the narrow kernel is the better choice: few MFMA workgroups and a long k chain

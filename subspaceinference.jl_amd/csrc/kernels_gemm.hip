@@ -462,6 +462,11 @@ static int pick_bm(int32_t out) {
 
 void launch_dense_f64(hipStream_t st, const double* W, const double* bias, const double* Hin,
                       double* Hout, int32_t out, int32_t in, int64_t B, int32_t act, const ChainBatch& cb) {
+  if (act_is_extra(act)) {   // leakyrelu / elu / softplus / selu: identity in the GEMM, one elementwise pass behind it
+    launch_dense_f64(st, W, bias, Hin, Hout, out, in, B, SI_ACT_IDENTITY, cb);
+    for (int s = 0; s < cb.n; ++s) launch_act_inplace(st, Hout + (int64_t)s * cb.hout, (int64_t)out * B, act);
+    return;
+  }
   FuseArgs fa;
   fa.cb = cb;
   switch (pick_bm(out)) {
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(256) void tail_sse_kernel(const double* __restrict_
     if (act_last == SI_ACT_RELU)
       v = v > 0.0 ? v : 0.0;
     else if (act_last != SI_ACT_IDENTITY)
-      v = apply_act(v, act_last);
+      v = act_full(v, act_last);
     if (yhat) yhat[idx] = v;
     const double r = Y[idx] - v;
     accv += r * r;

@@ -322,6 +322,7 @@ void launch_maxpool_bwd(hipStream_t st, const double* In, const double* Out, con
                         int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B);
 void launch_mul_dact(hipStream_t st, const double* G, const double* H, int64_t n, int act, double* D);
 size_t dact_rowsum_ws_elems(int max_rows);
+void launch_act_inplace(hipStream_t st, double* H, int64_t n, int act);
 bool dense_narrow_applies(int out, int in, int64_t B, int num_cu);
 void launch_dense_narrow(hipStream_t st, const double* W, const double* bias, const double* Hin, double* Hout, int out, int in, int64_t B,
                          int act);

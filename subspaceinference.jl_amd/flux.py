@@ -17,10 +17,14 @@ Semantics restated from Flux 0.11.2 (Manifest.toml:491; not vendored):
 """
 import numpy as np
 
-from ._capi import ACT_IDENTITY, ACT_RELU, ACT_SIGMOID, ACT_TANH, SubspaceError
+from ._capi import (ACT_ELU, ACT_IDENTITY, ACT_LEAKYRELU, ACT_RELU, ACT_SELU, ACT_SIGMOID, ACT_SOFTPLUS, ACT_TANH,
+                    SubspaceError)
 
 identity, relu, tanh, sigmoid = ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID
-_ACT_NAMES = {"identity": identity, "relu": relu, "tanh": tanh, "sigmoid": sigmoid, "σ": sigmoid}
+leakyrelu, elu, softplus, selu = ACT_LEAKYRELU, ACT_ELU, ACT_SOFTPLUS, ACT_SELU   # Flux 0.11.2 defaults: a = 0.01, alpha = 1
+_SELU_L, _SELU_A = 1.0507009873554805, 1.6732632423543772
+_ACT_NAMES = {"identity": identity, "relu": relu, "tanh": tanh, "sigmoid": sigmoid, "σ": sigmoid, "leakyrelu": leakyrelu,
+              "elu": elu, "softplus": softplus, "selu": selu}
 
 
 def _act_id(a):
@@ -36,7 +40,17 @@ def _act_fwd(a, kind):
         return np.maximum(a, 0)
     if kind == tanh:
         return np.tanh(a)
-    return 1.0 / (1.0 + np.exp(-a))
+    if kind == sigmoid:
+        return 1.0 / (1.0 + np.exp(-a))
+    if kind == leakyrelu:
+        return np.maximum(0.01 * a, a)
+    if kind == elu:
+        return np.where(a >= 0, a, (np.exp(np.minimum(a, 0)) - 1.0))
+    if kind == softplus:
+        return np.maximum(a, 0) + np.log1p(np.exp(-np.abs(a)))
+    if kind == selu:
+        return _SELU_L * np.where(a > 0, a, _SELU_A * (np.exp(np.minimum(a, 0)) - 1.0))
+    raise SubspaceError("Error: activation %r is not available" % (kind,))
 
 
 def _act_bwd(pre, post, kind):
@@ -46,7 +60,17 @@ def _act_bwd(pre, post, kind):
         return (pre > 0).astype(post.dtype)
     if kind == tanh:
         return 1.0 - post * post
-    return post * (1.0 - post)
+    if kind == sigmoid:
+        return post * (1.0 - post)
+    if kind == leakyrelu:
+        return np.where(pre > 0, 1.0, 0.01).astype(post.dtype)
+    if kind == elu:
+        return np.where(pre >= 0, 1.0, post + 1.0).astype(post.dtype)
+    if kind == softplus:
+        return (1.0 / (1.0 + np.exp(-pre))).astype(post.dtype)
+    if kind == selu:
+        return np.where(pre > 0, _SELU_L, post + _SELU_L * _SELU_A).astype(post.dtype)
+    raise SubspaceError("Error: activation %r is not available" % (kind,))
 
 
 class Dense:

@@ -82,7 +82,9 @@ end
 extract_params(ps) = mapreduce(p -> vec(p), vcat, ps)
 
 act_id(f) = f === identity ? Int32(0) : f === relu ? Int32(1) : f === tanh ? Int32(2) :
-            (f === σ || f === sigmoid) ? Int32(3) : throw("Error: activation $f is not available on the device")
+            (f === σ || f === sigmoid) ? Int32(3) : f === leakyrelu ? Int32(4) : f === elu ? Int32(5) :
+            f === softplus ? Int32(6) : f === selu ? Int32(7) :
+            throw("Error: activation $f is not available on the device")   # (gelu / swish: not invertible from the output)
 
 conv_out(wi, k, s, p, d) = div(wi + 2p - d * (k - 1) - 1, s) + 1
 

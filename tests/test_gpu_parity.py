@@ -959,6 +959,49 @@ def test_random_shape_sweep_forward_density_gradient(gpu_ctx):
         assert np.allclose(g, gr, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(gr).max())), tag
 
 
+def test_extra_activations_forward_density_gradient_training(si, gpu_ctx):
+    """leakyrelu / elu / softplus / selu (Flux 0.11.2 definitions, derivative rebuilt from the stored output): forward,
+    log-density, gradient and the training gradient on Dense chains that mix them with the original four, fused narrow
+    heads (width <= 4, activated) and generic heads."""
+    from subspaceinference_jl_amd import flux
+    rng = np.random.default_rng(4567)
+    for case in range(12):
+        nl = int(rng.integers(1, 4))
+        dims = [int(rng.integers(2, 30))] + [int(rng.choice([3, 16, 33, 64, 97, 130])) for _ in range(nl - 1)] + [int(rng.integers(1, 8))]
+        acts = [int(rng.integers(4, 8)) if rng.random() < 0.7 else int(rng.integers(0, 4)) for _ in range(nl)]
+        acts[int(rng.integers(0, nl))] = 4 + case % 4          # every new activation appears in three cases
+        b = int(rng.choice([3, 64, 129, 300]))
+        m = int(rng.integers(1, 6))
+        table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=300 + case)
+        gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=0.9)
+        zs = np.asfortranarray(0.5 * rng.standard_normal((m, 2)))
+        tag = "case %d dims %s acts %s B %d" % (case, dims, acts, b)
+        yref = so.forward(table, so.reconstruct(w_swa, p, zs[:, 0]), x)
+        assert np.allclose(gpu_ctx.forward(zs[:, 0]), yref, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(yref).max())), tag
+        lp_ref = np.array([so.logdensity(table, w_swa, p, x, y, 0.9, zs[:, j]) for j in range(2)])
+        assert np.allclose(gpu_ctx.logdensity(zs), lp_ref, rtol=1e-10), tag
+        lp, g = gpu_ctx.logdensity_grad(zs[:, 1])
+        lpr, gr, _ = so.logdensity_grad(table, w_swa, p, x, y, 0.9, zs[:, 1])
+        assert np.isclose(lp, lpr, rtol=1e-10), tag
+        assert np.allclose(g, gr, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(gr).max())), tag
+        # training gradient of the mse cost against the host stand-in (its own activation code, from the PRE-activation)
+        wr = np.random.default_rng(900 + case)
+        model = flux.Chain(*[flux.Dense(dims[i], dims[i + 1], acts[i], rng=wr) for i in range(nl)])
+        for l in model.layers:
+            l.b[...] = (0.1 * wr.standard_normal(l.b.shape)).astype(np.float32)
+        tb, tn = flux.layer_table(model)
+        gpu_ctx.train_setup(tb, tn, flux.extract_params(flux.params(model)), x, y, b, 0, 0.1)
+        ids = np.arange(b)
+        sse = gpu_ctx.train_grad(ids, b)
+        loss, gs = flux.mse.value_and_grad(model, x, y)
+        gref = np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1, order="F") for a in gs])
+        assert np.isclose(sse / (dims[-1] * b), loss, rtol=1e-10), tag
+        assert np.allclose(gpu_ctx.train_grad_get(), gref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(gref).max())), tag
+    with pytest.raises(si.SubspaceError):
+        gpu_ctx.infer_setup([(3, 2, 8, 0, 6)], 8, 1, np.zeros(8), np.zeros((8, 1), order="F"), np.zeros((3, 2), order="F"),
+                            np.zeros((2, 2), order="F"), 1.0)            # activation id 8 does not exist
+
+
 def test_random_shape_sweep_training_gradient(si, gpu_ctx):
     """si_train_grad (forward + reverse sweep of the mse cost, with the fused narrow-head path for heads of width <= 4 and
     the generic one above) against the host stand-in of Zygote's gradient on random Dense chains and batches."""

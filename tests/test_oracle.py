@@ -152,12 +152,29 @@ def test_golden_cnn_vectors_match_oracle():
     assert np.allclose(z, d["Z_chain"], rtol=1e-12) and np.allclose(lp, d["lp_chain"], rtol=1e-12) and nacc == int(d["nacc"])
 
 
+def test_later_activations_definitions_and_derivatives():
+    """leakyrelu / elu / softplus / selu as Flux 0.11.2 / NNlib 0.7.23 define them, and their derivative rebuilt from the
+    OUTPUT (what the reverse sweep does) against central differences of the definition."""
+    x = np.concatenate([np.linspace(-6.0, 6.0, 241), [-40.0, 40.0, 1e-9, -1e-9]])
+    x = x[x != 0.0]
+    lam, alpha = 1.0507009873554805, 1.6732632423543772
+    ref = {so.ACT_LEAKYRELU: np.maximum(0.01 * x, x), so.ACT_ELU: np.where(x >= 0, x, np.exp(x) - 1.0),
+           so.ACT_SOFTPLUS: np.logaddexp(0.0, x), so.ACT_SELU: lam * np.where(x > 0, x, alpha * (np.exp(x) - 1.0))}
+    for kind, r in ref.items():
+        h = so._act(x, kind)
+        assert np.allclose(h, r, rtol=1e-13, atol=1e-300)
+        eps = 1e-6 * np.maximum(1.0, np.abs(x))
+        keep = np.abs(x) > 2e-6                               # central differences must not straddle the kink at 0
+        fd = (so._act(x + eps, kind) - so._act(x - eps, kind)) / (2 * eps)
+        assert np.allclose(so._dact(h, kind)[keep], fd[keep], rtol=1e-6, atol=1e-9)
+
+
 def test_c_port_equals_numpy_port():
     """oracle/subspace_oracle_c.c (the compiled CPU-baseline leg of bench.py) against the NumPy restatement: forward and
     log-density on ragged shapes (row / column edges of the 16x12 and 8x6 micro-kernels, out = 1 heads, every activation)."""
     from oracle import c_port
     rng = np.random.default_rng(4)
-    for dims, acts, b in [([10, 20, 20, 2], [0, 0, 0], 100), ([7, 33, 50, 3], [1, 2, 3], 211), ([5, 17, 1], [2, 0], 13),
+    for dims, acts, b in [([10, 20, 20, 2], [0, 0, 0], 100), ([7, 33, 50, 3], [1, 2, 3], 211), ([5, 17, 1], [2, 0], 13), ([6, 19, 23, 30, 2], [4, 5, 6, 7], 57),
                           ([128, 96, 64, 1], [1, 1, 0], 1000)]:
         table, n = so.layer_table(dims, acts)
         w = 0.2 * rng.standard_normal(n)
