@@ -377,11 +377,14 @@ def run_chains(args, rk, real_stdout):
     ctx.synchronize()
     cst = ctx.stats()
     ctx.set_profiling(False)
-    barrier()
-    t0 = time.perf_counter()
-    construct()  # the wall-clock figure, without the event pairs
-    ctx.synchronize()
-    construct_ms = (time.perf_counter() - t0) * 1e3
+    construct_runs = []
+    for _ in range(3):   # the wall-clock figure, without the event pairs: median of three back-to-back constructions
+        barrier()
+        t0 = time.perf_counter()
+        construct()
+        ctx.synchronize()
+        construct_runs.append((time.perf_counter() - t0) * 1e3)
+    construct_ms = sorted(construct_runs)[1]
 
     # ---- sampling.  The timed region carries event pairs around the DOMINANT kernel only (roofline.achieved is its
     # live average launch duration); the per-class breakdown comes from a short untimed pass afterwards.
@@ -470,7 +473,7 @@ def run_chains(args, rk, real_stdout):
                                    "X 128x100000 Y 1x100000 fp64, M=20, K=100 fp32 snapshots, RWMH sigma_z=0.1 sigma_m=1",
                        "chains_per_gpu": 1, "mode": "chains",
                        "parallelism": "independent chains x%d (one per GPU), no data-path collective" % n_seen},
-            "construct_wall_ms": construct_ms,
+            "construct_wall_ms": construct_ms, "construct_wall_ms_runs": [round(t, 4) for t in construct_runs],
             "construct_device_ms": {k: round(cst[k]["ms"], 4) for k in ("push", "gram", "gram_reduce", "project")},
             "construct_host_eig_ms": round(cst["eig_host"]["ms"], 4),
             "construct_roofline": {"push": frac("push", "hbm"), "gram": frac("gram", "mfma"), "project": frac("project", "hbm")},
