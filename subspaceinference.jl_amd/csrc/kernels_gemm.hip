@@ -524,6 +524,7 @@ __global__ __launch_bounds__(256) void tail_sse_kernel(const double* __restrict_
     const int o = (int)(idx % out_last);
     const int64_t b = idx / out_last;
     double s = 0.0;
+#pragma unroll 4   // the loads of four slots in flight together (the additions keep their order: bit-identical)
     for (int sl = 0; sl < slots; ++sl) s += part[((int64_t)sl * out_last + o) * B + b];
     double v = s + bias_last[o];
     if (act_last == SI_ACT_RELU)

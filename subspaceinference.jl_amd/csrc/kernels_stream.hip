@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void sse_final_kernel(const double* __restrict
 }
 
 int sse_num_blocks(int64_t d, int num_cu) {
-  int64_t b = (d + 1023) / 1024;
+  int64_t b = (d + 255) / 256;   // one element per thread up to 4 blocks per CU (the tail of a step is latency-bound)
   if (b > (int64_t)num_cu * 4) b = (int64_t)num_cu * 4;
   if (b < 1) b = 1;
   return (int)b;
