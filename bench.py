@@ -249,7 +249,10 @@ def cpu_baseline(table, w_swa, p, x, y, z0, budget_s):
 
 
 class Rank:
-    """process-group plumbing of one rank (torch.distributed; backend nccl = RCCL on the GPU node)"""
+    """One rank.  Control plane: a torch.distributed `gloo` group (started by torchrun's env) that ships the 128-byte RCCL
+    id and brackets the timed regions with barriers.  Data plane: the RCCL communicator INSIDE the library
+    (si_comm_init_rank, attach()) -- every GPU collective of the hot path, the rank count and the max-over-ranks of the
+    timings go through it; torch never touches a device buffer of the library."""
 
     def __init__(self, args):
         self.rank = int(os.environ.get("RANK", "0"))
@@ -261,46 +264,56 @@ class Rank:
         # rehearsal knob: N ranks over gloo on however many GPUs are visible (ranks share devices) -- exercises the whole
         # N-rank flow of this file and of dist.py's host-staged collectives on a 1-GPU box; the timings mean nothing
         self.share_gpu = os.environ.get("SI_BENCH_SHARE_GPU") == "1"
+        self.ctx = None   # the si ctx whose in-library communicator carries the data plane (attach)
 
-    def cdev(self, device):
-        """device of the small tensors handed to the collective backend"""
-        return "cpu" if self.backend == "gloo" else device
-
-    def init(self, backend):
+    def init(self, backend="gloo"):
         self.backend = backend
-        if self.world > 1 or os.environ.get("SI_BENCH_FORCE_DIST") == "1":  # the env knob rehearses RCCL on one GPU
-            import torch
+        if self.world > 1 or os.environ.get("SI_BENCH_FORCE_DIST") == "1":  # the env knob rehearses the N-rank path on one GPU
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-            kw = {"device_id": torch.device("cuda", self.local_rank)} if backend == "nccl" else {}
-            dist.init_process_group(backend, **kw)
+            dist.init_process_group(backend)
             self.dist = dist
 
-    def count_ranks(self, device):
-        """ranks the collective backend actually saw: all-reduce of ones"""
+    def attach(self, ctx):
+        """join the in-library RCCL communicator (one rank per GPU); under SI_BENCH_SHARE_GPU the ranks share a device,
+        which RCCL refuses, so the rehearsal stays on the gloo test double of dist.py"""
+        if self.dist is not None and not self.share_gpu:
+            from subspaceinference_jl_amd import dist as sd
+            sd.comm_init(ctx)
+            self.ctx = ctx
+        return ctx
+
+    def count_ranks(self, device=None):
+        """ranks the collective backend actually saw: all-reduce of ones (RCCL inside the library when attached)"""
+        if self.ctx is not None:
+            return int(round(float(self.ctx.comm_allreduce_host([1.0], "sum")[0])))
         if self.dist is None:
             return 1
         import torch
-        t = torch.ones(1, dtype=torch.int64, device=self.cdev(device))
+        t = torch.ones(1, dtype=torch.int64)
         self.dist.all_reduce(t)
         return int(t.item())
 
-    def max_over_ranks(self, v, device):
+    def max_over_ranks(self, v, device=None):
+        if self.ctx is not None:
+            return float(self.ctx.comm_allreduce_host([v], "max")[0])
         if self.dist is None:
             return v
         import torch
-        t = torch.tensor([v], device=self.cdev(device), dtype=torch.float64)
+        t = torch.tensor([v], dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    def gather_floats(self, v, device):
+    def gather_floats(self, v, device=None):
+        if self.ctx is not None:
+            return [float(a) for a in self.ctx.comm_allgather_host([v])[:, 0]]
         if self.dist is None:
             return [v]
         import torch
-        t = torch.tensor([v], device=self.cdev(device), dtype=torch.float64)
+        t = torch.tensor([v], dtype=torch.float64)
         outs = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(outs, t)
         return [float(o.item()) for o in outs]
@@ -338,7 +351,8 @@ def run_chains(args, rk, real_stdout):
     import subspaceinference_jl_amd as si
     rank, world = rk.rank, rk.world
     dev = torch.device("cuda", rk.local_rank)
-    n_seen = rk.count_ranks(dev)
+    ctx = rk.attach(si.Context(rk.local_rank))
+    n_seen = rk.count_ranks()
     table, n_par = layer_table(DIMS, ACTS)
     assert n_par == 1047361
 
@@ -354,8 +368,6 @@ def run_chains(args, rk, real_stdout):
     snaps[:, :n_par] = (w0[None, :] + torch.cumsum(steps, dim=0)).to(torch.float32)  # K x N fp32, random walk
     del steps
     torch.cuda.synchronize()
-
-    ctx = si.Context(rk.local_rank)
 
     def barrier():
         ctx.synchronize()
@@ -511,7 +523,8 @@ def run_construct_sharded(args, rk, real_stdout):
     from subspaceinference_jl_amd import dist as sd
     rank, world = rk.rank, rk.world
     dev = torch.device("cuda", rk.local_rank)
-    n_seen = rk.count_ranks(dev)
+    ctx = rk.attach(si.Context(rk.local_rank))
+    n_seen = rk.count_ranks()
     cfg = CFG[args.config]
     n, k, m = cfg["n"], cfg["k"], cfg["m"]
     r0, r1 = sd.row_shard(n, rank, world)
@@ -524,9 +537,6 @@ def run_construct_sharded(args, rk, real_stdout):
         cur = cur + 0.002 * torch.randn(n_loc, generator=gen, device="cuda", dtype=torch.float32)
         snaps[j, :n_loc] = cur
     torch.cuda.synchronize()
-    ctx = si.Context(rk.local_rank)
-    if rk.dist is not None:
-        sd.bind_stream(ctx)
     ns = np.arange(1, k + 1, dtype=np.float64)
 
     def construct():
@@ -535,11 +545,10 @@ def run_construct_sharded(args, rk, real_stdout):
         return _finish()
 
     def _finish():
-        # K2 local -> ONE in-place RCCL all-reduce of the K x K Gram -> replicated H1 -> K3 local; results stay on device
+        # K2 local -> ONE in-place RCCL all-reduce of the K x K Gram inside the library (si_construct_allreduce_gram) ->
+        # replicated H1 -> K3 local; results stay on the device
         ctx.construct_gram()
-        if rk.dist is not None:
-            ptr, kk = ctx.construct_gram_ptr()
-            sd.allreduce_inplace(ctx, ptr, kk * kk)
+        sd._allreduce_gram(ctx)
         return ctx.construct_finish(m, want_swa=False, want_p=False)[2]
 
     def barrier():
@@ -604,7 +613,8 @@ def run_data_sharded(args, rk, real_stdout):
     from subspaceinference_jl_amd import dist as sd
     rank, world = rk.rank, rk.world
     dev = torch.device("cuda", rk.local_rank)
-    n_seen = rk.count_ranks(dev)
+    ctx = rk.attach(si.Context(rk.local_rank))
+    n_seen = rk.count_ranks()
     table, n = layer_table(DIMS5, ACTS5)
     b0, b1 = sd.col_shard(B5_TOTAL, rank, world)
     b_loc = b1 - b0
@@ -621,9 +631,6 @@ def run_data_sharded(args, rk, real_stdout):
     x_t, y_t = x_all[b0:b1].contiguous(), y_all[b0:b1].contiguous()
     del x_all, y_all
     torch.cuda.synchronize()
-    ctx = si.Context(rk.local_rank)
-    if rk.dist is not None:
-        sd.bind_stream(ctx)
     ctx.infer_setup_dev(table, n, M5, w_t.data_ptr(), p_t.data_ptr(), ld, x_t.data_ptr(), y_t.data_ptr(), DIMS5[0], 1,
                         b_loc, 1.0, borrow=True)
     d_total = B5_TOTAL
@@ -709,7 +716,7 @@ def main(argv=None):
     if rk.local_rank >= torch.cuda.device_count():
         raise SystemExit("bench.py: --gpus %d exceeds the %d visible GPUs" % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(rk.local_rank)
-    rk.init("gloo" if rk.share_gpu else "nccl")
+    rk.init("gloo")
     {"chains": run_chains, "construct-sharded": run_construct_sharded, "data-sharded": run_data_sharded}[args.mode](args, rk, real_stdout)
 
 

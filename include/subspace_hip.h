@@ -16,7 +16,8 @@
  *   - host pointers are caller-owned, contiguous, COLUMN-MAJOR (Julia layout); they are only read or
  *     written during the call and never retained.  "_dev" variants take device pointers instead.
  *   - device memory is owned by the opaque si_ctx and released by si_destroy.
- *   - one ctx drives ONE GPU (one process per GPU); a ctx is used by one host thread at a time.
+ *   - one ctx drives ONE GPU (one process per GPU); a ctx is used by one host thread at a time.  More than one GPU =
+ *     one process (and ctx) per GPU joined by an RCCL communicator: the si_comm_* section below.
  *   - there is NO CPU backend: si_create fails when no gfx950 device is usable.
  */
 #ifndef SUBSPACE_HIP_H
@@ -37,7 +38,8 @@ enum {
   SI_ERR_HIP = -3,      /* HIP runtime error, message has the hipError string   */
   SI_ERR_NOMEM = -4,    /* device or host allocation failed                     */
   SI_ERR_BOUNDS = -5,   /* M > rank(A): the reference's BoundsError at U[:,1:M] */
-  SI_ERR_NODEVICE = -6  /* no usable GPU                                        */
+  SI_ERR_NODEVICE = -6, /* no usable GPU                                        */
+  SI_ERR_COMM = -7      /* RCCL error / RCCL not loadable, message has the detail */
 };
 
 enum { SI_F32 = 0, SI_F64 = 1 };                                  /* dtype of a weight snapshot */
@@ -99,7 +101,7 @@ typedef struct {
   double bytes[SI_K_COUNT];     /* accumulated ALGORITHMIC HBM bytes per class                 */
 } si_stats;
 
-int32_t si_version(void); /* 200: si_layer carries the Conv / MaxPool geometry */
+int32_t si_version(void); /* 300: + the RCCL communicator (si_comm_*), streamed output map, pipelined host push */
 
 /* ---- context ------------------------------------------------------------------------------- */
 int32_t si_create(si_ctx** out, int32_t device_id);
@@ -171,6 +173,11 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out /* N */,
  * For device-to-device hand-over: an RCCL broadcast of (W_swa, P) to the other ranks' si_infer_setup_dev (independent
  * chains, cfg3), or checks that must not stage 26 GB of P through the host (cfg5).                                  */
 int32_t si_construct_result_ptr(si_ctx* ctx, double** W_swa_dev_out, double** P_dev_out, int64_t* ld_out, int32_t* M_out);
+/* Copy the results of the FINISHED construction the ctx holds to the host: its own (same values si_construct_finish
+ * returned), or one received from another rank (si_bcast_subspace / si_construct_allgather).  Any output may be NULL;
+ * N_out / M_out report the sizes (call once with NULL arrays to size them).                                         */
+int32_t si_construct_get_result(si_ctx* ctx, double* W_swa_out /* N */, double* P_out /* N x M */, double* s_out /* M */,
+                                int64_t* N_out, int32_t* M_out);
 /* read back deviation columns [k0, k0+nk) (N x nk col-major) -- parity tests of :51-52 */
 int32_t si_construct_get_A(si_ctx* ctx, int64_t k0, int64_t nk, double* A_out);
 
@@ -266,6 +273,59 @@ int32_t si_train_grad_ptr(si_ctx* ctx, double** grad_dev_out, int64_t* n_out);
 int32_t si_train_grad_get(si_ctx* ctx, double* g_out /* N */);
 int32_t si_train_grad_set(si_ctx* ctx, const double* g_in /* N */);
 int32_t si_train_apply(si_ctx* ctx);
+
+/* ---- R1: multi-GPU behind the C ABI ------------------------------------------------------------
+ * One process per GPU, one si_ctx per process, one RCCL communicator per ctx (RCCL over xGMI; bound with dlopen at the
+ * first si_comm_* call -- a host that already carries librccl.so.1, e.g. PyTorch, shares its copy).  The reference is
+ * single-process; what these collectives parallelise:  src/subspace_construction.jl:45-52,63 (row-sharded SWA /
+ * deviation / Gram / projection), src/space_inference.jl:94 (log-likelihood over column blocks of the data),
+ * src/subspace_construction.jl:39-43 (data-parallel training step), and independent chains (no per-step exchange).
+ * Every collective is issued on the ctx's stream, in place on buffers the library owns: no host staging and no
+ * synchronisation of its own.  All ranks must make the same calls in the same order (RCCL semantics).
+ *
+ * Start-up: rank 0 calls si_comm_unique_id and ships the 128 bytes to the other ranks by whatever the host has
+ * (Julia: Distributed.remotecall / a file; Python: a file or any process group); every rank then calls
+ * si_comm_init_rank.                                                                                               */
+#define SI_COMM_ID_BYTES 128
+enum { SI_COMM_SUM = 0, SI_COMM_MAX = 1 };
+int32_t si_comm_unique_id(uint8_t* id_out /* SI_COMM_ID_BYTES */);   /* needs no ctx; errors: si_last_error(NULL) */
+int32_t si_comm_init_rank(si_ctx* ctx, int32_t world, int32_t rank, const uint8_t* id /* SI_COMM_ID_BYTES */);
+int32_t si_comm_destroy(si_ctx* ctx);                                 /* also done by si_destroy */
+/* world = 0 when the ctx has no communicator; rccl_version = ncclGetVersion (0 when RCCL could not be loaded) */
+int32_t si_comm_info(si_ctx* ctx, int32_t* world_out, int32_t* rank_out, int32_t* rccl_version_out);
+/* small HOST values over the communicator (timings, losses, rank counts): n <= 4096, op = SI_COMM_SUM / SI_COMM_MAX;
+ * synchronous.  si_comm_barrier returns when every rank's stream has reached it.                                    */
+int32_t si_comm_allreduce_host(si_ctx* ctx, double* inout, int64_t n, int32_t op);
+int32_t si_comm_allgather_host(si_ctx* ctx, const double* send /* n */, int64_t n, double* recv /* n x world */);
+int32_t si_comm_barrier(si_ctx* ctx);
+/* The row partition every sharded entry point assumes: rank's rows [r0, r1) of n_total, boundaries on multiples of 32
+ * elements (256 B) so that each shard keeps the kernels' 16-byte alignment.  Pure arithmetic (no ctx, no GPU).      */
+int32_t si_row_shard(int64_t n_total, int32_t rank, int32_t world, int64_t* r0_out, int64_t* r1_out);
+/* Row-sharded construction: each rank pushes ITS rows of every snapshot (si_construct_begin with N = r1 - r0), then
+ *     si_construct_gram;  si_construct_allreduce_gram;                          -- G = sum of the local A'A, K x K fp64
+ *     si_construct_needs_refine -> if set: si_construct_refine; si_construct_allreduce_gram   (ill-conditioned A)
+ *     si_construct_finish            -- replicated K x K eigensolve, this rank's rows of P
+ *     si_construct_allgather(n_total) (optional) -- the FULL (W_swa, P) on every rank, device to device; the ctx then
+ *                                       holds a finished construction of n_total rows (si_infer_setup(NULL, NULL)).   */
+int32_t si_construct_allreduce_gram(si_ctx* ctx);
+int32_t si_construct_allgather(si_ctx* ctx, int64_t n_total);
+/* Independent chains (BASELINE cfg3): (W_swa, P, s) of the construction finished on `root` -> every rank's ctx, device
+ * to device, once (168 MB at cfg2); receivers then hold a finished construction.  No exchange per transition: rank r
+ * runs chains with its own chain ids (si_sample_rwmh), results are gathered with si_comm_allgather_host.            */
+int32_t si_bcast_subspace(si_ctx* ctx, int32_t root, int64_t N, int32_t M);
+/* Data-sharded density (BASELINE cfg5): each rank's si_infer_setup holds a column block of (X, Y) and the full
+ * W_swa / P; all ranks use the same seed / chain ids.  Between si_rwmh_step_eval(NULL) and si_rwmh_step_accept(NULL):
+ * all-reduce of the nchains partial sums of squared errors (8 * nchains bytes).  si_sample_rwmh_sharded is the whole
+ * loop in one call (eval -> all-reduce -> accept per transition on one stream, no host round trip); d_total =
+ * out_dim * observations over ALL ranks.                                                                            */
+int32_t si_rwmh_allreduce_sse(si_ctx* ctx);
+int32_t si_sample_rwmh_sharded(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0, int32_t nchains,
+                               int64_t d_total, double* Z_out, double* lp_out, double* accept_rate_out);
+/* Data-parallel training step: after si_train_grad on this rank's share of the batch, sum the N-double gradient and
+ * the local SSE over the ranks (one grouped launch); sse_total_out may be NULL (then no host synchronisation).
+ * si_train_step_dp = si_train_grad + si_train_allreduce_grad + si_train_apply; loss_out = mse of the WHOLE batch.   */
+int32_t si_train_allreduce_grad(si_ctx* ctx, double* sse_total_out);
+int32_t si_train_step_dp(si_ctx* ctx, const int64_t* idx, int64_t nb, int64_t nb_total, double* loss_out);
 
 /* ---- host utility (no GPU needed): the K x K symmetric eigensolver used inside si_construct_finish.
  * a: n x n symmetric column-major, overwritten by the eigenvectors (columns); w: eigenvalues ascending. */

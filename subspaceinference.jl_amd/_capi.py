@@ -15,6 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsubspace_hip.so")
 
 SI_OK, SI_ERR_INVALID, SI_ERR_STATE, SI_ERR_HIP, SI_ERR_NOMEM, SI_ERR_BOUNDS, SI_ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6
+SI_ERR_COMM = -7
+SI_COMM_ID_BYTES, SI_COMM_SUM, SI_COMM_MAX = 128, 0, 1
 SI_F32, SI_F64 = 0, 1
 ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 ACT_LEAKYRELU, ACT_ELU, ACT_SOFTPLUS, ACT_SELU = 4, 5, 6, 7
@@ -76,6 +78,7 @@ SIGNATURES = {
     "si_construct_refine": (c_int32, [c_void_p]),
     "si_construct_finish": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, POINTER(c_int64)]),
     "si_construct_get_A": (c_int32, [c_void_p, c_int64, c_int64, c_void_p]),
+    "si_construct_get_result": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int64), POINTER(c_int32)]),
     "si_infer_setup": (c_int32, [c_void_p, POINTER(SiLayer), c_int32, c_int64, c_int32, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_int32, c_int32, c_int64, c_double, c_int32]),
     "si_infer_setup_dev": (c_int32, [c_void_p, POINTER(SiLayer), c_int32, c_int64, c_int32, c_void_p, c_void_p, c_int64,
@@ -105,6 +108,22 @@ SIGNATURES = {
     "si_train_grad_get": (c_int32, [c_void_p, c_void_p]),
     "si_train_grad_set": (c_int32, [c_void_p, c_void_p]),
     "si_train_apply": (c_int32, [c_void_p]),
+    "si_comm_unique_id": (c_int32, [c_void_p]),
+    "si_comm_init_rank": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
+    "si_comm_destroy": (c_int32, [c_void_p]),
+    "si_comm_info": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
+    "si_comm_allreduce_host": (c_int32, [c_void_p, c_void_p, c_int64, c_int32]),
+    "si_comm_allgather_host": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "si_comm_barrier": (c_int32, [c_void_p]),
+    "si_row_shard": (c_int32, [c_int64, c_int32, c_int32, POINTER(c_int64), POINTER(c_int64)]),
+    "si_construct_allreduce_gram": (c_int32, [c_void_p]),
+    "si_construct_allgather": (c_int32, [c_void_p, c_int64]),
+    "si_bcast_subspace": (c_int32, [c_void_p, c_int32, c_int64, c_int32]),
+    "si_rwmh_allreduce_sse": (c_int32, [c_void_p]),
+    "si_sample_rwmh_sharded": (c_int32, [c_void_p, c_int64, c_double, c_uint64, c_int32, c_int32, c_int64, c_void_p, c_void_p,
+                                         c_void_p]),
+    "si_train_allreduce_grad": (c_int32, [c_void_p, c_void_p]),
+    "si_train_step_dp": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "si_host_sym_eig": (c_int, [c_int, c_void_p, c_void_p]),
     "si_host_sym_eig_top": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "si_host_jacobi_eig_psd": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
@@ -238,6 +257,85 @@ class Context:
         self._check(self.lib.si_get_stats(self.h, byref(st)))
         return {K_NAMES[i]: {"ms": st.ms[i], "launches": st.launches[i], "flops": st.flops[i], "bytes": st.bytes[i]}
                 for i in range(K_COUNT)}
+
+    # -- R1: the RCCL communicator of this ctx (one rank per ctx / GPU / process)
+    def comm_init_rank(self, world, rank, uid):
+        if len(uid) != SI_COMM_ID_BYTES:
+            raise SubspaceError("comm_init_rank: the id must be %d bytes" % SI_COMM_ID_BYTES)
+        buf = ctypes.create_string_buffer(bytes(uid), SI_COMM_ID_BYTES)
+        self._check(self.lib.si_comm_init_rank(self.h, int(world), int(rank), buf))
+
+    def comm_destroy(self):
+        self._check(self.lib.si_comm_destroy(self.h))
+
+    def comm_info(self):
+        """(world, rank, rccl_version); world = 0 without a communicator"""
+        w, r, v = c_int32(), c_int32(), c_int32()
+        self._check(self.lib.si_comm_info(self.h, byref(w), byref(r), byref(v)))
+        return int(w.value), int(r.value), int(v.value)
+
+    def comm_world(self):
+        return self.comm_info()[0]
+
+    def comm_allreduce_host(self, values, op="sum"):
+        a = np.array(values, dtype=np.float64, order="C").reshape(-1)
+        self._check(self.lib.si_comm_allreduce_host(self.h, _ptr(a), a.size, SI_COMM_SUM if op == "sum" else SI_COMM_MAX))
+        return a.reshape(np.shape(values))
+
+    def comm_allgather_host(self, values):
+        """(world, n) array: row r = rank r's `values`"""
+        a = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        out = np.empty((self.comm_world(), a.size), dtype=np.float64)
+        self._check(self.lib.si_comm_allgather_host(self.h, _ptr(a), a.size, _ptr(out)))
+        return out
+
+    def comm_barrier(self):
+        self._check(self.lib.si_comm_barrier(self.h))
+
+    def construct_allreduce_gram(self):
+        self._check(self.lib.si_construct_allreduce_gram(self.h))
+
+    def construct_allgather(self, n_total):
+        """full (W_swa, P) on every rank, device to device; the ctx then holds a finished construction of n_total rows"""
+        self._check(self.lib.si_construct_allgather(self.h, int(n_total)))
+        self._n = int(n_total)
+
+    def bcast_subspace(self, root, n, m):
+        self._check(self.lib.si_bcast_subspace(self.h, int(root), int(n), int(m)))
+        self._n = int(n)
+
+    def rwmh_allreduce_sse(self):
+        self._check(self.lib.si_rwmh_allreduce_sse(self.h))
+
+    def sample_rwmh_sharded(self, itr, sigma_z, seed, d_total, chain_id0=0, nchains=1):
+        z = np.empty((self._m, int(itr), int(nchains)), dtype=np.float64, order="F")
+        lp = np.empty((int(itr), int(nchains)), dtype=np.float64, order="F")
+        acc = np.empty(int(nchains), dtype=np.float64)
+        self._check(self.lib.si_sample_rwmh_sharded(self.h, int(itr), float(sigma_z), int(seed), int(chain_id0), int(nchains),
+                                                    int(d_total), _ptr(z), _ptr(lp), _ptr(acc)))
+        return z, lp, acc
+
+    def train_allreduce_grad(self, want_sse=True):
+        sse = np.empty(1, dtype=np.float64) if want_sse else None
+        self._check(self.lib.si_train_allreduce_grad(self.h, _ptr(sse)))
+        return float(sse[0]) if want_sse else None
+
+    def train_step_dp(self, idx, nb_total, want_loss=True):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        loss = np.empty(1, dtype=np.float64) if want_loss else None
+        self._check(self.lib.si_train_step_dp(self.h, _ptr(idx) if idx.size else None, idx.size, int(nb_total), _ptr(loss)))
+        return float(loss[0]) if want_loss else None
+
+    def construct_get_result(self, want_p=True):
+        """(W_swa, P, s) of the FINISHED construction the ctx holds -- its own, or one received through bcast_subspace /
+        construct_allgather -- copied to the host."""
+        n, m = c_int64(), c_int32()
+        self._check(self.lib.si_construct_get_result(self.h, None, None, None, byref(n), byref(m)))
+        w = np.empty(n.value, dtype=np.float64)
+        p = np.empty((n.value, m.value), dtype=np.float64, order="F") if want_p else None
+        s = np.empty(m.value, dtype=np.float64)
+        self._check(self.lib.si_construct_get_result(self.h, _ptr(w), _ptr(p), _ptr(s), byref(n), byref(m)))
+        return w, p, s
 
     # -- construction
     def construct_begin(self, n, k_capacity, max_cols=0):
@@ -512,6 +610,24 @@ class Context:
                 raise ValueError("reconstruct: `out` must be a Fortran-ordered float64 array of shape (N, C)")
         self._check(self.lib.si_reconstruct(self.h, _ptr(z), z.shape[1], _ptr(w)))
         return w
+
+
+def comm_unique_id():
+    """128-byte RCCL id (rank 0 creates it and ships it to the other ranks; needs no ctx)."""
+    lib = load()
+    buf = ctypes.create_string_buffer(SI_COMM_ID_BYTES)
+    rc = lib.si_comm_unique_id(buf)
+    if rc != SI_OK:
+        raise SubspaceError(lib.si_last_error(None).decode(), rc)
+    return buf.raw
+
+
+def row_shard(n_total, rank, world):
+    """si_row_shard: rows [r0, r1) of rank `rank` (32-element aligned boundaries) -- the partition the library assumes."""
+    r0, r1 = c_int64(), c_int64()
+    if load().si_row_shard(int(n_total), int(rank), int(world), byref(r0), byref(r1)) != SI_OK:
+        raise SubspaceError("si_row_shard: bad argument")
+    return int(r0.value), int(r1.value)
 
 
 def host_sym_eig(g):

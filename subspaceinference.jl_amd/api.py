@@ -44,10 +44,10 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
     init ("zeros" | "pretrained"): "zeros" is what the reference's CODE does (W_swa = zeros, :31 -- quirk Q1, the default);
     "pretrained" starts the running mean at the model's weights, as the reference's docs describe (nn_example.md:44).
 
-    Under a torch.distributed process group (one process per GPU, dist.init) the device training step is
+    With a ctx that carries an RCCL communicator (one process per GPU, dist.comm_init) the device training step is
     data-parallel: every rank must be called with the same model, data and DataLoader seed; each takes its share
-    of every batch and the gradient is all-reduced once per step (dist.train_step_data_parallel), so all ranks
-    return the same (W_swa, P).
+    of every batch and the gradient is all-reduced once per step inside the library (si_train_step_dp), so all
+    ranks return the same (W_swa, P).
     """
     ps = flux.params(model)
     n_par = int(sum(p.size for p in ps))
@@ -72,7 +72,7 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
         elif _alg_name(init) != "zeros":
             raise SubspaceError("init must be :zeros (the reference's behaviour) or :pretrained")
         training_loss = 0.0
-        dp_rank, dp_world = dist.world() if use_dev else (0, 1)
+        dp_rank, dp_world = dist.world(ctx) if use_dev else (0, 1)
         if use_dev:
             xm, ym, in_size = flux.data_matrices(data)
             table, _ = flux.layer_table(model, in_size)
@@ -83,7 +83,7 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
                 last = (i % print_freq == 0) or (i == T)
                 batches = list(data.index_batches())
                 for j, ids in enumerate(batches):
-                    if dp_world > 1:
+                    if dp_world > 1 or dist._has_comm(ctx):
                         # data-parallel step: this rank's share of the batch, one gradient all-reduce (dist.py)
                         c0, c1 = dist.col_shard(len(ids), dp_rank, dp_world)
                         loss = dist.train_step_data_parallel(ctx, np.asarray(ids)[c0:c1], len(ids))

@@ -17,6 +17,7 @@ ARCH = "gfx950"
 SOURCES = [
     ("capi.hip", []),
     ("capi_train.hip", []),
+    ("comm.hip", []),
     ("kernels_stream.hip", ["-ffp-contract=off"]),
     ("kernels_gemm.hip", []),
     ("kernels_gram.hip", []),

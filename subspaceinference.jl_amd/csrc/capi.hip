@@ -147,6 +147,33 @@ static void free_infer(Ctx* c) {
   c->i_swa = c->i_P = nullptr;
 }
 
+int32_t construct_adopt(Ctx* c, int64_t N, int32_t M) {
+  const int64_t ld = pad_ld(N);
+  double *w = nullptr, *p = nullptr;
+  if (dev_alloc(&w, (size_t)ld) != hipSuccess || dev_alloc(&p, (size_t)ld * (size_t)M) != hipSuccess) {
+    dev_free(w);
+    dev_free(p);
+    return fail(c, SI_ERR_NOMEM, "allocation of W_swa / P for a received subspace failed");
+  }
+  SI_HIP(c, hipMemsetAsync(w, 0, (size_t)ld * sizeof(double), c->stream));
+  SI_HIP(c, hipMemsetAsync(p, 0, (size_t)ld * (size_t)M * sizeof(double), c->stream));
+  construct_install(c, N, M, w, p);
+  return SI_OK;
+}
+
+void construct_install(Ctx* c, int64_t N, int32_t M, double* w_swa, double* P) {
+  (void)hipStreamSynchronize(c->stream);
+  free_construct(c);  // also drops an inference bound to the old W_swa / P
+  c->N = N;
+  c->ldA = pad_ld(N);
+  c->d_swa = w_swa;
+  c->d_P = P;
+  c->M_built = M;
+  c->svals.assign((size_t)M, 0.0);
+  c->c_active = false;  // no deviation matrix: nothing can be pushed or re-finished
+  c->c_finished = true;
+}
+
 }  // namespace si
 
 using namespace si;
@@ -157,7 +184,7 @@ using namespace si;
 
 extern "C" {
 
-int32_t si_version(void) { return 200; }
+int32_t si_version(void) { return 300; }
 
 const char* si_last_error(si_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -204,6 +231,7 @@ int32_t si_destroy(si_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   resolve_events(ctx);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  comm_release(ctx);
   free_train(ctx);
   free_construct(ctx);
   free_infer(ctx);
@@ -717,6 +745,23 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
   if (s_out) std::copy(ctx->svals.begin(), ctx->svals.end(), s_out);
   if (W_swa_out)
     SI_HIP(ctx, hipMemcpyAsync(W_swa_out, ctx->d_swa, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (P_out)
+    SI_HIP(ctx, hipMemcpy2DAsync(P_out, (size_t)N * sizeof(double), ctx->d_P, (size_t)ctx->ldA * sizeof(double),
+                                 (size_t)N * sizeof(double), (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+int32_t si_construct_get_result(si_ctx* ctx, double* W_swa_out, double* P_out, double* s_out, int64_t* N_out, int32_t* M_out) {
+  CHECK_CTX(ctx);
+  if (!ctx->c_finished) return fail(ctx, SI_ERR_STATE, "si_construct_get_result: no finished construction");
+  BIND(ctx);
+  const int64_t N = ctx->N;
+  const int32_t M = ctx->M_built;
+  if (N_out) *N_out = N;
+  if (M_out) *M_out = M;
+  if (s_out) std::copy(ctx->svals.begin(), ctx->svals.end(), s_out);
+  if (W_swa_out) SI_HIP(ctx, hipMemcpyAsync(W_swa_out, ctx->d_swa, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (P_out)
     SI_HIP(ctx, hipMemcpy2DAsync(P_out, (size_t)N * sizeof(double), ctx->d_P, (size_t)ctx->ldA * sizeof(double),
                                  (size_t)N * sizeof(double), (size_t)M, hipMemcpyDeviceToHost, ctx->stream));

@@ -90,6 +90,10 @@ struct Ctx {
   std::string err;
   char devname[256] = {0};
   int num_cu = 256;
+  // R1: RCCL communicator of this ctx (comm.hip; an ncclComm_t, kept opaque here), one rank per ctx
+  void* comm = nullptr;
+  int comm_world = 0, comm_rank = 0;
+  double* d_commtmp = nullptr;  // device scratch of the host-value collectives
 
   // experiment knob SI_OVERLAP_HALVES=1: the two halves of the batch of ONE chain on two streams
   bool overlap_halves = false;
@@ -197,6 +201,12 @@ struct Ctx {
 };
 
 void free_train(Ctx* c);
+void comm_release(Ctx* c);  // comm.hip: destroy the communicator (si_destroy / si_comm_destroy)
+// capi.hip: make `c` hold a FINISHED construction of N rows and M columns without a deviation matrix (what a rank that
+// receives (W_swa, P) from another rank ends up with).  adopt allocates zeroed W_swa / P; install takes ownership of the
+// two device buffers (ld = pad_ld(N), padding rows zero).  Both drop whatever construction / bound inference was there.
+int32_t construct_adopt(Ctx* c, int64_t N, int32_t M);
+void construct_install(Ctx* c, int64_t N, int32_t M, double* w_swa, double* P);
 
 // error helpers -------------------------------------------------------------------------------
 int32_t fail(Ctx* c, int32_t code, const std::string& msg);

@@ -26,12 +26,16 @@
 #   * :mala / :hmc / :nuts sampler logic (:117-120, :139-160)                                    -> the reference's own
 #       AdvancedMH / AdvancedHMC calls, unchanged, driven by the two device callbacks above
 #   * output map :125                                                                            -> GPU (si_reconstruct)
+#   * more than one GPU: one Julia process per GPU (Distributed workers), one Ctx each, joined by the RCCL communicator
+#       INSIDE the library (si_comm_*): `init_gpus()`, then `subspace_inference(...; ngpu = 8, nchains = 8)`,
+#       `sub_inference_chains`, `sharded_construct_finish!`, `sample_data_sharded` (section at the end of this file)
 module SubspaceInferenceHIP
 
-using Flux, Zygote, Random
+using Flux, Zygote, Random, Distributed
 using Distributions: MvNormal
 using AdvancedMH, AdvancedHMC
 export subspace_construction, subspace_inference, sub_inference, inference, predict
+export init_gpus, sub_inference_chains, sharded_construct_finish!, sample_data_sharded, bcast_subspace!
 
 const LIB = get(ENV, "SUBSPACE_HIP_LIB", joinpath(@__DIR__, "..", "libsubspace_hip.so"))
 const SI_F32, SI_F64 = Int32(0), Int32(1)
@@ -173,10 +177,21 @@ function train_on_device!(ctx::Ctx, model, data, opt, T, c, print_freq)
         ctx.h, tbl, length(tbl), N, w0, X, Y, size(X, 1), size(Y, 1), size(X, 2), min(data.batchsize, data.nobs),
         kind, η, p1, p2))
     loss = Ref{Float64}(0.0)
+    world, rank = comm_info(ctx)
     for i in 1:T
         for ids in index_batches(data)
-            GC.@preserve ids check(ctx, ccall((:si_train_step, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int64, Ref{Float64}),
-                                              ctx.h, ids, length(ids), loss))
+            if world > 0
+                # data-parallel step (SURVEY 8e): this rank's share of the batch; the N-double gradient and the SSE are
+                # all-reduced inside the library (RCCL, in place, one grouped launch) -- every rank must iterate the
+                # same batches (same DataLoader seed)
+                lo, hi = col_shard(length(ids), rank, world)
+                mine = ids[lo+1:hi]
+                GC.@preserve mine check(ctx, ccall((:si_train_step_dp, LIB), Int32,
+                    (Ptr{Cvoid}, Ptr{Int64}, Int64, Int64, Ref{Float64}), ctx.h, mine, length(mine), length(ids), loss))
+            else
+                GC.@preserve ids check(ctx, ccall((:si_train_step, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int64, Ref{Float64}),
+                                                  ctx.h, ids, length(ids), loss))
+            end
             # :45-52 with W read in place from the device-resident Float32 weights (no extract_params, no PCIe)
             mod(i, c) == 0 && check(ctx, ccall((:si_train_push, LIB), Int32, (Ptr{Cvoid}, Float64), ctx.h, i / c))
         end
@@ -338,10 +353,198 @@ function predict(ctx::Ctx, Z::Matrix{Float64}, Xnew::Matrix{Float64}, out_dim::I
     return Yh
 end
 
+# =====================================================================================================================
+# More than one GPU (SURVEY 2.2 R1, 8e).  One Julia PROCESS per GPU (Distributed workers, `addprocs(8)` +
+# `@everywhere using SubspaceInferenceHIP`), one Ctx per process, joined by an RCCL communicator that lives INSIDE the
+# library (si_comm_*): every collective runs in place on the library's device buffers, on its stream.  Julia ships only
+# the 128-byte id (remotecall) and, at the end, the small (Z, lp) results.  The reference is single-process; the loops
+# these calls parallelise are src/subspace_construction.jl:37-59 and src/space_inference.jl:94,116.
+# =====================================================================================================================
+const RANK_CTX = Ref{Union{Nothing,Ctx}}(nothing)        # the ctx of THIS process once init_gpus has run
+rank_ctx() = RANK_CTX[] === nothing ? throw("Error: this process has no GPU context (call init_gpus first)") : RANK_CTX[]
+
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    rc = GC.@preserve id ccall((:si_comm_unique_id, LIB), Int32, (Ptr{UInt8},), id)
+    rc == 0 || throw(unsafe_string(ccall((:si_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+    return id
+end
+
+comm_init!(ctx::Ctx, world, rank, id::Vector{UInt8}) = GC.@preserve id check(ctx, ccall((:si_comm_init_rank, LIB), Int32,
+    (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}), ctx.h, world, rank, id))
+comm_destroy!(ctx::Ctx) = check(ctx, ccall((:si_comm_destroy, LIB), Int32, (Ptr{Cvoid},), ctx.h))
+
+# (world, rank); world == 0 when the ctx has no communicator
+function comm_info(ctx::Ctx)
+    w = Ref{Int32}(0); r = Ref{Int32}(0); v = Ref{Int32}(0)
+    check(ctx, ccall((:si_comm_info, LIB), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ref{Int32}), ctx.h, w, r, v))
+    return Int(w[]), Int(r[])
+end
+
+comm_barrier(ctx::Ctx) = check(ctx, ccall((:si_comm_barrier, LIB), Int32, (Ptr{Cvoid},), ctx.h))
+
+# small host values over the communicator (losses, timings): op 0 = sum, 1 = max
+function comm_allreduce!(ctx::Ctx, v::Vector{Float64}; op = 0)
+    GC.@preserve v check(ctx, ccall((:si_comm_allreduce_host, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int32),
+                                    ctx.h, v, length(v), op))
+    return v
+end
+
+function comm_allgather(ctx::Ctx, v::Vector{Float64})
+    world, _ = comm_info(ctx)
+    out = Matrix{Float64}(undef, length(v), world)
+    GC.@preserve v out check(ctx, ccall((:si_comm_allgather_host, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}),
+                                        ctx.h, v, length(v), out))
+    return out
+end
+
+# rows [r0, r1) (0-based, r1 exclusive) of rank `rank`: the partition every sharded entry point of the library assumes
+function row_shard(n_total, rank, world)
+    r0 = Ref{Int64}(0); r1 = Ref{Int64}(0)
+    ccall((:si_row_shard, LIB), Int32, (Int64, Int32, Int32, Ref{Int64}, Ref{Int64}), n_total, rank, world, r0, r1) == 0 ||
+        throw("si_row_shard: bad argument")
+    return Int(r0[]), Int(r1[])
+end
+
+# observation block (0-based, exclusive end) of rank `rank`: contiguous, sizes differ by at most one
+function col_shard(b, rank, world)
+    base, rem = divrem(b, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (rank < rem ? 1 : 0)
+end
+
+"""
+    init_gpus(ws = workers())
+
+One GPU per Distributed worker: worker `ws[r]` creates its `Ctx(r - 1)` and joins an RCCL communicator of
+`length(ws)` ranks (rank = r - 1).  Run once after `addprocs(n); @everywhere using SubspaceInferenceHIP`.
+"""
+function init_gpus(ws::Vector{Int} = workers())
+    id = comm_unique_id()                                   # needs no GPU; travels to the workers by remotecall
+    world = length(ws)
+    @sync for (r, w) in enumerate(ws)
+        @async remotecall_wait(w, id, world, r - 1) do id, world, rank
+            ctx = Ctx(rank)
+            comm_init!(ctx, world, rank, id)
+            RANK_CTX[] = ctx
+            nothing
+        end
+    end
+    return ws
+end
+
+# (W_swa, P, s) of the construction finished on rank `root` -> every rank's ctx, device to device (168 MB at cfg2, once);
+# collective: every rank calls it.  Receivers then hold a finished construction (sub_inference(..., nothing, nothing)).
+bcast_subspace!(ctx::Ctx, root, N, M) = check(ctx, ccall((:si_bcast_subspace, LIB), Int32,
+    (Ptr{Cvoid}, Int32, Int64, Int32), ctx.h, root, N, M))
+
+"""
+    sharded_construct_finish!(ctx, M, n_total; gather = true)
+
+Row-sharded `psvd` + `P` (src/subspace_construction.jl:63,65): this rank pushed ITS rows `row_shard(n_total, rank, world)`
+of every snapshot (si_construct_begin with N = r1 - r0).  ONE all-reduce of the K x K Gram matrix inside the library
+(a second one on the ill-conditioned route), replicated eigensolve, row-local projection; `gather` assembles the full
+(W_swa, P) on every rank, device to device.  Returns the M singular values.
+"""
+function sharded_construct_finish!(ctx::Ctx, M, n_total; gather = true)
+    check(ctx, ccall((:si_construct_gram, LIB), Int32, (Ptr{Cvoid},), ctx.h))
+    check(ctx, ccall((:si_construct_allreduce_gram, LIB), Int32, (Ptr{Cvoid},), ctx.h))
+    flag = Ref{Int32}(0)
+    check(ctx, ccall((:si_construct_needs_refine, LIB), Int32, (Ptr{Cvoid}, Int32, Ref{Int32}), ctx.h, M, flag))
+    if flag[] != 0
+        check(ctx, ccall((:si_construct_refine, LIB), Int32, (Ptr{Cvoid},), ctx.h))
+        check(ctx, ccall((:si_construct_allreduce_gram, LIB), Int32, (Ptr{Cvoid},), ctx.h))
+    end
+    s = Vector{Float64}(undef, M); K = Ref{Int64}(0)
+    GC.@preserve s check(ctx, ccall((:si_construct_finish, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}), ctx.h, M, C_NULL, C_NULL, s, K))
+    gather && check(ctx, ccall((:si_construct_allgather, LIB), Int32, (Ptr{Cvoid}, Int64), ctx.h, n_total))
+    return s
+end
+
+# host copies of the finished construction a ctx holds (its own, or one received by bcast_subspace! / the all-gather)
+function construct_result(ctx::Ctx)
+    N = Ref{Int64}(0); M = Ref{Int32}(0)
+    check(ctx, ccall((:si_construct_get_result, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Ref{Int32}), ctx.h, C_NULL, C_NULL, C_NULL, N, M))
+    W = Vector{Float64}(undef, N[]); P = Matrix{Float64}(undef, N[], M[]); s = Vector{Float64}(undef, M[])
+    GC.@preserve W P s check(ctx, ccall((:si_construct_get_result, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}, Ref{Int32}), ctx.h, W, P, s, N, M))
+    return W, P, s
+end
+
+"""
+    sample_data_sharded(ctx, itr, σ_z, d_total, M; seed, chain_id, nchains)
+
+RWMH with the observations split over the ranks (BASELINE cfg5): `ctx` was set up (si_infer_setup) with THIS rank's
+column block of (X, Y) and the full W_swa / P.  One library call: per transition eval -> RCCL all-reduce of the
+partial sums of squared errors -> accept, on one stream.  Every rank returns the same chain.
+"""
+function sample_data_sharded(ctx::Ctx, itr, σ_z, d_total, M; seed = 0, chain_id = 0, nchains = 1)
+    Z = Array{Float64}(undef, M, itr, nchains); lp = Matrix{Float64}(undef, itr, nchains); acc = Vector{Float64}(undef, nchains)
+    GC.@preserve Z lp acc check(ctx, ccall((:si_sample_rwmh_sharded, LIB), Int32,
+        (Ptr{Cvoid}, Int64, Float64, UInt64, Int32, Int32, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        ctx.h, itr, σ_z, seed, chain_id, nchains, d_total, Z, lp, acc))
+    return Z, lp, acc
+end
+
+"""
+    sub_inference_chains(in_model, data, W_swa, P; nchains, ws = workers(), kwargs...)
+
+`nchains` independent chains of `sub_inference` spread over the GPUs of `ws` (BASELINE cfg3: one chain per GPU, no
+exchange per transition).  Chain c uses the library's Philox stream c, so the union over ranks is what one GPU running
+all chains would produce.  `W_swa === nothing`: every rank's ctx already holds the subspace (bcast_subspace!).
+Returns `(chains::Vector, lps::Vector)` in chain order.
+"""
+function sub_inference_chains(in_model, data, W_swa, P; nchains, ws::Vector{Int} = workers(), seed = 0, kwargs...)
+    world = length(ws)
+    futs = map(enumerate(ws)) do (r, w)
+        base, rem = divrem(nchains, world)
+        lo = (r - 1) * base + min(r - 1, rem)
+        ids = lo:(lo + base + ((r - 1) < rem ? 1 : 0) - 1)
+        remotecall(w, in_model, data, W_swa, P, collect(ids), seed, kwargs) do m, d, Ws, Pm, ids, seed, kw
+            [sub_inference(m, d, Ws, Pm; ctx = rank_ctx(), seed = seed, chain_id = c, kw...) for c in ids]
+        end
+    end
+    res = reduce(vcat, map(fetch, futs))
+    return map(first, res), map(last, res)
+end
+
+# subspace_inference on `ngpu` GPUs: construction on every rank (data-parallel device training: identical (W_swa, P)
+# everywhere, one gradient all-reduce per step) or on rank 0 followed by ONE device-to-device broadcast; then `nchains`
+# independent chains.  Called by subspace_inference(...; ngpu > 1).
+function subspace_inference_multi(model, cost, data, opt; ngpu, nchains, ws::Vector{Int} = workers()[1:ngpu], σ_z, σ_m, σ_p, itr,
+                                  T, c, M, print_freq, alg, backend, device_training)
+    length(ws) == ngpu || throw("Error: ngpu = $ngpu needs that many initialised workers (init_gpus)")
+    N = sum(length, Flux.params(model))
+    outs = map(enumerate(ws)) do (r, w)
+        remotecall(w, model, cost, data, opt, r - 1) do m, cst, d, o, rank
+            ctx = rank_ctx()
+            Wl = nothing
+            if device_training || rank == 0
+                # (device_training: every rank runs the SAME loop on its share of each batch -> same result everywhere)
+                Wl, _ = subspace_construction(m, cst, d, o; T = T, c = c, M = M, print_freq = print_freq, ctx = ctx,
+                                              keep_on_device = true, device_training = device_training)
+            end
+            device_training || bcast_subspace!(ctx, 0, N, M)     # collective: all ranks
+            rank == 0 ? Wl : nothing
+        end
+    end
+    W_swa = first(filter(x -> x !== nothing, map(fetch, outs)))
+    chains, lps = sub_inference_chains(model, data, nothing, nothing; nchains = nchains, ws = ws, σ_z = σ_z, σ_m = σ_m,
+                                       σ_p = σ_p, itr = itr, M = M, alg = alg, backend = backend)
+    return chains, lps, W_swa
+end
+
+# ngpu / nchains are additions: ngpu = 1 (default) is the reference's single chain on one GPU; ngpu > 1 runs `nchains`
+# independent chains on the GPUs prepared by init_gpus and returns a Vector of chains / lps (chain order)
 function subspace_inference(model, cost, data, opt; σ_z = 1.0, σ_m = 1.0, σ_p = 1.0, itr = 1000, T = 25, c = 1, M = 20,
                             print_freq = 1, alg = :rwmh, backend = :forwarddiff, method = :subspace, device = 0,
-                            device_training = false)
+                            device_training = false, ngpu = 1, nchains = ngpu)
     method == :subspace || throw("Error: No method found")
+    ngpu > 1 && return subspace_inference_multi(model, cost, data, opt; ngpu = ngpu, nchains = nchains, σ_z = σ_z, σ_m = σ_m,
+                                                σ_p = σ_p, itr = itr, T = T, c = c, M = M, print_freq = print_freq, alg = alg,
+                                                backend = backend, device_training = device_training)
     ctx = Ctx(device)
     W_swa, _ = subspace_construction(model, cost, data, opt; T = T, c = c, M = M, print_freq = print_freq, ctx = ctx,
                                      keep_on_device = true, device_training = device_training)

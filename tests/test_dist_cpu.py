@@ -124,6 +124,16 @@ def _worker(rank, world, port, q):
     try:
         r, w = sd.init(backend="gloo")
         assert (r, w) == (rank, world)
+        # the RCCL id of the in-library communicator travels through the process group: every rank ends up with rank 0's
+        class Rec:
+            def comm_init_rank(self, world, rank, uid):
+                self.got = (world, rank, uid)
+        rec = Rec()
+        assert sd.comm_init(rec) == (rank, world) and rec.got[:2] == (world, rank) and len(rec.got[2]) == 128
+        import torch.distributed as td
+        ids = [None] * world
+        td.all_gather_object(ids, rec.got[2])
+        assert len(set(ids)) == 1
         n, k, m = 1000 + 37, 12, 3
         rng = np.random.default_rng(0)  # same data on every rank
         snaps = [rng.standard_normal(n).astype(np.float32) for _ in range(k)]
@@ -202,12 +212,41 @@ def test_partitions():
             assert blocks[0][0] == 0 and blocks[-1][1] == n
             assert all(blocks[i][1] == blocks[i + 1][0] for i in range(ws - 1))
             assert all(b[0] % 32 == 0 or b[0] == b[1] for b in blocks)  # non-empty shards start 256-B aligned
+            # the library's own partition (si_row_shard: what the Julia wrapper and the sharded entry points use) agrees
+            import subspaceinference_jl_amd as si
+            assert blocks == [si._capi.row_shard(n, r, ws) for r in range(ws)]
     assert [sd.chain_ids(8, r, 8) for r in range(8)] == [[i] for i in range(8)]
     assert sd.chain_ids(5, 0, 2) == [0, 1, 2] and sd.chain_ids(5, 1, 2) == [3, 4]
     assert sd.chain_ids(1, 1, 2) == []
     assert [sd.col_shard(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
     assert sd.world() == (0, 1)
     assert np.array_equal(sd.allreduce_sum(np.eye(3)), np.eye(3))  # no process group: identity
+
+
+def test_rccl_is_bound_at_run_time_and_ids_are_unique(tmp_path):
+    """R1 start-up without a GPU: the library has no link-time RCCL dependency (dlopen at the first si_comm_* call); the id
+    needs no ctx; the file rendezvous of dist.comm_init delivers rank 0's id to a late rank."""
+    sys.path.insert(0, ROOT)
+    import subprocess
+    import subspaceinference_jl_amd as si
+    needed = subprocess.run(["readelf", "-d", si._capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" not in needed and "libtorch" not in needed
+    a, b = si._capi.comm_unique_id(), si._capi.comm_unique_id()
+    assert len(a) == len(b) == si._capi.SI_COMM_ID_BYTES == 128 and a != b
+
+    class Rec:
+        def comm_init_rank(self, world, rank, uid):
+            self.got = (world, rank, uid)
+    from subspaceinference_jl_amd import dist as sd
+    path = str(tmp_path / "id")
+    r0, r1 = Rec(), Rec()
+    assert sd.comm_init(r0, rank=0, world=2, id_file=path) == (0, 2)
+    assert sd.comm_init(r1, rank=1, world=2, id_file=path) == (1, 2)
+    assert r0.got[2] == r1.got[2] and len(r1.got[2]) == 128 and (r0.got[:2], r1.got[:2]) == ((2, 0), (2, 1))
+    with pytest.raises(si.SubspaceError):
+        sd.comm_init(Rec(), rank=1, world=2, id_file=str(tmp_path / "never"), timeout_s=0.2)
+    with pytest.raises(si.SubspaceError):
+        sd.comm_init(Rec(), rank=0, world=2)          # two ranks and no way to share the id
 
 
 @pytest.mark.timeout(300)

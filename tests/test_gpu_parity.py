@@ -537,52 +537,6 @@ def test_data_parallel_training_step(si, gpu_ctx):
             c.close()
 
 
-_DP_RCCL_SCRIPT = r"""
-import os, sys
-import numpy as np
-sys.path.insert(0, os.environ["SI_ROOT"])
-import subspaceinference_jl_amd as si
-from subspaceinference_jl_amd import dist as sd, flux
-rank, world = sd.init(backend="nccl", device=0, force=True)
-import torch.distributed as td
-assert td.is_initialized() and td.get_backend() == "nccl"
-rng = np.random.default_rng(0)
-x, y = rng.standard_normal((6, 64)), rng.standard_normal((1, 64))
-wr = np.random.default_rng(1)
-m = flux.Chain(flux.Dense(6, 40, flux.relu, rng=wr), flux.Dense(40, 1, rng=wr))
-table, n = flux.layer_table(m)
-w0 = flux.extract_params(flux.params(m))
-a, b = si.Context(0), si.Context(0)
-for c in (a, b):
-    c.train_setup(table, n, w0, x, y, 64, *flux.device_optimiser(flux.Momentum(0.01, 0.9)))
-for ids in (np.arange(0, 64), np.arange(10, 50)):
-    la = a.train_step(ids)
-    lb = sd.train_step_data_parallel(b, ids, ids.size)   # world 1: the in-place RCCL all-reduce is the identity
-    assert np.isclose(la, lb, rtol=1e-12), (la, lb)
-assert np.array_equal(a.train_get_weights(), b.train_get_weights())
-td.destroy_process_group()
-print("DP_RCCL_OK")
-"""
-
-
-def test_data_parallel_step_over_rccl_zero_copy(tmp_path):
-    """dist.train_step_data_parallel with backend nccl (= RCCL): torch all-reduces the library's device gradient buffer in
-    place through __cuda_array_interface__ (world 1 on the one GPU of the test box; world 2 is the gloo CPU test)."""
-    import socket
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / "dp_rccl.py"
-    script.write_text(_DP_RCCL_SCRIPT)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, SI_ROOT=root, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "DP_RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
-
-
 _DP_API_SCRIPT = r"""
 import os, sys
 import numpy as np

@@ -29,6 +29,7 @@ COMPAT = {
     "si_layer*": {"Ptr{SiLayer}"},
     "si_stats*": {"Ptr{SiStats}", "Ref{SiStats}"},
     "char*": {"Ptr{UInt8}", "Cstring"},
+    "uint8_t*": {"Ptr{UInt8}"},
 }
 RET = {"int32_t": {"Int32", "Cint"}, "int": {"Cint", "Int32"}, "const char*": {"Cstring", "Ptr{UInt8}"}}
 
@@ -71,6 +72,8 @@ def test_header_is_parsed_completely():
     assert protos["si_create"] == ("int32_t", ["si_ctx**", "int32_t"])
     assert protos["si_last_error"] == ("const char*", ["si_ctx*"])
     assert protos["si_train_grad_ptr"] == ("int32_t", ["si_ctx*", "double**", "int64_t*"])
+    assert protos["si_comm_init_rank"] == ("int32_t", ["si_ctx*", "int32_t", "int32_t", "uint8_t*"])
+    assert protos["si_comm_unique_id"] == ("int32_t", ["uint8_t*"])
 
 
 def test_every_ccall_matches_the_header():
@@ -92,11 +95,20 @@ def test_the_wrapper_binds_the_whole_single_process_path():
             "si_infer_setup", "si_logdensity", "si_logdensity_grad", "si_sample_rwmh", "si_reconstruct", "si_predict",
             "si_train_setup", "si_train_step", "si_train_push", "si_train_get_weights"}
     assert need <= bound, need - bound
-    # what is deliberately NOT bound from Julia: device-pointer / multi-GPU hooks (torch.distributed side), profiling, test read-backs
+    # R1: the multi-GPU path is reachable from Julia through ccall alone (VERDICT r2 row b')
+    need_multi = {"si_comm_unique_id", "si_comm_init_rank", "si_comm_destroy", "si_comm_info", "si_comm_barrier",
+                  "si_comm_allreduce_host", "si_comm_allgather_host", "si_row_shard", "si_construct_gram",
+                  "si_construct_allreduce_gram", "si_construct_needs_refine", "si_construct_refine", "si_construct_allgather",
+                  "si_construct_get_result", "si_bcast_subspace", "si_sample_rwmh_sharded", "si_train_step_dp"}
+    assert need_multi <= bound, need_multi - bound
+    # what is deliberately NOT bound from Julia: device-pointer hooks, the step-wise pieces of calls bound as a whole
+    # (si_sample_rwmh_sharded, si_train_step_dp), profiling, test read-backs
     unbound = set(header_prototypes()) - bound
     for name in unbound:
-        assert re.search(r"_dev$|_ptr$|gram|rwmh_|train_grad|train_apply|profiling|stats|stream|synchronize|version|device_name|"
-                         r"get_A|host_sym_eig|host_jacobi|refine|si_forward|push_batch", name), "unbound without a reason: " + name
+        assert re.search(r"_dev$|_ptr$|gram_get|gram_set|rwmh_|train_grad|train_apply|allreduce_grad|profiling|stats|stream|synchronize|"
+                         r"version|device_name|get_A|host_sym_eig|host_jacobi|si_forward|push_batch", name), "unbound without a reason: " + name
+    jl = open(JL).read()
+    assert "function init_gpus" in jl and "ngpu = 1, nchains = ngpu" in jl and "remotecall" in jl
 
 
 def test_silayer_mirrors_si_layer():
