@@ -130,7 +130,11 @@ int32_t si_construct_begin(si_ctx* ctx, int64_t N, int64_t K_capacity, int32_t m
 int32_t si_construct_set_mean(si_ctx* ctx, const void* w_host, int32_t w_dtype);
 /* :45-52  W = extract_params(ps); n = i/c; W_swa = (n.*W_swa + W)./(n+1); W_dev = W - W_swa;
  * append!(A, W_dev).  `n` is supplied by the caller (it is the EPOCH counter i/c, repeated for every
- * batch of the epoch).  w has N elements of w_dtype.                                                */
+ * batch of the epoch).  w has N elements of w_dtype.
+ * si_construct_push (host snapshot, pageable is fine) is PIPELINED: the call copies w into one of two pinned staging
+ * buffers (host threads, SI_HOST_COPY_THREADS), queues H2D + K1 on the ctx's stream and returns -- w_host may be reused
+ * at once, the transfer and the kernel overlap the caller's next gradient / update!.  Errors of the queued work surface
+ * at the next synchronising call (si_construct_finish, si_synchronize).                                              */
 int32_t si_construct_push(si_ctx* ctx, const void* w_host, int32_t w_dtype, double n);
 int32_t si_construct_push_dev(si_ctx* ctx, const void* w_dev, int32_t w_dtype, double n);
 /* `count` pushes in one pass over snapshots already on the device: snapshot j starts at w_dev + j*ld elements and is
@@ -222,6 +226,14 @@ int32_t si_predict(si_ctx* ctx, const double* Z /* M x C */, int32_t C, const do
  * Z_out is M x itr x nchains, lp_out is itr x nchains (column-major), accept_rate_out nchains.        */
 int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0,
                        int32_t nchains, double* Z_out, double* lp_out, double* accept_rate_out);
+/* si_sample_rwmh plus the reference's output map (:125 `map(z -> W_swa + P*z.params, chm)`), delivered WHILE the chain
+ * runs: W_out is N x itr x nchains (column-major; sample t of chain c at W_out + N*(t + itr*c)), may be pageable and
+ * untouched.  K4 has already formed W_swa + P z' for every proposal; the library keeps the chains' current weights in a
+ * small device ring (select on accept, no second K4 pass over P), a second stream DMAs sample t into pinned staging
+ * during transition t+1 and host threads (SI_HOST_COPY_THREADS) move it into W_out a few transitions later -- at cfg2
+ * 8.4 MB per sample against 3.2 ms of compute.  Bit-identical to si_reconstruct on the returned Z.                   */
+int32_t si_sample_rwmh_weights(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0,
+                               int32_t nchains, double* Z_out, double* lp_out, double* accept_rate_out, double* W_out);
 /* The same chain, one transition at a time, with the proposal's sum of squared errors handed to the caller between
  * evaluation and acceptance: a DATA-SHARDED density (every rank holds a column block of X, Y and the same W_swa, P)
  * all-reduces the per-rank partial SSE there (one 8*nchains-byte RCCL all-reduce per step).  d_total = out_dim * B over

@@ -90,6 +90,8 @@ SIGNATURES = {
     "si_predict": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "si_sample_rwmh": (c_int32, [c_void_p, c_int64, c_double, c_uint64, c_int32, c_int32, c_void_p, c_void_p,
                                  c_void_p]),
+    "si_sample_rwmh_weights": (c_int32, [c_void_p, c_int64, c_double, c_uint64, c_int32, c_int32, c_void_p, c_void_p,
+                                         c_void_p, c_void_p]),
     "si_rwmh_begin": (c_int32, [c_void_p, c_int64, c_double, c_uint64, c_int32, c_int32, c_int64]),
     "si_rwmh_step_eval": (c_int32, [c_void_p, c_void_p]),
     "si_rwmh_step_accept": (c_int32, [c_void_p, c_void_p]),
@@ -557,6 +559,22 @@ class Context:
         self._check(self.lib.si_sample_rwmh(self.h, int(itr), float(sigma_z), int(seed), int(chain_id0), int(nchains),
                                             _ptr(z), _ptr(lp), _ptr(acc)))
         return z, lp, acc
+
+    def sample_rwmh_weights(self, itr, sigma_z, seed, chain_id0=0, nchains=1, out=None):
+        """si_sample_rwmh + the output map (:125) streamed while the chain runs: returns (z, lp, acc, W) with
+        W of shape (N, itr, nchains), Fortran order -- W[:, t, c] == W_swa + P z[:, t, c]."""
+        z = np.empty((self._m, int(itr), int(nchains)), dtype=np.float64, order="F")
+        lp = np.empty((int(itr), int(nchains)), dtype=np.float64, order="F")
+        acc = np.empty(int(nchains), dtype=np.float64)
+        if out is None:
+            w = np.empty((self._ni, int(itr), int(nchains)), dtype=np.float64, order="F")
+        else:
+            w = out
+            if w.dtype != np.float64 or w.shape != (self._ni, int(itr), int(nchains)) or not w.flags.f_contiguous:
+                raise ValueError("sample_rwmh_weights: `out` must be a Fortran-ordered float64 array of shape (N, itr, nchains)")
+        self._check(self.lib.si_sample_rwmh_weights(self.h, int(itr), float(sigma_z), int(seed), int(chain_id0), int(nchains),
+                                                    _ptr(z), _ptr(lp), _ptr(acc), _ptr(w)))
+        return z, lp, acc, w
 
     def rwmh_begin(self, itr, sigma_z, seed, chain_id0=0, nchains=1, d_total=0):
         self._check(self.lib.si_rwmh_begin(self.h, int(itr), float(sigma_z), int(seed), int(chain_id0), int(nchains),

@@ -154,18 +154,16 @@ def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=10
         ctx.set_prior(σ_p if include_prior else 0.0)
         if nchains != 1 and a not in _RWMH_ALGS:
             raise SubspaceError("nchains > 1 is available for alg = :rwmh / :mh only")
-        if a in _RWMH_ALGS and nchains > 1:
-            z, lp, _ = ctx.sample_rwmh(itr, σ_z, seed, chain_id, nchains)
-            if return_z:
-                return z, lp
-            out = []
-            for c in range(nchains):
-                w = ctx.reconstruct(z[:, :, c])
-                out.append([w[:, t] for t in range(w.shape[1])])
-            return out, lp
         if a in _RWMH_ALGS:
-            z, lp, _ = ctx.sample_rwmh(itr, σ_z, seed, chain_id, 1)
-            z, lp = z[:, :, 0], lp[:, 0]
+            if return_z:
+                z, lp, _ = ctx.sample_rwmh(itr, σ_z, seed, chain_id, nchains)
+                return (z, lp) if nchains > 1 else (z[:, :, 0], lp[:, 0])
+            # :125 map(z -> W_swa + P*z.params, chm): the weight samples stream out of the device WHILE the chain runs
+            # (si_sample_rwmh_weights: K4's own output, selected on accept; DMA + host copy hidden under the next transitions)
+            _, lp, _, w = ctx.sample_rwmh_weights(itr, σ_z, seed, chain_id, nchains)
+            if nchains > 1:
+                return [[w[:, t, c] for t in range(itr)] for c in range(nchains)], lp
+            return [w[:, t, 0] for t in range(itr)], lp[:, 0]
         else:
             # :mala (:117-120) / :hmc, :nuts (:139-160): the sampler logic is host control flow, every density + gradient
             # evaluation is the device reverse sweep (si_logdensity_grad) instead of M-wide ForwardDiff duals (:107)

@@ -18,6 +18,7 @@ SOURCES = [
     ("capi.hip", []),
     ("capi_train.hip", []),
     ("comm.hip", []),
+    ("host_copy.cpp", []),
     ("kernels_stream.hip", ["-ffp-contract=off"]),
     ("kernels_gemm.hip", []),
     ("kernels_gram.hip", []),

@@ -8,9 +8,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
-#include <sched.h>
-#include <system_error>
-#include <thread>
 #include <vector>
 
 #include "si_internal.h"
@@ -182,6 +179,9 @@ using namespace si;
   if (!(ctx)) return SI_ERR_INVALID
 #define BIND(ctx) SI_HIP(ctx, hipSetDevice((ctx)->device))
 
+static void free_push_staging(si_ctx* ctx);
+static void free_wstream(si_ctx* ctx);
+
 extern "C" {
 
 int32_t si_version(void) { return 300; }
@@ -236,6 +236,8 @@ int32_t si_destroy(si_ctx* ctx) {
   free_construct(ctx);
   free_infer(ctx);
   dev_free(ctx->d_wstage);
+  free_push_staging(ctx);
+  free_wstream(ctx);
   dev_free(ctx->d_nvals);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   for (int b = 0; b < 2; ++b) {
@@ -434,26 +436,51 @@ int32_t si_construct_push_batch_dev(si_ctx* ctx, const void* w_dev, int32_t w_dt
   return SI_OK;
 }
 
+// Host snapshots (the Julia wrapper's default path: `W = extract_params(ps)` lives in pageable host memory and is only
+// valid during the call).  Pipelined over two pinned staging buffers and two device buffers: the call copies the snapshot
+// into pinned memory with the host copy pool (host_copy.cpp), queues H2D + K1 on the stream and RETURNS -- the DMA and
+// the kernel overlap the caller's next gradient / update!; the only wait is for the staging buffer of two pushes ago.
+static void free_push_staging(si_ctx* ctx) {
+  for (int b = 0; b < 2; ++b) {
+    if (ctx->h_wpin[b]) (void)hipHostFree(ctx->h_wpin[b]);
+    ctx->h_wpin[b] = nullptr;
+    dev_free(ctx->d_wpush[b]);
+    if (ctx->ev_wpin[b]) (void)hipEventDestroy(ctx->ev_wpin[b]);
+    ctx->ev_wpin[b] = nullptr;
+    ctx->wpin_busy[b] = false;
+  }
+  ctx->wpin_bytes = 0;
+}
+
 int32_t si_construct_push(si_ctx* ctx, const void* w_host, int32_t w_dtype, double n) {
   CHECK_CTX(ctx);
   if (!ctx->c_active) return fail(ctx, SI_ERR_STATE, "si_construct_push: call si_construct_begin first");
   if (!w_host || (w_dtype != SI_F32 && w_dtype != SI_F64))
     return fail(ctx, SI_ERR_INVALID, "si_construct_push: bad pointer or dtype");
+  if (ctx->max_cols == 0 && ctx->K >= ctx->Kcap) return fail(ctx, SI_ERR_STATE, "si_construct_push: more pushes than K_capacity");
   BIND(ctx);
   const size_t bytes = (size_t)ctx->N * (w_dtype == SI_F32 ? 4 : 8);
-  if (ctx->wstage_bytes < bytes) {
+  if (ctx->wpin_bytes < bytes) {
     SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    dev_free(ctx->d_wstage);
-    if (hipMalloc(&ctx->d_wstage, bytes) != hipSuccess) {
-      ctx->wstage_bytes = 0;
-      return fail(ctx, SI_ERR_NOMEM, "si_construct_push: staging allocation failed");
+    free_push_staging(ctx);
+    for (int b = 0; b < 2; ++b) {
+      if (hipHostMalloc(&ctx->h_wpin[b], bytes, hipHostMallocDefault) != hipSuccess ||
+          hipMalloc(&ctx->d_wpush[b], bytes) != hipSuccess ||
+          hipEventCreateWithFlags(&ctx->ev_wpin[b], hipEventDisableTiming) != hipSuccess) {
+        free_push_staging(ctx);
+        return fail(ctx, SI_ERR_NOMEM, "si_construct_push: staging allocation failed");
+      }
     }
-    ctx->wstage_bytes = bytes;
+    ctx->wpin_bytes = bytes;
   }
-  // the host buffer is only valid during this call (Julia GC.@preserve), so the copy is synchronous
-  SI_HIP(ctx, hipMemcpyAsync(ctx->d_wstage, w_host, bytes, hipMemcpyHostToDevice, ctx->stream));
-  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return push_common(ctx, ctx->d_wstage, w_dtype, n);
+  const int b = (int)(ctx->wpin_next & 1);
+  ctx->wpin_next += 1;
+  if (ctx->wpin_busy[b]) SI_HIP(ctx, hipEventSynchronize(ctx->ev_wpin[b]));  // the H2D of two pushes ago has read this buffer
+  host_copy(ctx->h_wpin[b], w_host, bytes);
+  SI_HIP(ctx, hipMemcpyAsync(ctx->d_wpush[b], ctx->h_wpin[b], bytes, hipMemcpyHostToDevice, ctx->stream));
+  SI_HIP(ctx, hipEventRecord(ctx->ev_wpin[b], ctx->stream));
+  ctx->wpin_busy[b] = true;
+  return push_common(ctx, ctx->d_wpush[b], w_dtype, n);  // K1 of this push is ordered before the H2D of push + 2 on the stream
 }
 
 int32_t si_construct_gram(si_ctx* ctx) {
@@ -1435,22 +1462,66 @@ int32_t si_predict(si_ctx* ctx, const double* Z, int32_t C, const double* Xnew, 
   return SI_OK;
 }
 
-int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0, int32_t nchains,
-                       double* Z_out, double* lp_out, double* accept_rate_out) {
+// ---- streamed output map (a13, src/space_inference.jl:125: `map(z -> W_swa + P*z.params, chm)`) ------------------------
+// K4 has already produced W_swa + P z' for every proposal (d_w); the weight vector of sample t is that vector when the
+// proposal was accepted and the previous sample's otherwise.  A select kernel keeps the CURRENT weights of every chain in
+// a small device ring (8 bytes read + 8 written per weight, ~4 us at cfg2 -- instead of a second K4 pass over P), a DMA
+// on the second stream moves ring slot t into pinned memory while transition t+1 computes, and the host copy pool
+// moves it into the caller's array R-1 transitions later.  The chain never waits for PCIe.
+static constexpr int SI_WRING = 4;
+
+static void free_wstream(si_ctx* ctx) {
+  dev_free(ctx->d_wring);
+  dev_free(ctx->d_accflag);
+  for (int r = 0; r < SI_WRING; ++r) {
+    if (ctx->h_wring[r]) (void)hipHostFree(ctx->h_wring[r]);
+    ctx->h_wring[r] = nullptr;
+    if (ctx->ev_wcomp[r]) (void)hipEventDestroy(ctx->ev_wcomp[r]);
+    if (ctx->ev_wcopy[r]) (void)hipEventDestroy(ctx->ev_wcopy[r]);
+    ctx->ev_wcomp[r] = ctx->ev_wcopy[r] = nullptr;
+  }
+  ctx->wring_N = 0;
+  ctx->wring_C = 0;
+}
+
+static int32_t ensure_wstream(si_ctx* ctx, int32_t C) {
+  const size_t need = (size_t)C * (size_t)pad_ld(ctx->iN);
+  if (!ctx->stream2) SI_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  if (ctx->wring_N == ctx->iN && ctx->wring_C >= C) return SI_OK;
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  free_wstream(ctx);
+  bool ok = dev_alloc(&ctx->d_wring, need * SI_WRING) == hipSuccess && dev_alloc(&ctx->d_accflag, (size_t)C) == hipSuccess;
+  for (int r = 0; r < SI_WRING && ok; ++r)
+    ok = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_wring[r]), (size_t)C * (size_t)ctx->iN * sizeof(double), hipHostMallocDefault) == hipSuccess &&
+         hipEventCreateWithFlags(&ctx->ev_wcomp[r], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&ctx->ev_wcopy[r], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    free_wstream(ctx);
+    return fail(ctx, SI_ERR_NOMEM, "si_sample_rwmh_weights: allocation of the weight ring / pinned staging failed");
+  }
+  ctx->wring_N = ctx->iN;
+  ctx->wring_C = C;
+  return SI_OK;
+}
+
+static int32_t sample_rwmh_impl(si_ctx* ctx, const char* who, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0,
+                                int32_t nchains, double* Z_out, double* lp_out, double* accept_rate_out, double* W_out) {
   CHECK_CTX(ctx);
-  if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_sample_rwmh: call si_infer_setup first");
+  if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, std::string(who) + ": call si_infer_setup first");
   if (itr <= 0 || nchains <= 0 || chain_id0 < 0 || !(sigma_z > 0.0))
-    return fail(ctx, SI_ERR_INVALID, "si_sample_rwmh: itr, nchains, sigma_z must be positive");
-  if (ctx->sw_Z) return fail(ctx, SI_ERR_STATE, "si_sample_rwmh: a step-wise RWMH session is open; its proposal / SSE buffers are shared (si_rwmh_end or si_rwmh_abort first)");
+    return fail(ctx, SI_ERR_INVALID, std::string(who) + ": itr, nchains, sigma_z must be positive");
+  if (ctx->sw_Z) return fail(ctx, SI_ERR_STATE, std::string(who) + ": a step-wise RWMH session is open; its proposal / SSE buffers are shared (si_rwmh_end or si_rwmh_abort first)");
   BIND(ctx);
   const int32_t C = nchains, M = ctx->iM;
+  const int64_t N = ctx->iN, ldw = pad_ld(N);
   int32_t rc = ensure_chains(ctx, C);
   if (rc != SI_OK) return rc;
+  if (W_out && (rc = ensure_wstream(ctx, C)) != SI_OK) return rc;
   double *dZ = nullptr, *dlp = nullptr;
   if (dev_alloc(&dZ, (size_t)M * itr * C) != hipSuccess || dev_alloc(&dlp, (size_t)itr * C) != hipSuccess) {
     dev_free(dZ);
     dev_free(dlp);
-    return fail(ctx, SI_ERR_NOMEM, "si_sample_rwmh: output allocation failed");
+    return fail(ctx, SI_ERR_NOMEM, std::string(who) + ": output allocation failed");
   }
   const double d = (double)ctx->out_dim * (double)ctx->B;
   const double c0 = mvnormal_c0(d, ctx->sigma_m), s2 = ctx->sigma_m * ctx->sigma_m;
@@ -1458,6 +1529,8 @@ int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, 
     ProfScope ps(ctx, SI_K_RWMH, 0, 0);
     launch_rwmh_init(ctx->stream, ctx->d_zcur, ctx->d_lpcur, ctx->d_nacc, ctx->d_steps, M, C);
   }
+  // the proposal weights of ALL chains are still in d_w at accept time only when one pass of launches carries them all
+  const bool select_path = W_out && C <= ctx->fw_slots;
   // one transition for all chains; the transition index is a device-side counter, so the launches are identical
   auto transition = [&]() -> int32_t {
     {
@@ -1469,20 +1542,53 @@ int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, 
     ProfScope ps(ctx, SI_K_RWMH, 0, 0);
     launch_rwmh_accept(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->d_lpcur, ctx->d_sse, ctx->d_nacc, M, C, c0, s2, seed,
                        chain_id0, ctx->d_steps, dZ, dlp, itr, ctx->sigma_p > 0.0 ? ctx->d_wsq : nullptr, prior_c0(ctx),
-                       ctx->sigma_p * ctx->sigma_p);
+                       ctx->sigma_p * ctx->sigma_p, select_path ? ctx->d_accflag : nullptr);
     return SI_OK;
+  };
+  hipError_t e = hipSuccess;
+  auto ring = [&](int64_t t) { return ctx->d_wring + (size_t)(t % SI_WRING) * (size_t)C * (size_t)ldw; };
+  auto drain = [&](int64_t u) {   // sample u of every chain: pinned slot -> the caller's (pageable) N x itr x C array
+    const int r = (int)(u % SI_WRING);
+    hipError_t w = hipEventSynchronize(ctx->ev_wcopy[r]);
+    for (int c = 0; c < C && w == hipSuccess; ++c)
+      host_copy(W_out + (size_t)N * ((size_t)u + (size_t)itr * c), ctx->h_wring[r] + (size_t)c * N, (size_t)N * sizeof(double));
+    return w;
   };
   // Replaying one captured transition as a hipGraph was measured and dropped: the README-toy transition takes 27.8 us
   // graphed vs 25.7 us eager -- it is bound by the serial latency of its 8 dependent small kernels, not by host
   // launches -- and at cfg2 a transition is 3.3 ms of kernel time.
-  for (int64_t t = 0; t < itr && rc == SI_OK; ++t) rc = transition();
-  if (rc != SI_OK) {
+  for (int64_t t = 0; t < itr && rc == SI_OK && e == hipSuccess; ++t) {
+    rc = transition();
+    if (rc != SI_OK || !W_out) continue;
+    const int r = (int)(t % SI_WRING);
+    if (t >= SI_WRING) e = hipStreamWaitEvent(ctx->stream, ctx->ev_wcopy[r], 0);  // the DMA of sample t - R has read this slot
+    if (e != hipSuccess) break;
+    {
+      ProfScope ps(ctx, SI_K_RECON, 0.0, 16.0 * (double)N * C);
+      if (select_path)
+        launch_weights_select(ctx->stream, ctx->d_accflag, ctx->d_w, ldw, t > 0 ? ring(t - 1) : nullptr, ring(t), ldw, N, C, ctx->num_cu);
+      else  // more chains than one pass of launches carries: K4 on the current states (same kernel, same bits)
+        launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, ctx->d_zcur, C, ring(t), ldw, ctx->num_cu);
+    }
+    e = hipEventRecord(ctx->ev_wcomp[r], ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream2, ctx->ev_wcomp[r], 0);
+    if (e == hipSuccess)
+      e = hipMemcpy2DAsync(ctx->h_wring[r], (size_t)N * sizeof(double), ring(t), (size_t)ldw * sizeof(double), (size_t)N * sizeof(double),
+                           (size_t)C, hipMemcpyDeviceToHost, ctx->stream2);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_wcopy[r], ctx->stream2);
+    if (e == hipSuccess && t >= SI_WRING - 1) e = drain(t - (SI_WRING - 1));   // frees the pinned slot sample t + 1 will use
+  }
+  if (rc == SI_OK && e == hipSuccess && W_out)
+    for (int64_t u = std::max<int64_t>(0, itr - (SI_WRING - 1)); u < itr && e == hipSuccess; ++u) e = drain(u);
+  if (W_out) (void)hipStreamSynchronize(ctx->stream2);
+  if (rc != SI_OK || e != hipSuccess) {
     (void)hipStreamSynchronize(ctx->stream);
     dev_free(dZ);
     dev_free(dlp);
-    return rc;
+    if (rc != SI_OK) return rc;
+    return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
   }
-  hipError_t e = hipGetLastError();
+  e = hipGetLastError();
   std::vector<int64_t> nacc((size_t)C);
   if (e == hipSuccess && Z_out)
     e = hipMemcpyAsync(Z_out, dZ, (size_t)M * itr * C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
@@ -1493,11 +1599,22 @@ int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, 
   hipError_t e2 = hipStreamSynchronize(ctx->stream);
   dev_free(dZ);
   dev_free(dlp);
-  if (e != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string("si_sample_rwmh: ") + hipGetErrorString(e));
-  if (e2 != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string("si_sample_rwmh: ") + hipGetErrorString(e2));
+  if (e != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e2));
   if (accept_rate_out)
     for (int c = 0; c < C; ++c) accept_rate_out[c] = itr > 1 ? (double)nacc[(size_t)c] / (double)(itr - 1) : 0.0;
   return SI_OK;
+}
+
+int32_t si_sample_rwmh(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0, int32_t nchains,
+                       double* Z_out, double* lp_out, double* accept_rate_out) {
+  return sample_rwmh_impl(ctx, "si_sample_rwmh", itr, sigma_z, seed, chain_id0, nchains, Z_out, lp_out, accept_rate_out, nullptr);
+}
+
+int32_t si_sample_rwmh_weights(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0, int32_t nchains,
+                               double* Z_out, double* lp_out, double* accept_rate_out, double* W_out) {
+  if (ctx && !W_out) return fail(ctx, SI_ERR_INVALID, "si_sample_rwmh_weights: W_out is NULL (use si_sample_rwmh)");
+  return sample_rwmh_impl(ctx, "si_sample_rwmh_weights", itr, sigma_z, seed, chain_id0, nchains, Z_out, lp_out, accept_rate_out, W_out);
 }
 
 // ---- step-wise RWMH: the same chain as si_sample_rwmh, but the SSE of every proposal passes through the caller
@@ -1613,40 +1730,6 @@ int32_t si_rwmh_end(si_ctx* ctx, double* Z_out, double* lp_out, double* accept_r
 // into one of two device buffers (compute stream) -> DMA into one of two PINNED staging buffers (copy stream) -> a few
 // host threads move the previous group from the staging buffer into the caller's (pageable, usually never-touched)
 // array (its first-touch page faults are spread over those threads too; a MADV_HUGEPAGE hint was tried and gained nothing).  A plain hipMemcpy into pageable memory does the last two steps on one thread: 0.79 ms per 8.4 MB sample.
-static void host_copy_parallel(double* dst, const double* src, size_t elems, int nthreads) {
-  if (nthreads <= 1 || elems < ((size_t)1 << 18)) {
-    std::memcpy(dst, src, elems * sizeof(double));
-    return;
-  }
-  std::vector<std::thread> th;
-  const size_t per = ((elems + nthreads - 1) / nthreads + 511) & ~(size_t)511;   // 4 KiB-granular slices
-  size_t done_to = std::min(elems, per);   // slices [per, done_to) are in the hands of helper threads
-  for (int t = 1; t < nthreads; ++t) {
-    const size_t lo = std::min(elems, per * t), hi = std::min(elems, per * (t + 1));
-    if (hi <= lo) break;
-    try {
-      th.emplace_back([=] { std::memcpy(dst + lo, src + lo, (hi - lo) * sizeof(double)); });
-      done_to = hi;
-    } catch (const std::system_error&) {   // no more threads to be had (process limit): this thread copies the rest
-      break;
-    }
-  }
-  std::memcpy(dst, src, std::min(elems, per) * sizeof(double));
-  if (done_to < elems) std::memcpy(dst + done_to, src + done_to, (elems - done_to) * sizeof(double));
-  for (auto& t : th) t.join();
-}
-
-static int host_copy_threads() {
-  static const int n = [] {
-    int avail = 1;
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) avail = CPU_COUNT(&set);
-    if (const char* e = getenv("SI_HOST_COPY_THREADS")) return std::max(1, atoi(e));
-    return std::max(1, std::min(8, avail / 2));
-  }();
-  return n;
-}
-
 int32_t si_reconstruct(si_ctx* ctx, const double* Z, int64_t C, double* W_out) {
   CHECK_CTX(ctx);
   if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, "si_reconstruct: call si_infer_setup first");
@@ -1657,7 +1740,6 @@ int32_t si_reconstruct(si_ctx* ctx, const double* Z, int64_t C, double* W_out) {
   // samples per pipeline stage: ~32 MB of output, at most 64 samples, and at least four stages when C allows it
   const int64_t group_cap = std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)32 << 20) / (N * 8)));   // sizes the buffers once per N
   const int64_t group = std::max<int64_t>(1, std::min<int64_t>((C + 3) / 4, group_cap));
-  const int nthreads = host_copy_threads();
   hipEvent_t ev_comp[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
   hipError_t e = hipSuccess;
   if (!ctx->stream2) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
@@ -1698,7 +1780,7 @@ int32_t si_reconstruct(si_ctx* ctx, const double* Z, int64_t C, double* W_out) {
     const int b = (int)(g & 1);
     const int64_t c0 = g * group, nc = std::min(group, C - c0);
     hipError_t w = hipEventSynchronize(ev_copy[b]);
-    if (w == hipSuccess) host_copy_parallel(W_out + c0 * N, hp[b], (size_t)N * (size_t)nc, nthreads);
+    if (w == hipSuccess) host_copy(W_out + c0 * N, hp[b], (size_t)N * (size_t)nc * sizeof(double));
     return w;
   };
   const int64_t ngroups = (C + group - 1) / group;

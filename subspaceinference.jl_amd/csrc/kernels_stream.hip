@@ -336,7 +336,8 @@ __global__ void rwmh_accept_kernel(double* __restrict__ zcur, const double* __re
                                    int64_t* __restrict__ nacc, int32_t M, double c0, double sigma2,
                                    uint64_t seed, int32_t chain_id0, uint64_t* __restrict__ steps,
                                    double* __restrict__ Z_out, double* __restrict__ lp_out,
-                                   int64_t itr, const double* __restrict__ wsq, double c0p, double sigma_p2) {
+                                   int64_t itr, const double* __restrict__ wsq, double c0p, double sigma_p2,
+                                   int32_t* __restrict__ accflag) {
   const int c = blockIdx.x;
   const uint64_t step = steps[c];
   const uint32_t chain = (uint32_t)(chain_id0 + c);
@@ -364,7 +365,22 @@ __global__ void rwmh_accept_kernel(double* __restrict__ zcur, const double* __re
     lp_out[step + (uint64_t)itr * c] = lp_keep;
     if (accept && step > 0) nacc[c] += 1;
     steps[c] = step + 1;
+    if (accflag) accflag[c] = accept ? 1 : 0;
   }
+}
+
+// Output map (src/space_inference.jl:125) without a second K4 pass: K4 already produced W_swa + P z' for the proposal;
+// the chain's current weights are that vector when the proposal was kept, the previous sample's otherwise.
+__global__ __launch_bounds__(256) void weights_select_kernel(const int32_t* __restrict__ flag, const double* __restrict__ wprop,
+                                                             int64_t ldw, const double* __restrict__ prev, double* __restrict__ dst,
+                                                             int64_t ldd, int64_t N) {
+  const int c = blockIdx.y;
+  const double* src = (prev == nullptr || flag[c] != 0) ? wprop + (int64_t)c * ldw : prev + (int64_t)c * ldd;
+  double* out = dst + (int64_t)c * ldd;
+  const int64_t npair = (N + 1) >> 1;   // both buffers are padded to an even length (pad_ld)
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npair; p += stride)
+    *reinterpret_cast<double2*>(out + 2 * p) = *reinterpret_cast<const double2*>(src + 2 * p);
 }
 
 void launch_rwmh_init(hipStream_t st, double* zcur, double* lpcur, int64_t* nacc, uint64_t* steps, int32_t M, int32_t C) {
@@ -377,9 +393,15 @@ void launch_rwmh_propose(hipStream_t st, const double* zcur, double* zprop, int3
 void launch_rwmh_accept(hipStream_t st, double* zcur, const double* zprop, double* lpcur,
                         const double* sse, int64_t* nacc, int32_t M, int32_t C, double c0,
                         double sigma2, uint64_t seed, int32_t chain_id0, uint64_t* steps,
-                        double* Z_out, double* lp_out, int64_t itr, const double* wsq, double c0p, double sigma_p2) {
+                        double* Z_out, double* lp_out, int64_t itr, const double* wsq, double c0p, double sigma_p2,
+                        int32_t* accflag) {
   hipLaunchKernelGGL(rwmh_accept_kernel, dim3(C), dim3(64), 0, st, zcur, zprop, lpcur, sse, nacc, M, c0,
-                     sigma2, seed, chain_id0, steps, Z_out, lp_out, itr, wsq, c0p, sigma_p2);
+                     sigma2, seed, chain_id0, steps, Z_out, lp_out, itr, wsq, c0p, sigma_p2, accflag);
+}
+void launch_weights_select(hipStream_t st, const int32_t* flag, const double* wprop, int64_t ldw, const double* prev, double* dst,
+                           int64_t ldd, int64_t N, int32_t C, int num_cu) {
+  hipLaunchKernelGGL(weights_select_kernel, dim3(stream_grid((N + 1) >> 1, num_cu), C), dim3(256), 0, st, flag, wprop, ldw, prev, dst,
+                     ldd, N);
 }
 
 // g[i] -= w[i] * inv_s2   (gradient of the optional prior term -||w||^2 / (2 sigma_p^2))

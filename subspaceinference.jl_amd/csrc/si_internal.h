@@ -107,6 +107,13 @@ struct Ctx {
   size_t h_stage_cap = 0;
   double *d_stage[2] = {nullptr, nullptr}, *d_zstage[2] = {nullptr, nullptr};   // its device-side double buffer
   size_t d_stage_cap = 0, d_zstage_cap = 0;
+  // streamed output map (si_sample_rwmh_weights): device ring of the chains' CURRENT weights, pinned twin, events
+  double* d_wring = nullptr;
+  int32_t* d_accflag = nullptr;
+  double* h_wring[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_wcomp[4] = {nullptr, nullptr, nullptr, nullptr}, ev_wcopy[4] = {nullptr, nullptr, nullptr, nullptr};
+  int64_t wring_N = 0;
+  int32_t wring_C = 0;
   bool profiling = false;
   uint32_t prof_mask = 0xffffffffu;  // classes that get event pairs while profiling is on
   std::vector<EventPair> pending;
@@ -120,7 +127,14 @@ struct Ctx {
   int64_t npush = 0;
   double* d_swa = nullptr;    // N (padded) fp64
   double* d_A = nullptr;      // ldA x Kcap fp64, column-major; with max_cols>0 a ring of max_cols columns
-  void* d_wstage = nullptr;   // staging for host snapshots
+  void* d_wstage = nullptr;   // staging of si_construct_set_mean
+  // pipelined host pushes (si_construct_push): two pinned host buffers -> two device buffers, events mark the H2D of each
+  void* h_wpin[2] = {nullptr, nullptr};
+  void* d_wpush[2] = {nullptr, nullptr};
+  hipEvent_t ev_wpin[2] = {nullptr, nullptr};
+  bool wpin_busy[2] = {false, false};
+  size_t wpin_bytes = 0;
+  uint64_t wpin_next = 0;
   double* d_nvals = nullptr;  // per-push n values of a batched push
   int64_t nvals_cap = 0;
   size_t wstage_bytes = 0;
@@ -363,9 +377,16 @@ void launch_rwmh_accept(hipStream_t st, double* zcur, const double* zprop, doubl
                         const double* sse, int64_t* nacc, int32_t M, int32_t C, double c0,
                         double sigma2, uint64_t seed, int32_t chain_id0, uint64_t* steps,
                         double* Z_out, double* lp_out, int64_t itr, const double* wsq = nullptr, double c0p = 0.0,
-                        double sigma_p2 = 1.0);
+                        double sigma_p2 = 1.0, int32_t* accflag = nullptr /* per chain: 1 = this step's proposal was kept */);
+// current weights of every chain after a transition: dst[c] = flag[c] ? wprop[c] : prev[c]   (prev == nullptr: all kept)
+void launch_weights_select(hipStream_t st, const int32_t* flag, const double* wprop, int64_t ldw, const double* prev, double* dst,
+                           int64_t ldd, int64_t N, int32_t C, int num_cu);
 void launch_prior_grad(hipStream_t st, double* g, const double* w, int64_t n, double inv_s2, int num_cu);
 void launch_widen_f32(hipStream_t st, const float* src, double* dst, int64_t n, int num_cu);
+
+// host copy pool (host_copy.cpp): parallel memcpy between pageable caller arrays and pinned staging
+void host_copy(void* dst, const void* src, size_t bytes);
+int host_copy_threads();
 
 // host symmetric eigensolver (eig.cpp): a is n x n symmetric col-major, overwritten by eigenvectors
 // (columns), w gets eigenvalues ascending.  Returns 0 on success.

@@ -314,11 +314,14 @@ function sub_inference(in_model, data, W_swa, P; σ_z = 1.0, σ_m = 1.0, σ_p = 
     check(ctx, ccall((:si_infer_set_prior, LIB), Int32, (Ptr{Cvoid}, Float64), ctx.h, include_prior ? Float64(σ_p) : 0.0))
     if alg == :rwmh
         # :111-116 on the device: chain state, proposals (Philox) and accept decisions never leave the GPU
+        # ... and the output map (:125) streams out while the chain runs (K4's own output, selected on accept; the DMA and
+        # the host copy of sample t hide under transitions t+1 ..): no second pass over P, no PCIe wait at the end
         Z = Matrix{Float64}(undef, M, itr); lp = Vector{Float64}(undef, itr); acc = Ref{Float64}(0.0)
-        GC.@preserve Z lp check(ctx, ccall((:si_sample_rwmh, LIB), Int32,
-            (Ptr{Cvoid}, Int64, Float64, UInt64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
-            ctx.h, itr, σ_z, seed, chain_id, 1, Z, lp, acc))
-        return reconstruct(ctx, Z, N), lp
+        Wm = Matrix{Float64}(undef, N, itr)
+        GC.@preserve Z lp Wm check(ctx, ccall((:si_sample_rwmh_weights, LIB), Int32,
+            (Ptr{Cvoid}, Int64, Float64, UInt64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ptr{Float64}),
+            ctx.h, itr, σ_z, seed, chain_id, 1, Z, lp, acc, Wm))
+        return [Wm[:, t] for t in 1:itr], lp
     end
     density = DeviceDensity(ctx)
     ℓπ_grad(θ) = logdensity_grad(ctx, θ)
