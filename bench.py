@@ -60,6 +60,7 @@ B, M, K_SNAP = 100000, 20, 100
 SIGMA_Z, SIGMA_M = 0.1, 1.0
 PEAK_F64_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet; the guide's table has no f64 row -- DESIGN.md section 4)
 PEAK_HBM_GBS = 8000.0
+PMC_PROFILE = "r02_pmc_dense_main.json"   # rocprofv3 --pmc passes of the dominant kernel (sha-keyed to kernels_gemm.hip)
 CFG = {  # construct-only configurations
     "cfg2": dict(n=1047361, k=100, m=20),
     "cfg4": dict(n=5200266, k=200, m=20),
@@ -349,8 +350,8 @@ def run_chains(args, rk, real_stdout):
     import numpy as np
     import torch
     import subspaceinference_jl_amd as si
+    from subspaceinference_jl_amd import flux
     rank, world = rk.rank, rk.world
-    dev = torch.device("cuda", rk.local_rank)
     ctx = rk.attach(si.Context(rk.local_rank))
     n_seen = rk.count_ranks()
     table, n_par = layer_table(DIMS, ACTS)
@@ -368,6 +369,7 @@ def run_chains(args, rk, real_stdout):
     snaps[:, :n_par] = (w0[None, :] + torch.cumsum(steps, dim=0)).to(torch.float32)  # K x N fp32, random walk
     del steps
     torch.cuda.synchronize()
+    ns = np.arange(1, K_SNAP + 1, dtype=np.float64)   # T = 100 epochs, full batch, c = 1: n = i
 
     def barrier():
         ctx.synchronize()
@@ -375,68 +377,133 @@ def run_chains(args, rk, real_stdout):
         if rk.dist is not None:
             rk.dist.barrier()
 
-    # ---- subspace construction (K pushes + Gram + eig + project), results stay on the device
-    def construct():
+    # ---- subspace construction: K pushes + Gram + eig + project, results stay on the device.  Three ways in:
+    #   per_push  100 x si_construct_push_dev -- what api.subspace_construction / the .jl wrapper call once per batch
+    #             (si_train_push is this call on the device-resident Float32 weights); THE `construct_wall_ms`
+    #   batched   si_construct_push_batch_dev -- all K snapshots in one pass, W_swa in registers (bit-identical); an
+    #             OFFLINE entry point (snapshots collected first), reported as construct_wall_ms_batched
+    #   host      100 x si_construct_push from a pageable Float32 host vector (the .jl wrapper's default path: Zygote /
+    #             Flux step in Julia, extract_params, ccall), pipelined through pinned staging
+    base = snaps.data_ptr()
+
+    def construct(kind):
         ctx.construct_begin(n_par, K_SNAP)
-        # T=100 epochs, full batch, c=1: n = i.  The snapshots are device-resident, so they are pushed in one pass
-        # (bit-identical to K_SNAP single pushes, tests/test_gpu_parity.py::test_push_batch_equals_sequential)
-        ctx.construct_push_batch_dev(snaps.data_ptr(), 0, ldw, np.arange(1, K_SNAP + 1, dtype=np.float64))
+        if kind == "batched":
+            ctx.construct_push_batch_dev(base, 0, ldw, ns)
+        elif kind == "per_push":
+            for j in range(K_SNAP):
+                ctx.construct_push_dev(base + 4 * ldw * j, 0, ns[j])
+        else:
+            for j in range(K_SNAP):
+                ctx.construct_push(snaps_host[j], ns[j])
         return ctx.construct_finish(M, want_swa=False, want_p=False)
+
+    def wall3(kind):
+        runs = []
+        for _ in range(3):   # median of three back-to-back constructions, no event pairs
+            barrier()
+            t0 = time.perf_counter()
+            construct(kind)
+            ctx.synchronize()
+            runs.append((time.perf_counter() - t0) * 1e3)
+        return sorted(runs)[1], [round(t, 4) for t in runs]
     ctx.set_profiling(True)
-    construct()  # warm-up (allocations, code-object load)
+    construct("per_push")  # warm-up (allocations, code-object load)
     ctx.reset_stats()
-    construct()  # per-kernel breakdown (hipEvent pairs around every launch: ~5 us of stream time each)
+    construct("per_push")  # per-kernel breakdown (hipEvent pairs around every launch: ~5 us of stream time each)
     ctx.synchronize()
     cst = ctx.stats()
+    ctx.reset_stats()
+    construct("batched")
+    ctx.synchronize()
+    cst_b = ctx.stats()
     ctx.set_profiling(False)
-    construct_runs = []
-    for _ in range(3):   # the wall-clock figure, without the event pairs: median of three back-to-back constructions
-        barrier()
+    construct_ms, construct_runs = wall3("per_push")
+    construct_b_ms, construct_b_runs = wall3("batched")
+    host_push = None
+    if rank == 0:
+        snaps_host = snaps[:, :n_par].cpu().numpy()   # 100 pageable Float32 vectors (419 MB)
+        construct("host")                             # warm-up: pinned staging, copy pool
+        hruns, pruns = [], []
+        for _ in range(3):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            ctx.construct_begin(n_par, K_SNAP)
+            for j in range(K_SNAP):
+                ctx.construct_push(snaps_host[j], ns[j])
+            tq = time.perf_counter()                  # every push has RETURNED (the caller could be in its next step)
+            ctx.synchronize()
+            tp = time.perf_counter()
+            ctx.construct_finish(M, want_swa=False, want_p=False)
+            ctx.synchronize()
+            hruns.append((time.perf_counter() - t0) * 1e3)
+            pruns.append(((tp - t0) * 1e3, (tq - t0) * 1e3))
+        k = int(np.argsort(hruns)[1])
+        push_ms = pruns[k][0]
+        host_push = {"construct_host_push_ms": hruns[k], "runs": [round(t, 3) for t in hruns], "push_phase_ms": push_ms,
+                     "calls_returned_after_ms": pruns[k][1],
+                     "host_push_GBs": K_SNAP * n_par * 4 / (push_ms * 1e-3) / 1e9, "pcie_peak_GBs": 63.0,
+                     "note": "100 x si_construct_push of a pageable 4.19 MB Float32 vector: host copy pool -> pinned double "
+                             "buffer -> async H2D + K1, no synchronisation per push; then Gram + eig + projection"}
+        del snaps_host
+    # end to end through the drop-in call itself: subspace_construction(model, mse, data, ADAM; T = 100, M = 20) with the
+    # training step on the device (src/subspace_construction.jl:37-59 as a whole: 100 x [gradient + update! + push] + psvd)
+    e2e = None
+    if rank == 0:
+        wr = np.random.default_rng(1)
+        mdl = flux.Chain(*[flux.Dense(i, o, a, rng=wr) for i, o, a in zip(DIMS[:-1], DIMS[1:], ACTS)])
+        data = flux.DataLoader(x, y, batchsize=B)
         t0 = time.perf_counter()
-        construct()
+        si.subspace_construction(mdl, flux.mse, data, flux.ADAM(1e-3), T=K_SNAP, c=1, M=M, ctx=ctx, verbose=False,
+                                 device_training=True, keep_on_device=True)
         ctx.synchronize()
-        construct_runs.append((time.perf_counter() - t0) * 1e3)
-    construct_ms = sorted(construct_runs)[1]
+        e2e = (time.perf_counter() - t0) * 1e3
+    construct("per_push")   # the subspace the chains below sample in (rank 0's is broadcast when there are more ranks)
+    if rk.ctx is not None:
+        ctx.bcast_subspace(0, n_par, M)   # cfg3: (W_swa, P) device to device over RCCL inside the library, once
 
     # ---- sampling.  The timed region carries event pairs around the DOMINANT kernel only (roofline.achieved is its
     # live average launch duration); the per-class breakdown comes from a short untimed pass afterwards.
     ctx.infer_setup(table, n_par, M, None, None, x, y, SIGMA_M)
     ctx.set_profiling(True, classes=["dense_main"])
-    ctx.sample_rwmh(max(1, args.warmup), SIGMA_Z, seed=100 + rank, chain_id0=rank, want_z=False)
+    ctx.sample_rwmh(max(1, args.warmup), SIGMA_Z, seed=100, chain_id0=rank, want_z=False)
     barrier()
     ctx.reset_stats()
     t0 = time.perf_counter()
-    z, lp, acc = ctx.sample_rwmh(args.steps, SIGMA_Z, seed=100 + rank, chain_id0=rank)
+    z, lp, acc = ctx.sample_rwmh(args.steps, SIGMA_Z, seed=100, chain_id0=rank)
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     st = ctx.stats()
-    dt = rk.max_over_ranks(dt, dev)
+    dt = rk.max_over_ranks(dt_local)
     value = n_seen * args.steps / dt
+    per_rank_ms = rk.gather_floats(dt_local / args.steps * 1e3)
+    lp_per_rank = rk.gather_floats(float(lp[-1, 0]))
+    ctx.set_profiling(False)
+    # the same K transitions WITH the reference's output map (a13, src/space_inference.jl:125): every weight sample
+    # delivered to a fresh pageable host array while the chain runs -- what the drop-in sub_inference call does
+    barrier()
+    t0 = time.perf_counter()
+    zw, lpw, _, wmap = ctx.sample_rwmh_weights(args.steps, SIGMA_Z, seed=100, chain_id0=rank)
+    barrier()
+    dt_map = rk.max_over_ranks(time.perf_counter() - t0)
+    map_ok = bool(np.array_equal(zw, z) and np.array_equal(wmap[:, -1, 0], ctx.reconstruct(z[:, -1:, 0])[:, 0]))
+    del wmap
+    # one long chain, reported beside `value`: itr = 1000 is what BASELINE's cfg2 names; a short --steps run is corroborated
+    barrier()
+    t0 = time.perf_counter()
+    ctx.sample_rwmh(1000, SIGMA_Z, seed=100, chain_id0=rank, want_z=False)
+    barrier()
+    dt_1000 = rk.max_over_ranks(time.perf_counter() - t0)
     bsteps = 20
     ctx.set_profiling(True)
     ctx.reset_stats()
-    ctx.sample_rwmh(bsteps, SIGMA_Z, seed=100 + rank, chain_id0=rank, want_z=False)
+    ctx.sample_rwmh(bsteps, SIGMA_Z, seed=100, chain_id0=rank, want_z=False)
     ctx.synchronize()
     bst = ctx.stats()
     ctx.set_profiling(False)
 
-    # ---- the reference's output map a13 (src/space_inference.jl:125): W_swa + P*z for every sample, delivered to the
-    # host like the reference's Vector{Vector{Float64}} -- NOT part of `value` (api.sub_inference does it on request)
     extras = {}
     if rank == 0:
-        nmap = min(args.steps, 32)
-        zz = np.asfortranarray(z[:, :nmap, 0])
-        ctx.reconstruct(zz[:, :2])
-        tmap = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            wmap = ctx.reconstruct(zz)   # a fresh (never touched) N x nmap array each time, like the reference's map
-            tmap.append((time.perf_counter() - t0) / nmap * 1e3)
-            del wmap                     # (outside the timed region: unmapping 268 MB takes longer than producing it)
-        extras["output_map_ms_per_sample"] = sorted(tmap)[1]
-        extras["output_map_ms_per_sample_runs"] = [round(t, 4) for t in tmap]
-        extras["output_map_note"] = ("a13: one K4 pass + %d-byte D2H per sample into a fresh pageable array, pipelined through pinned staging (%d samples timed); "
-                                     "excluded from `value`, which times the chain itself" % (8 * n_par, nmap))
         # the "next" rows at the same workload (outside every timed region above)
         ctx.reset_stats()
         ctx.set_profiling(True)
@@ -463,13 +530,13 @@ def run_chains(args, rk, real_stdout):
         avg_ms = dm["ms"] / max(1, dm["launches"])
         fl = dm["flops"] / max(1, dm["launches"])
         achieved = fl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic("r02_pmc_dense_main.json", ["kernels_gemm.hip"])
+        traffic, traffic_src = pmc_traffic(PMC_PROFILE, ["kernels_gemm.hip"])
         ms_step = dt / args.steps * 1e3
         step_flops = 2.0 * B * sum(a * b for a, b in zip(DIMS[:-1], DIMS[1:]))
         step_tflops = step_flops / (ms_step * 1e-3) / 1e12
 
-        def frac(cls, bound):
-            v = cst[cls]
+        def frac(stats, cls, bound):
+            v = stats[cls]
             if v["ms"] <= 0:
                 return None
             if bound == "hbm":
@@ -484,11 +551,29 @@ def run_chains(args, rk, real_stdout):
             "config": {"workload": "cfg2: Chain(Dense(128,960,relu),Dense(960,960,relu),Dense(960,1)) N=1047361, "
                                    "X 128x100000 Y 1x100000 fp64, M=20, K=100 fp32 snapshots, RWMH sigma_z=0.1 sigma_m=1",
                        "chains_per_gpu": 1, "mode": "chains",
-                       "parallelism": "independent chains x%d (one per GPU), no data-path collective" % n_seen},
-            "construct_wall_ms": construct_ms, "construct_wall_ms_runs": [round(t, 4) for t in construct_runs],
+                       "parallelism": "independent chains x%d (one per GPU; chain id = rank), subspace broadcast once over RCCL "
+                                      "inside the library, no data-path collective per step" % n_seen},
+            "value_with_output_map": n_seen * args.steps / dt_map,
+            "output_map_note": "the same %d transitions through si_sample_rwmh_weights (what sub_inference calls): every weight "
+                               "sample (8.4 MB) streamed to a fresh pageable host array under the following transitions; "
+                               "bit-identical to si_reconstruct: %s" % (args.steps, map_ok),
+            "chain_1000_steps_samples_per_s": n_seen * 1000 / dt_1000,
+            "per_rank_ms_per_step": [round(t, 4) for t in per_rank_ms], "lp_last_per_rank": lp_per_rank,
+            "chains_are_independent": bool(len(set(lp_per_rank)) == len(lp_per_rank)),
+            "construct_wall_ms": construct_ms, "construct_wall_ms_runs": construct_runs,
+            "construct_wall_ms_note": "100 x si_construct_push_dev (one K1 launch per batch, the entry point api.py / the .jl "
+                                      "wrapper use) + Gram + host eigensolve + projection",
+            "construct_wall_ms_batched": construct_b_ms, "construct_wall_ms_batched_runs": construct_b_runs,
+            "construct_host_push": host_push,
+            "construct_end_to_end_ms": e2e,
+            "construct_end_to_end_note": "subspace_construction(model, mse, DataLoader(batchsize = B), ADAM; T = 100, M = 20) through "
+                                         "api.py with the training step on the device: 100 x [forward + reverse sweep + ADAM + K1] + psvd, "
+                                         "incl. the one-off upload of X, Y and the weights",
             "construct_device_ms": {k: round(cst[k]["ms"], 4) for k in ("push", "gram", "gram_reduce", "project")},
+            "construct_device_ms_batched": {k: round(cst_b[k]["ms"], 4) for k in ("push", "gram", "gram_reduce", "project")},
             "construct_host_eig_ms": round(cst["eig_host"]["ms"], 4),
-            "construct_roofline": {"push": frac("push", "hbm"), "gram": frac("gram", "mfma"), "project": frac("project", "hbm")},
+            "construct_roofline": {"push": frac(cst, "push", "hbm"), "push_batched": frac(cst_b, "push", "hbm"),
+                                   "gram": frac(cst, "gram", "mfma"), "project": frac(cst, "project", "hbm")},
             "sample_device_ms_per_step": {k: round(bst[k]["ms"] / bsteps, 4) for k in ("reconstruct", "dense", "sse", "rwmh")},
             "accept_rate": float(acc[0]), "lp_last": float(lp[-1, 0]),
             "roofline": {"kernel": "dense_f64_kernel<96,128> layer 960x960 + fused 960->1 tail (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
@@ -502,8 +587,8 @@ def run_chains(args, rk, real_stdout):
             "next_rows": extras,
         }
         if n_seen == 1 and not args.no_cpu_baseline:
-            # W_swa / P of the construction just timed, brought to the host only for the CPU leg (outside all timers)
-            w_swa, p, _, _ = ctx.construct_finish(M)
+            # W_swa / P the chains sampled in, brought to the host only for the CPU leg (outside all timers)
+            w_swa, p, _ = ctx.construct_get_result()
             cb, lp_cpu = cpu_baseline(table, w_swa, p, x, y, z[:, 0, 0], args.cpu_budget)
             out["cpu_baseline"] = cb
             out["parity_lp_rel_err_vs_oracle"] = abs(lp_cpu - float(lp[0, 0])) / abs(lp_cpu)
