@@ -305,10 +305,20 @@ def _layer_backward(row, wflat, h_in, h_out, g_out, gw):
         g4 = g_out.reshape(y4.shape, order="F")
         gx = np.zeros_like(x4)
         wo, ho = y4.shape[:2]
-        for a in range(win[0]):       # every element equal to its window's maximum receives the gradient [upstream NNlib ∇maxpool]
-            for d in range(win[1]):
+        # [upstream NNlib 0.7.23 src/impl/pooling_direct.jl, `∇maxpool_direct!`, from memory]: for each output element the
+        # window is walked `for kd in 1:kernel_d, kh in 1:kernel_h, kw in 1:kernel_w` (kw FASTEST) and the gradient goes to
+        # the FIRST input with `y_idx ≈ x[...] && !maxpool_already_chosen` -- one element per window, chosen by
+        # `isapprox` (rtol = sqrt(eps), atol = 0), not every element equal to the maximum.
+        chosen = np.zeros(y4.shape, dtype=bool)
+        rtol = math.sqrt(np.finfo(np.float64).eps)
+        for d in range(win[1]):           # kh (outer)
+            for a in range(win[0]):       # kw (inner, fastest)
                 sl = (slice(a, a + (wo - 1) * stride[0] + 1, stride[0]), slice(d, d + (ho - 1) * stride[1] + 1, stride[1]))
-                gx[sl] += g4 * (x4[sl] == y4)
+                xv = x4[sl]
+                approx = (xv == y4) | (np.isfinite(xv) & np.isfinite(y4) & (np.abs(xv - y4) <= rtol * np.maximum(np.abs(xv), np.abs(y4))))
+                hit = approx & ~chosen
+                gx[sl] += g4 * hit
+                chosen |= hit
         return gx.reshape((-1, bsz), order="F")
     if row[0] == "conv":
         _, (kw, kh, cin, cout), (wi, hi), stride, pad, dil, act, w_off, b_off = row
@@ -340,6 +350,80 @@ def _layer_backward(row, wflat, h_in, h_out, g_out, gw):
 def reconstruct(w_swa, p, z):
     """src/space_inference.jl:91 and :125  `W_swa + P*z`."""
     return w_swa + p @ z
+
+
+# --------------------------------------------------------------------------- training step (SURVEY 8 f1)
+FLUX_EPS = 1e-8   # [upstream Flux 0.11.2 src/optimise/optimisers.jl: `const ϵ = 1e-8`]
+
+
+def mse_value_and_grad(table, w64, x, y):
+    """src/subspace_construction.jl:39-42 for `cost(m, x, y) = Flux.Losses.mse(m(x), y)`:
+        gs = gradient(ps) do training_loss = cost(model, d...) end
+    [upstream Flux 0.11.2 `mse(ŷ, y; agg = mean) = agg((ŷ .- y).^2)`; Zygote 0.5.17 reverse mode].  The Float32
+    parameters meet Float64 data, so every product promotes to Float64 and the gradient comes back as Float64 arrays
+    (Zygote 0.5 does not project it onto the parameter's eltype).  Returns (loss, flat gradient in extract_params order)."""
+    hs = [x]
+    for row in table:
+        hs.append(_layer_forward(row, w64, hs[-1]))
+    diff = hs[-1] - y
+    loss = float(np.mean(diff * diff))
+    gw = np.zeros_like(w64)
+    g = (2.0 / diff.size) * diff
+    for l in range(len(table) - 1, -1, -1):
+        g = _layer_backward(table[l], w64, hs[l], hs[l + 1], g, gw)
+    return loss, gw
+
+
+def optimiser_state(n, opt):
+    """`zero(x)` state of a fresh optimiser, flat over the parameter vector: Float32 like the parameters
+    [upstream Flux 0.11.2: Momentum `get!(o.velocity, x, zero(x))`; ADAM `get!(o.state, x, (zero(x), zero(x), β))`]."""
+    kind = opt[0]
+    st = {"m": np.zeros(n, dtype=np.float32), "v": np.zeros(n, dtype=np.float32), "bp": None}
+    if kind == "adam":
+        st["bp"] = [float(opt[2]), float(opt[3])]
+    return st
+
+
+def apply_update(w32, state, g64, opt):
+    """src/subspace_construction.jl:43 `Flux.update!(opt, ps, gs)` [upstream Flux 0.11.2 src/optimise/{train,optimisers}.jl]:
+
+        update!(opt, x, x̄) = (x .-= apply!(opt, x, x̄))                 # per parameter array; flat here (elementwise rules)
+        apply!(o::Descent, x, Δ)   = (Δ .*= o.eta)
+        apply!(o::Momentum, x, Δ)  = (v = get!(o.velocity, x, zero(x)); @. v = ρ * v - η * Δ; @. Δ = -v)
+        apply!(o::ADAM, x, Δ)      = (mt, vt, βp = get!(o.state, x, (zero(x), zero(x), β));
+                                      @. mt = β[1] * mt + (1 - β[1]) * Δ;  @. vt = β[2] * vt + (1 - β[2]) * Δ^2;
+                                      @. Δ = mt / (1 - βp[1]) / (√(vt / (1 - βp[2])) + ϵ) * η;  o.state[x] = (mt, vt, βp .* β))
+
+    η, ρ, β are Float64 fields; x and the state are Float32 arrays, Δ is Float64: every broadcast computes in Float64 and
+    ROUNDS ONCE on the store into the Float32 array (v, mt, vt, and x itself); ADAM's step reads the stored (rounded) mt,
+    vt.  No fused multiply-add (Julia does not contract `a * b + c`).  opt = ("descent", η) | ("momentum", η, ρ) |
+    ("adam", η, β1, β2).  Updates w32 / state in place."""
+    kind = opt[0]
+    eta = np.float64(opt[1])
+    if kind == "descent":
+        step = g64 * eta
+    elif kind == "momentum":
+        rho = np.float64(opt[2])
+        state["m"][...] = (rho * state["m"].astype(np.float64) - eta * g64).astype(np.float32)
+        step = -state["m"].astype(np.float64)
+    elif kind == "adam":
+        b1, b2 = np.float64(opt[2]), np.float64(opt[3])
+        bp = state["bp"]
+        state["m"][...] = (b1 * state["m"].astype(np.float64) + (1.0 - b1) * g64).astype(np.float32)
+        state["v"][...] = (b2 * state["v"].astype(np.float64) + (1.0 - b2) * (g64 * g64)).astype(np.float32)
+        step = state["m"].astype(np.float64) / (1.0 - bp[0]) / (np.sqrt(state["v"].astype(np.float64) / (1.0 - bp[1])) + FLUX_EPS) * eta
+        state["bp"] = [bp[0] * float(b1), bp[1] * float(b2)]
+    else:
+        raise ValueError(kind)
+    w32[...] = (w32.astype(np.float64) - step).astype(np.float32)
+
+
+def train_step(table, w32, state, x, y, opt):
+    """One pass of the reference's loop body, src/subspace_construction.jl:39-43: Zygote gradient of the mse cost on the
+    batch (x, y), then Flux.update!.  Returns the loss BEFORE the update (Zygote's forward value, `training_loss`)."""
+    loss, g = mse_value_and_grad(table, w32.astype(np.float64), x, y)
+    apply_update(w32, state, g, opt)
+    return loss
 
 
 # --------------------------------------------------------------------------- sampler

@@ -51,10 +51,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+DEV_LIB = os.path.join(os.path.dirname(HERE), "tools", "bin", "libsubspace_hip_dev.so")
+
+
+def build(force=False, verbose=False, dev=False):
+    """dev=True: the DEVELOPMENT build (-DSI_DEV_KNOBS: the alternative kernels and SI_* environment knobs behind the
+    measurements quoted in DESIGN.md) into tools/bin/libsubspace_hip_dev.so -- never loaded by the package."""
     hipcc = _hipcc()
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build_dev" if dev else "build")
     os.makedirs(objdir, exist_ok=True)
+    lib = DEV_LIB if dev else LIB
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs, jobs = [], []
     for entry in SOURCES:
@@ -64,7 +71,7 @@ def build(force=False, verbose=False):
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
             jobs.append([hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-                         "-c", s, "-o", o] + extra)
+                         "-c", s, "-o", o] + extra + (["-DSI_DEV_KNOBS"] if dev else []))
 
     def run(cmd):
         if verbose:
@@ -74,13 +81,14 @@ def build(force=False, verbose=False):
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) - 1), 8)) as ex:
             list(ex.map(run, jobs))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(verbose=True))
+    import sys
+    print(build(verbose=True, dev="--dev" in sys.argv))

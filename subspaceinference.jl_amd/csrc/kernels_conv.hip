@@ -672,7 +672,25 @@ void launch_maxpool(hipStream_t st, const double* In, double* Out, int Cp, int W
   hipLaunchKernelGGL(maxpool_kernel, dim3(idx_grid((int64_t)Cp * Wo * Ho * B)), dim3(256), 0, st, In, Out, Cp, Wi, Hi, Wo, Ho, PW,
                      PH, sw, sh, B);
 }
-// every input element equal to the maximum of a window it belongs to receives that window's gradient [upstream NNlib]
+// MaxPool gradient [upstream NNlib 0.7.23 src/impl/pooling_direct.jl `∇maxpool_direct!`, from memory]: for each window the
+// inputs are walked `for kh in 1:kernel_h, kw in 1:kernel_w` (kw fastest) and the window's gradient goes to the FIRST input
+// with `y ≈ x` (`maxpool_already_chosen`; isapprox: rtol = sqrt(eps), atol = 0) -- ONE element per window, not every
+// element equal to the maximum: exact ties (constant image regions -> conv output = bias) would otherwise count 4 times.
+__device__ __forceinline__ bool pool_approx(double x, double y) {
+  return x == y || (isfinite(x) && isfinite(y) && fabs(x - y) <= 1.4901161193847656e-08 * fmax(fabs(x), fabs(y)));
+}
+// does input (a, d) of the window whose first input is at `win0` (element stride `es`, row stride `rs`) receive the
+// window's gradient?  x = that input's value, ymax = the window's stored maximum
+__device__ __forceinline__ bool pool_chosen(const double* __restrict__ win0, int64_t es, int64_t rs, double x, double ymax, int a,
+                                            int d, int PW) {
+  if (!pool_approx(ymax, x)) return false;
+  for (int dd = 0; dd <= d; ++dd) {
+    const int alim = dd == d ? a : PW;
+    for (int aa = 0; aa < alim; ++aa)
+      if (pool_approx(ymax, win0[es * aa + rs * dd])) return false;   // an earlier input already took it
+  }
+  return true;
+}
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const double* __restrict__ In, const double* __restrict__ Out,
                                                           const double* __restrict__ Gout, double* __restrict__ Gin, int Cp, int Wi,
                                                           int Hi, int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B) {
@@ -694,7 +712,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const double* __restri
       for (int wo = wo_hi; wo >= 0 && wo * sw + PW > wi; --wo) {
         if (wo >= Wo) continue;
         const int64_t o = c + (int64_t)Cp * (wo + (int64_t)Wo * (ho + (int64_t)Ho * n));
-        if (Out[o] == x) gsum += Gout[o];
+        const double* win0 = In + c + (int64_t)Cp * ((wo * sw) + (int64_t)Wi * ((ho * sh) + (int64_t)Hi * n));
+        if (pool_chosen(win0, Cp, (int64_t)Cp * Wi, x, Out[o], wi - wo * sw, hi - ho * sh, PW)) gsum += Gout[o];
       }
     }
     Gin[e] = gsum;
@@ -753,13 +772,14 @@ __global__ __launch_bounds__(256) void dact_rowsum_kernel(const double* __restri
       const double x = H[off];
       double g;
       if constexpr (POOL) {
-        g = 0.0;  // every input equal to the maximum of a window it belongs to receives that window's gradient [upstream NNlib]
+        g = 0.0;  // the first input (kw fastest) that is ≈ the window's maximum receives its gradient [upstream NNlib, pool_chosen]
         for (int ho = hi / sh; ho >= 0 && ho * sh + PH > hi; --ho) {
           if (ho >= Ho) continue;
           for (int wo = wi / sw; wo >= 0 && wo * sw + PW > wi; --wo) {
             if (wo >= Wo) continue;
             const int64_t o = i + (int64_t)rows * (wo + (int64_t)Wo * (ho + (int64_t)Ho * n));
-            if (PoolOut[o] == x) g += G[o];
+            const double* win0 = H + i + (int64_t)rows * ((wo * sw) + (int64_t)Wi * ((ho * sh) + (int64_t)Hi * n));
+            if (pool_chosen(win0, rows, (int64_t)rows * Wi, x, PoolOut[o], wi - wo * sw, hi - ho * sh, PW)) g += G[o];
           }
         }
         wi += dw;

@@ -456,7 +456,7 @@ static bool gram_wave_dispatch(hipStream_t st, const double* A, int64_t ldA, int
   return true;
 }
 
-// development knob (tools/gram_bench.hip): SI_GRAM_PANELS=1 forces the 128-column panel kernels for every K
+#ifdef SI_DEV_KNOBS   // development build (tools/gram_bench.hip): SI_GRAM_PANELS=1 forces the 128-column panel kernels for every K
 static bool gram_force_panels() {
   static const bool v = [] {
     const char* e = getenv("SI_GRAM_PANELS");
@@ -464,6 +464,9 @@ static bool gram_force_panels() {
   }();
   return v;
 }
+#else
+static constexpr bool gram_force_panels() { return false; }
+#endif
 
 size_t launch_gram(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, double* Gpart,
                    double* G, int num_cu, Ctx* prof) {
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(256) void project_kernel(const double* __restrict__
   }
 }
 
-// development knob: SI_PROJECT_GEMM=1 keeps the generic GEMM for wide subspaces (comparison runs)
+#ifdef SI_DEV_KNOBS   // development build: SI_PROJECT_GEMM=1 keeps the generic GEMM for wide subspaces (comparison runs)
 static bool project_force_gemm() {
   static const bool v = [] {
     const char* e = getenv("SI_PROJECT_GEMM");
@@ -540,6 +543,9 @@ static bool project_force_gemm() {
   }();
   return v;
 }
+#else
+static constexpr bool project_force_gemm() { return false; }
+#endif
 
 int project_mpad(int M) {
   int m0 = 0;

@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64 * GW_WAVES, OCC) void gram_glds_kernel(const dou
 }
 
 
+#ifdef SI_DEV_KNOBS   // development build only (python build.py --dev): the variants behind the measurements in DESIGN.md section 4
 // ------------------------------------------------------------------------------------------------
 // Wave-specialised variant: the 4 MFMA waves (one per SIMD) issue NOTHING but LDS reads and MFMAs; NP extra PRODUCER
 // waves issue every LDS-DMA piece of the ring.  Why: a global_load_lds instruction holds the issuing wave for 60-190
@@ -519,9 +520,12 @@ static void launch_spec(hipStream_t st, const double* A, int64_t ldA, int64_t N,
   hipLaunchKernelGGL((gram_spec_kernel<NT, KS, NB, NP>), dim3(nblocks), dim3(64 * (GW_WAVES + NP)), lds, st, A, ldA, N, K, tiles, dbg);
 }
 
+#endif  // SI_DEV_KNOBS
+
 // Up to K = 144 two workgroups per CU (two ring buffers each; 8 * pairs-per-wave + ~90 registers <= 256) are the shipped
 // configuration: 0-6 % faster than one workgroup with a 4-deep ring (K = 100: 0.275 ms either way; K = 128: 2.22 against
-// 2.33 ms at N = 6.4 M; K = 144: 0.411 against 0.437 ms).  Development knob SI_GRAM_OCC1=1 selects the other one.
+// 2.33 ms at N = 6.4 M; K = 144: 0.411 against 0.437 ms).  (Development build: SI_GRAM_OCC1=1 selects the other one.)
+#ifdef SI_DEV_KNOBS
 static bool gram_two_per_cu() {
   static const bool v = [] {
     const char* e = getenv("SI_GRAM_OCC1");
@@ -529,6 +533,9 @@ static bool gram_two_per_cu() {
   }();
   return v;
 }
+#else
+static constexpr bool gram_two_per_cu() { return true; }
+#endif
 
 // KS / KS2: k-step split with one / two workgroups per CU (two per CU needs 8 * pairs-per-wave + ~90 registers <= 256)
 template <int NT, int KS, int KS2>
@@ -554,7 +561,9 @@ static void launch_nt(hipStream_t st, const double* A, int64_t ldA, int64_t N, i
 // workgroups per CU the launcher of this tile count will use (the caller sizes the grid and the partial-tile workspace)
 #if SI_GW_PART == 0
 int gram_wave_blocks_per_cu(int nt) {
+#ifdef SI_DEV_KNOBS
   if (gram_spec_enabled() && (nt == 7 || nt == 8)) return 1;
+#endif
   return (nt <= 9 && gram_two_per_cu()) ? 2 : 1;
 }
 #endif
@@ -570,17 +579,21 @@ bool launch_gram_wave_part0(hipStream_t st, const double* A, int64_t ldA, int64_
     case 5: launch_nt<5, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
     case 6: launch_nt<6, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0); return true;
     case 7:
+#ifdef SI_DEV_KNOBS
       if (gram_spec_enabled()) {
         launch_spec<7, 2, 5, 2>(st, A, ldA, N, K, tiles, nblocks);
         return true;
       }
+#endif
       launch_nt<7, 4, 2>(st, A, ldA, N, K, tiles, nblocks, 0);
       return true;
     case 8:
+#ifdef SI_DEV_KNOBS
       if (gram_spec_enabled()) {
         launch_spec<8, 2, 4, 2>(st, A, ldA, N, K, tiles, nblocks);
         return true;
       }
+#endif
       launch_nt<8, 2, 2>(st, A, ldA, N, K, tiles, nblocks, 0);
       return true;
     default: return false;

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(64 * PJ_WAVES, OCC) void project_glds_kernel(const 
 
 // Two workgroups per CU with two ring buffers each is the shipped configuration (cfg5 share: 1.92 ms against 2.20 ms for
 // one workgroup per CU with four buffers: one workgroup's barrier / issue gaps are the other's MFMA time);
-// development knob SI_PROJECT_OCC1=1 selects the other one for comparison runs
+// the development build's SI_PROJECT_OCC1=1 selects the other one for comparison runs
+#ifdef SI_DEV_KNOBS
 static bool project_two_per_cu() {
   static const bool v = [] {
     const char* e = getenv("SI_PROJECT_OCC1");
@@ -165,6 +166,9 @@ static bool project_two_per_cu() {
   }();
   return v;
 }
+#else
+static constexpr bool project_two_per_cu() { return true; }
+#endif
 
 template <int NT>
 static void launch_project_nt(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, const double* V, int Mpad, int m0,

@@ -95,7 +95,7 @@ struct Ctx {
   int comm_world = 0, comm_rank = 0;
   double* d_commtmp = nullptr;  // device scratch of the host-value collectives
 
-  // experiment knob SI_OVERLAP_HALVES=1: the two halves of the batch of ONE chain on two streams
+  // development build only (-DSI_DEV_KNOBS, SI_OVERLAP_HALVES=1): the two halves of the batch of ONE chain on two streams
   bool overlap_halves = false;
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;

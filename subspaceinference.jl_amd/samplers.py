@@ -62,39 +62,52 @@ def _kinetic(r, minv):
 
 
 def find_good_stepsize(logdensity_grad, z, lp, g, rng, eps=0.1, max_iter=100):
-    """AdvancedHMC 0.2.x `find_good_stepsize` (called at src/space_inference.jl:147) restated from its published
-    algorithm [upstream, unverifiable offline]: identity metric (it runs before any adaptation), ONE momentum draw,
-      1. crossing: double / halve eps until the one-leapfrog acceptance ratio exp(-dH) crosses a_cross = 0.5
-         (NOT Stan's / Hoffman & Gelman's 0.8 -- ADVICE r1), which leaves a bracket (eps, eps') one doubling apart;
-      2. bisection inside the bracket until a_min = 0.25 < ratio < a_max = 0.75.
+    """AdvancedHMC 0.2.27 `find_good_stepsize` (src/trajectory.jl; called at src/space_inference.jl:147) restated line by
+    line [upstream, from memory, unverifiable offline] -- INCLUDING its two quirks:
+      * identity metric (it runs before any adaptation), ONE momentum draw, start at eps = 0.1;
+      * direction = +1 when the one-leapfrog acceptance exp(dH) at eps is above a_cross = 0.5 (NOT Stan's 0.8), else -1;
+      * crossing loop: `eps' = direction == 1 ? 2 eps : eps / 2;  z', H' = A(h, z, eps)` -- the proposal is evaluated at
+        the OLD eps, one step behind the candidate eps' (upstream's code, reproduced as is); break when exp(dH) is no
+        longer on the starting side of a_cross, else eps = eps'.  Comparisons with a NaN dH are false, so a NaN energy
+        makes direction = -1 at the start and BREAKS the loop at once (no extra handling, as upstream);
+      * then (eps, eps') sorted and bisected until a_min = 0.25 <= exp(dH) <= a_max = 0.75 (a NaN lands in that branch and
+        is accepted, as upstream); after max_iter bisections the lower end is returned.
     The result seeds the dual averaging (mu = log 10 eps), so it matters most for short runs (n_adapts = itr / 2)."""
     a_min, a_cross, a_max = 0.25, 0.5, 0.75
     r = rng.standard_normal(z.size)
     h0 = lp - 0.5 * float(r @ r)
+    log_cross = math.log(a_cross)
 
     def delta_h(e):
         _, rp, lpp, _ = _leapfrog(logdensity_grad, z, r, g, e)
-        d = lpp - 0.5 * float(rp @ rp) - h0          # = H - H' : exp(d) is the MH ratio
-        return d if np.isfinite(d) else -np.inf
-    direction = 1 if delta_h(eps) > math.log(a_cross) else -1
+        return lpp - 0.5 * float(rp @ rp) - h0          # = H - H' : exp(d) is the MH ratio (may be NaN / -inf)
+
+    def ratio(d):
+        try:
+            return math.exp(d)
+        except OverflowError:
+            return math.inf
+    direction = 1 if delta_h(eps) > log_cross else -1
     eps_next = eps
     for _ in range(max_iter):
         eps_next = 2.0 * eps if direction == 1 else 0.5 * eps
-        d = delta_h(eps_next)
-        if (direction == 1 and not d > math.log(a_cross)) or (direction == -1 and not d < math.log(a_cross)):
+        d = delta_h(eps)                               # upstream evaluates at eps, not eps' (sic)
+        if direction == 1 and not d > log_cross:
+            break
+        if direction == -1 and not d < log_cross:
             break
         eps = eps_next
     lo, hi = (eps, eps_next) if eps < eps_next else (eps_next, eps)
     for _ in range(max_iter):
         mid = 0.5 * (lo + hi)
-        d = delta_h(mid)
-        a = math.exp(min(0.0, d)) if d > -np.inf else 0.0
+        a = ratio(delta_h(mid))
         if a > a_max:
             lo = mid
         elif a < a_min:
             hi = mid
         else:
-            return mid
+            lo = mid
+            break
     return lo
 
 

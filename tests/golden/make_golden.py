@@ -76,6 +76,23 @@ def main():
     np.savez_compressed(os.path.join(HERE, "cnn_density_rwmh.npz"), X=cx, Y=cy, W_swa=cw, P=cp, Z=czs, lp=clps, Yhat0=cyhat0,
                         grad1=cgrad, Z_chain=cz_chain, lp_chain=clp_chain, nacc=np.array(cnacc), seed=np.array(77),
                         sigma_z=np.array(0.05), sigma_m=np.array(0.7))
+    # ---- the training step (src/subspace_construction.jl:39-43 with Flux 0.11.2 Descent / Momentum / ADAM as
+    # restated in the oracle): 12 steps of each optimiser on a tanh/relu toy chain, shuffled batches of 25 + a ragged one
+    tdims, tacts = [10, 20, 20, 2], [so.ACT_TANH, so.ACT_RELU, so.ACT_IDENTITY]
+    ttab, tn = so.layer_table(tdims, tacts)
+    rng = np.random.default_rng(21)
+    tx, ty = rng.random((10, 100)), rng.random((2, 100))
+    tw0 = so.extract_params(glorot(np.random.default_rng(5), tdims))
+    batches = [rng.permutation(100)[:25] for _ in range(11)] + [np.array([3, 97, 41])]
+    opts = {"descent": ("descent", 0.1), "momentum": ("momentum", 0.01, 0.9), "adam": ("adam", 0.001, 0.9, 0.999)}
+    out = dict(X=tx, Y=ty, w0=tw0, batches=np.array([np.pad(b, (0, 25 - b.size), constant_values=-1) for b in batches]))
+    for name, opt in opts.items():
+        w, st, losses = tw0.copy(), so.optimiser_state(tn, opt), []
+        for ids in batches:
+            losses.append(so.train_step(ttab, w, st, tx[:, ids], ty[:, ids], opt))
+        out.update({name + "_w": w, name + "_loss": np.array(losses), name + "_m": st["m"], name + "_v": st["v"],
+                    name + "_bp": np.array(st["bp"] if st["bp"] else [0.0, 0.0])})
+    np.savez_compressed(os.path.join(HERE, "toy_train_steps.npz"), **out)
     print("wrote golden fixtures to", HERE)
 
 

@@ -51,6 +51,33 @@ def test_product_never_imports_oracle():
                 assert "import oracle" not in txt and "from oracle" not in txt, f
 
 
+def test_shipped_library_has_no_development_knobs(si):
+    """alternative kernels and SI_* environment knobs live in the development build only
+    (`python subspaceinference.jl_amd/build.py --dev`, -DSI_DEV_KNOBS).  The shipped .so reads two environment variables:
+    SI_HOST_COPY_THREADS (host copy pool size) and SI_RCCL_LIB (explicit RCCL path)."""
+    blob = open(si._capi.LIB_PATH, "rb").read()
+    names = set(m.decode() for m in re.findall(rb"SI_[A-Z0-9_]{3,}", blob))
+    env_like = {n for n in names if not n.startswith(("SI_ERR", "SI_K_", "SI_F", "SI_ACT", "SI_LAYER", "SI_OK", "SI_COMM", "SI_HIP", "SI_NCCL"))}
+    assert env_like <= {"SI_HOST_COPY_THREADS", "SI_RCCL_LIB"}, env_like
+    assert b"gram_spec" not in blob                       # the wave-specialised development Gram variant is not compiled in
+    # every getenv in the sources is one of the two, or sits inside an #ifdef SI_DEV_KNOBS / SI_BWD_DEBUG_KNOB block
+    csrc = os.path.join(ROOT, "subspaceinference.jl_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".cpp", ".h")):
+            continue
+        depth = []
+        for ln in open(os.path.join(csrc, f)):
+            t = ln.strip()
+            if t.startswith("#if"):
+                depth.append("SI_DEV_KNOBS" in t or "SI_BWD_DEBUG_KNOB" in t or "SI_GRAM_TS" in t)
+            elif t.startswith("#else") and depth:
+                depth[-1] = False
+            elif t.startswith("#endif") and depth:
+                depth.pop()
+            elif "getenv(" in t and not any(depth):
+                assert "SI_HOST_COPY_THREADS" in t or "SI_RCCL_LIB" in t, (f, t)
+
+
 def test_host_eigensolver(si):
     rng = np.random.default_rng(0)
     for n in (1, 2, 5, 33, 100):
@@ -222,10 +249,12 @@ def test_jacobi_resolves_graded_psd_matrices(si):
     assert np.allclose((a.T @ a) @ v2, v2 * w2[None, :], atol=1e-11 * w2[0])
 
 
-def test_find_good_stepsize_crosses_at_one_half_then_bisects():
-    """AdvancedHMC's heuristic crosses at acceptance 0.5 (not Stan's 0.8) and then bisects into (0.25, 0.75).
-    Pinned on Gaussian targets N(0, sigma^2 I): the returned eps_0 must (i) give a one-leapfrog acceptance inside
-    (0.25, 0.75) for the momentum it was tuned with, (ii) scale with sigma, (iii) be reproducible."""
+def test_find_good_stepsize_reproduces_upstreams_lagged_crossing():
+    """ADVICE r1 + r2: AdvancedHMC's heuristic crosses at acceptance 0.5 (not Stan's 0.8), evaluates the crossing test at
+    the OLD step size (one doubling / halving behind the candidate) and breaks at once on a NaN energy.  Pinned on Gaussian
+    targets N(0, sigma^2 I): the returned eps_0 is reproducible, follows the scale of the target, and sits at the FIRST
+    doubling / halving of 0.1 whose one-leapfrog acceptance is on the far side of 0.5 (the bracket upstream bisects lies
+    wholly beyond the crossing, so the bisection converges onto that end unless an interior point lands in (0.25, 0.75))."""
     from subspaceinference_jl_amd import samplers
 
     for sigma, d in ((0.01, 5), (1.0, 20), (100.0, 3)):
@@ -235,8 +264,21 @@ def test_find_good_stepsize_crosses_at_one_half_then_bisects():
         lp, g = lg(z)
         eps = samplers.find_good_stepsize(lg, z, lp, g, np.random.default_rng(5))
         assert eps == samplers.find_good_stepsize(lg, z, lp, g, np.random.default_rng(5))
-        r = np.random.default_rng(5).standard_normal(d)             # the momentum the search drew
-        _, rp, lpp, _ = samplers._leapfrog(lg, z, r, g, eps)
-        a = np.exp(min(0.0, (lpp - 0.5 * rp @ rp) - (lp - 0.5 * r @ r)))
-        assert 0.25 < a < 0.75, (sigma, eps, a)
         assert 0.2 * sigma < eps < 20 * sigma, (sigma, eps)         # the step size follows the scale of the target
+        r = np.random.default_rng(5).standard_normal(d)             # the momentum the search drew
+
+        def acc(e):
+            _, rp, lpp, _ = samplers._leapfrog(lg, z, r, g, e)
+            return np.exp(min(0.0, (lpp - 0.5 * rp @ rp) - (lp - 0.5 * r @ r)))
+        up = acc(0.1) > 0.5
+        e, steps = 0.1, 0
+        while (acc(e) > 0.5) == up and steps < 60:                  # first doubling / halving on the far side of 0.5
+            e = 2 * e if up else e / 2
+            steps += 1
+        lo, hi = (e, 2 * e) if up else (e / 2, e)
+        assert lo * (1 - 1e-9) <= eps <= hi * (1 + 1e-9), (sigma, eps, lo, hi)
+        a = acc(eps)
+        assert 0.25 <= a <= 0.75 or abs(eps - e) < 1e-6 * e, (sigma, eps, a)
+    # a NaN energy: direction -1 at the start, the crossing loop breaks at once, the bisection accepts its first midpoint
+    nan_lg = lambda zz: (float("nan"), np.zeros_like(zz))
+    assert samplers.find_good_stepsize(nan_lg, np.zeros(3), 0.0, np.zeros(3), np.random.default_rng(0)) == 0.5 * (0.05 + 0.1)

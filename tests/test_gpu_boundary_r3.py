@@ -82,3 +82,81 @@ def test_streamed_output_map_many_chains_falls_back_to_k4(gpu_ctx):
         assert np.array_equal(w[:, :, c], gpu_ctx.reconstruct(z[:, :, c]))
     z1, lp1, _, w1 = gpu_ctx.sample_rwmh_weights(6, 0.05, seed=3, nchains=1)
     assert np.array_equal(z1[:, :, 0], z[:, :, 0]) and np.array_equal(w1[:, :, 0], w[:, :, 0])   # select path == K4 path
+
+
+TRAIN_DIMS, TRAIN_ACTS = [10, 20, 20, 2], [so.ACT_TANH, so.ACT_RELU, so.ACT_IDENTITY]
+TRAIN_OPTS = {"descent": (0, ("descent", 0.1), (0.1, 0.0, 0.0)), "momentum": (1, ("momentum", 0.01, 0.9), (0.01, 0.9, 0.0)),
+              "adam": (2, ("adam", 0.001, 0.9, 0.999), (0.001, 0.9, 0.999))}
+
+
+@pytest.mark.parametrize("name", ["descent", "momentum", "adam"])
+def test_device_training_step_against_the_oracle_optimiser(gpu_ctx, name):
+    """si_train_step / si_train_get_opt_state (src/subspace_construction.jl:39-43 on the device) against the ORACLE's
+    restatement of Flux 0.11.2's Descent / Momentum / ADAM (not against the package's own flux.py): the
+    committed 12-step fixture (tests/golden/toy_train_steps.npz) and a live oracle run on other batches."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "toy_train_steps.npz"))
+    batches = [row[row >= 0] for row in d["batches"]]
+    kind, opt, (eta, p1, p2) = TRAIN_OPTS[name]
+    table, n = so.layer_table(TRAIN_DIMS, TRAIN_ACTS)
+    x, y = np.asfortranarray(d["X"]), np.asfortranarray(d["Y"])
+    gpu_ctx.train_setup(table, n, d["w0"], x, y, 25, kind, eta, p1, p2)
+    losses = [gpu_ctx.train_step(ids) for ids in batches]
+    assert np.allclose(losses, d[name + "_loss"], rtol=1e-9)                 # the loss sees the weights of every earlier step
+    w = gpu_ctx.train_get_weights()
+    # Float32 weights from Float64 arithmetic: the device's gradient sums differ from NumPy's in the last bits of fp64, which
+    # can move a Float32 rounding by one ulp now and then
+    assert w.dtype == np.float32 and np.allclose(w, d[name + "_w"], rtol=0, atol=4e-7)
+    m, v, bp = gpu_ctx.train_get_opt_state()
+    if name != "descent":
+        assert np.allclose(m, d[name + "_m"], rtol=1e-5, atol=1e-9)
+    if name == "adam":
+        assert np.allclose(v, d[name + "_v"], rtol=1e-5, atol=1e-12) and np.allclose(bp, d["adam_bp"], rtol=1e-13)
+    # live: continue both from the device's state for 5 more steps on fresh batches
+    rng = np.random.default_rng(77)
+    wo = w.copy()
+    st = {"m": m.copy(), "v": v.copy(), "bp": [bp[0], bp[1]] if name == "adam" else None}
+    for _ in range(5):
+        ids = rng.permutation(100)[:25]
+        lo = so.train_step(table, wo, st, x[:, ids], y[:, ids], opt)
+        assert np.isclose(gpu_ctx.train_step(ids), lo, rtol=1e-9)
+    assert np.allclose(gpu_ctx.train_get_weights(), wo, rtol=0, atol=4e-7)
+
+
+def test_maxpool_gradient_with_exact_ties(gpu_ctx):
+    """constant image regions make the conv output equal at every pixel of a pooling window; NNlib's
+    ∇maxpool gives the window's gradient to ONE input (the first ≈ maximum, kw fastest).  Both device routes -- the pass
+    fused with act' / bias sum behind a Conv, and the plain MaxPool gradient -- against the oracle, through the density
+    gradient and the training gradient."""
+    whc = (8, 8, 2)
+    spec = [("conv", (3, 3), 6, so.ACT_IDENTITY, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("maxpool", (2, 2)), ("flatten",),
+            ("dense", 3, so.ACT_IDENTITY)]
+    table, n = so.conv_table(spec, whc)
+    rng = np.random.default_rng(3)
+    b = 6
+    x4 = rng.standard_normal(whc + (b,))
+    x4[:, :, :, 0] = 0.5                    # a constant image: interior conv outputs are all equal -> ties in every window
+    x4[:, 4:, :, 1] = 0.0                   # half of another one is zero: conv output = bias there
+    x4[:, :, :, 2] = np.round(x4[:, :, :, 2])   # coarse values
+    x = np.asfortranarray(x4.reshape((-1, b), order="F"))
+    w_swa = 0.3 * rng.standard_normal(n)
+    p = np.asfortranarray(0.1 * rng.standard_normal((n, 2)))
+    y = np.asfortranarray(rng.standard_normal((3, b)))
+    gpu_ctx.infer_setup(table, n, 2, w_swa, p, x, y, 0.9)
+    z = np.array([0.3, -0.2])
+    lpg, g = gpu_ctx.logdensity_grad(z)
+    lpo, go, gwo = so.logdensity_grad(table, w_swa, p, x, y, 0.9, z)
+    assert np.isclose(lpg, lpo, rtol=1e-11) and np.allclose(g, go, rtol=1e-8, atol=1e-10 * np.abs(go).max())
+    # the old "every tied input" rule gives a different answer on this input (the test would not see a regression otherwise)
+    hs = [x]
+    for row in table:
+        hs.append(so._layer_forward(row, w_swa + p @ z, hs[-1]))
+    x1 = hs[1].reshape((8, 8, 6, b), order="F")
+    ties = sum(int(np.sum(x1[a::2, d::2] == hs[2].reshape((4, 4, 6, b), order="F"))) for a in range(2) for d in range(2))
+    assert ties > 4 * 4 * 6 * b                                   # more maxima than windows: ties exist
+    w0 = w_swa.astype(np.float32)
+    gpu_ctx.train_setup(table, n, w0, x, y, b, 0, 0.05)
+    gpu_ctx.train_grad(np.arange(b), b)
+    gt = gpu_ctx.train_grad_get()
+    _, gref = so.mse_value_and_grad(table, w0.astype(np.float64), x, y)
+    assert np.allclose(gt, gref, rtol=1e-8, atol=1e-10 * np.abs(gref).max())

@@ -253,3 +253,101 @@ def test_flux_conv_standins_match_the_oracle():
     assert n == n2 and [tuple(r) for r in table] == [tuple(r) for r in tab2]
     wflat = flux.extract_params(flux.params(model)).astype(np.float64)
     assert np.allclose(model(x4), so.forward(table, wflat, x4.reshape((-1, 6), order="F")), rtol=1e-6, atol=1e-6)
+
+
+TRAIN_DIMS, TRAIN_ACTS = [10, 20, 20, 2], [so.ACT_TANH, so.ACT_RELU, so.ACT_IDENTITY]
+TRAIN_OPTS = {"descent": ("descent", 0.1), "momentum": ("momentum", 0.01, 0.9), "adam": ("adam", 0.001, 0.9, 0.999)}
+
+
+def _train_fixture():
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "toy_train_steps.npz"))
+    batches = [row[row >= 0] for row in d["batches"]]
+    return d, batches
+
+
+def test_training_step_restatement():
+    """oracle.train_step (src/subspace_construction.jl:39-43; Flux 0.11.2 Descent / Momentum / ADAM): the committed fixture,
+    the gradient against finite differences, closed forms of the first steps, Float32 state with Float64 arithmetic."""
+    d, batches = _train_fixture()
+    table, n = so.layer_table(TRAIN_DIMS, TRAIN_ACTS)
+    x, y = d["X"], d["Y"]
+    for name, opt in TRAIN_OPTS.items():
+        w, st = d["w0"].copy(), so.optimiser_state(n, opt)
+        losses = [so.train_step(table, w, st, x[:, ids], y[:, ids], opt) for ids in batches]
+        assert w.dtype == np.float32 and st["m"].dtype == np.float32
+        assert np.array_equal(w, d[name + "_w"]) and np.array_equal(np.array(losses), d[name + "_loss"])
+        assert np.array_equal(st["m"], d[name + "_m"]) and np.array_equal(st["v"], d[name + "_v"])
+        assert losses[-2] < losses[0]                                           # it trains
+    assert np.allclose(d["adam_bp"], [0.9 ** 13, 0.999 ** 13], rtol=1e-13)      # beta powers start at beta: beta^(t+1) after t steps
+    # gradient of the mse cost against central differences
+    w64 = d["w0"].astype(np.float64)
+    ids = batches[0]
+    loss, g = so.mse_value_and_grad(table, w64, x[:, ids], y[:, ids])
+    assert np.isclose(loss, np.mean((so.forward(table, w64, x[:, ids]) - y[:, ids]) ** 2), rtol=1e-14)
+    for i in (0, 57, 230, 640, 681):
+        e = np.zeros(n)
+        e[i] = 1e-6
+        fd = (so.mse_value_and_grad(table, w64 + e, x[:, ids], y[:, ids])[0] - so.mse_value_and_grad(table, w64 - e, x[:, ids], y[:, ids])[0]) / 2e-6
+        assert abs(fd - g[i]) < 1e-8 * max(1.0, abs(g[i]))
+    # closed forms: Descent x - eta g; Momentum's first step eta g; ADAM's first step eta * g / (|g| + eps') ~ eta sign(g)
+    g32 = np.array([0.5, -2.0, 1e-3])
+    for opt, want in ((("descent", 0.1), -0.1 * g32), (("momentum", 0.01, 0.9), -0.01 * g32),
+                      (("adam", 0.001, 0.9, 0.999), -0.001 * np.sign(g32))):
+        w, st = np.zeros(3, dtype=np.float32), so.optimiser_state(3, opt)
+        so.apply_update(w, st, g32.copy(), opt)
+        assert np.allclose(w, want, rtol=1e-4)
+    # second Momentum step: v2 = rho v1 - eta g with v1 ROUNDED to Float32
+    w, st = np.zeros(3, dtype=np.float32), so.optimiser_state(3, ("momentum", 0.01, 0.9))
+    so.apply_update(w, st, g32.copy(), ("momentum", 0.01, 0.9))
+    v1 = st["m"].copy()
+    so.apply_update(w, st, g32.copy(), ("momentum", 0.01, 0.9))
+    assert np.array_equal(st["m"], (0.9 * v1.astype(np.float64) - 0.01 * g32).astype(np.float32))
+
+
+def test_flux_standin_optimisers_are_pinned_to_the_oracle():
+    """the Python host's stand-ins for Flux's optimisers (product code, flux.py) against the oracle's restatement on the
+    committed fixture: same Float32 weights after 12 steps, bit for bit."""
+    from subspaceinference_jl_amd import flux
+    d, batches = _train_fixture()
+    x, y = d["X"], d["Y"]
+    mk = {"descent": lambda: flux.Descent(0.1), "momentum": lambda: flux.Momentum(0.01, 0.9), "adam": lambda: flux.ADAM(0.001, (0.9, 0.999))}
+    for name in TRAIN_OPTS:
+        m = flux.Chain(flux.Dense(10, 20, flux.tanh), flux.Dense(20, 20, flux.relu), flux.Dense(20, 2))
+        flux.load_flat(m, d["w0"])
+        opt, ps = mk[name](), flux.params(m)
+        losses = []
+        for ids in batches:
+            loss, gs = flux.gradient(flux.mse, m, x[:, ids], y[:, ids])
+            flux.update(opt, ps, gs)
+            losses.append(loss)
+        assert np.allclose(losses, d[name + "_loss"], rtol=1e-12)
+        assert np.allclose(flux.extract_params(ps), d[name + "_w"], rtol=0, atol=2e-7), name   # <= an ulp or two of Float32
+
+
+def test_maxpool_gradient_goes_to_one_element_per_window():
+    """NNlib's ∇maxpool routes a window's gradient to the FIRST input that is ≈ its maximum (kw
+    fastest), not to every tied input.  Checked against an independent scalar loop, on inputs with exact ties."""
+    rng = np.random.default_rng(0)
+    wi, hi, c, b = 6, 4, 2, 3
+    x4 = rng.integers(0, 3, size=(wi, hi, c, b)).astype(np.float64)      # many exact ties
+    x4[:, :, 0, 0] = 0.25                                                 # a constant image channel
+    row = ("maxpool", (2, 2), c, (wi, hi), (2, 2))
+    h_in = x4.reshape((-1, b), order="F")
+    h_out = so._layer_forward(row, None, h_in)
+    g_out = rng.standard_normal(h_out.shape)
+    gx = so._layer_backward(row, None, h_in, h_out, g_out, None).reshape(x4.shape, order="F")
+    y4, g4 = h_out.reshape((3, 2, c, b), order="F"), g_out.reshape((3, 2, c, b), order="F")
+    ref = np.zeros_like(x4)
+    for n in range(b):
+        for ch in range(c):
+            for ho in range(2):
+                for wo in range(3):
+                    done = False
+                    for kh in range(2):
+                        for kw in range(2):
+                            if not done and np.isclose(y4[wo, ho, ch, n], x4[2 * wo + kw, 2 * ho + kh, ch, n], rtol=1.4901161193847656e-08, atol=0):
+                                ref[2 * wo + kw, 2 * ho + kh, ch, n] += g4[wo, ho, ch, n]
+                                done = True
+    assert np.array_equal(gx, ref)
+    assert np.isclose(gx.sum(), g_out.sum())                              # every window's gradient lands exactly once
+    assert np.array_equal(gx[0::2, 0::2, 0, 0], g4[:, :, 0, 0]) and gx[1::2, :, 0, 0].sum() == 0.0   # constant channel: first element
