@@ -28,7 +28,8 @@ def _alg_name(alg):
 
 
 def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, *, device=0, ctx=None,
-                          max_cols=0, verbose=True, keep_on_device=False, device_training="auto", init="zeros"):
+                          max_cols=0, verbose=True, keep_on_device=False, device_training="auto", init="zeros",
+                          data_parallel="auto"):
     """src/subspace_construction.jl:26-67.
 
     Per batch the host does `gradient` + `update!` (:39-43, caller side) and hands the flattened weights
@@ -47,7 +48,8 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
     With a ctx that carries an RCCL communicator (one process per GPU, dist.comm_init) the device training step is
     data-parallel: every rank must be called with the same model, data and DataLoader seed; each takes its share
     of every batch and the gradient is all-reduced once per step inside the library (si_train_step_dp), so all
-    ranks return the same (W_swa, P).
+    ranks return the same (W_swa, P).  data_parallel=False keeps the step local even then (a rank doing extra work on
+    its own: every rank of a data-parallel step must make the same calls).
     """
     ps = flux.params(model)
     n_par = int(sum(p.size for p in ps))
@@ -72,7 +74,8 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
         elif _alg_name(init) != "zeros":
             raise SubspaceError("init must be :zeros (the reference's behaviour) or :pretrained")
         training_loss = 0.0
-        dp_rank, dp_world = dist.world(ctx) if use_dev else (0, 1)
+        use_dp = use_dev and data_parallel is not False
+        dp_rank, dp_world = dist.world(ctx) if use_dp else (0, 1)
         if use_dev:
             xm, ym, in_size = flux.data_matrices(data)
             table, _ = flux.layer_table(model, in_size)
@@ -83,7 +86,7 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
                 last = (i % print_freq == 0) or (i == T)
                 batches = list(data.index_batches())
                 for j, ids in enumerate(batches):
-                    if dp_world > 1 or dist._has_comm(ctx):
+                    if use_dp and (dp_world > 1 or dist._has_comm(ctx)):
                         # data-parallel step: this rank's share of the batch, one gradient all-reduce (dist.py)
                         c0, c1 = dist.col_shard(len(ids), dp_rank, dp_world)
                         loss = dist.train_step_data_parallel(ctx, np.asarray(ids)[c0:c1], len(ids))
