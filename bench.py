@@ -482,6 +482,7 @@ def run_chains(args, rk, real_stdout):
     ctx.set_profiling(False)
     # the same K transitions WITH the reference's output map (a13, src/space_inference.jl:125): every weight sample
     # delivered to a fresh pageable host array while the chain runs -- what the drop-in sub_inference call does
+    ctx.sample_rwmh_weights(5, SIGMA_Z, seed=100, chain_id0=rank)   # warm-up: weight ring, pinned staging, copy pool
     barrier()
     t0 = time.perf_counter()
     zw, lpw, _, wmap = ctx.sample_rwmh_weights(args.steps, SIGMA_Z, seed=100, chain_id0=rank)

@@ -2,10 +2,16 @@
 // caller's pageable arrays and the library's pinned staging buffers (si_construct_push: host -> pinned -> HBM;
 // si_reconstruct / si_sample_rwmh_weights: HBM -> pinned -> host).  One host thread copies ~10 GB/s; the PCIe link
 // moves ~55 GB/s, so the staging copy, not the DMA, would set the pace of a push without it.  Threads are created once
-// (creating them per call costs more than a 4 MB copy) and sleep on a condition variable between jobs.
+// (creating them per call costs more than a 4 MB copy); between jobs they spin for a short while (a loop of pushes hands
+// over the next vector within ~100 us: a futex wake-up per worker and push would cost as much as its slice of the copy)
+// and then sleep on a condition variable.
 #include <sched.h>
 
+#include <immintrin.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +21,10 @@
 #include <vector>
 
 #include "si_internal.h"
+
+#ifndef SI_COPY_SPIN_US
+#define SI_COPY_SPIN_US 200   // measured on the GPU box (tools/host_copy_bench.cpp, profiles/r03_host_copy_pool.log)
+#endif
 
 namespace si {
 
@@ -45,7 +55,7 @@ class CopyPool {
     {
       std::lock_guard<std::mutex> lk(m_);
       stop_ = true;
-      ++gen_;
+      gen_.fetch_add(1, std::memory_order_release);
     }
     cv_.notify_all();
     for (auto& t : workers_) t.join();
@@ -59,19 +69,20 @@ class CopyPool {
     std::lock_guard<std::mutex> use(use_);  // one copy at a time (contexts on several host threads share the pool)
     const size_t parts = nw + 1;
     const size_t per = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;  // 4 KiB-granular slices
+    int sleepers;
     {
       std::lock_guard<std::mutex> lk(m_);
       for (size_t i = 0; i < nw; ++i) {
         const size_t lo = std::min(bytes, per * (i + 1)), hi = std::min(bytes, per * (i + 2));
         slices_[i] = {dst + lo, src + lo, hi - lo};
       }
-      pending_ = (int)nw;
-      ++gen_;
+      pending_.store((int)nw, std::memory_order_relaxed);
+      gen_.fetch_add(1, std::memory_order_release);
+      sleepers = sleeping_;
     }
-    cv_.notify_all();
+    if (sleepers > 0) cv_.notify_all();   // spinning workers see the new generation by themselves
     std::memcpy(dst, src, std::min(bytes, per));
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [this] { return pending_ == 0; });
+    while (pending_.load(std::memory_order_acquire) != 0) _mm_pause();   // the slices are equal: the others finish within us
   }
   int threads() const { return (int)workers_.size() + 1; }
 
@@ -84,27 +95,37 @@ class CopyPool {
   void run(int i) {
     uint64_t seen = 0;
     for (;;) {
+      // spin SI_COPY_SPIN_US for the next job, then sleep
+      const auto t0 = std::chrono::steady_clock::now();
+      int polls = 0;
+      while (gen_.load(std::memory_order_acquire) == seen) {
+        _mm_pause();
+        if ((++polls & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(SI_COPY_SPIN_US)) {
+          std::unique_lock<std::mutex> lk(m_);
+          ++sleeping_;
+          cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+          --sleeping_;
+          break;
+        }
+      }
       Slice s;
       {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return gen_ != seen; });
-        seen = gen_;
+        std::lock_guard<std::mutex> lk(m_);   // orders the read of the slice after the writer's update
+        seen = gen_.load(std::memory_order_acquire);
         if (stop_) return;
         s = slices_[(size_t)i];
       }
       if (s.bytes) std::memcpy(s.dst, s.src, s.bytes);
-      {
-        std::lock_guard<std::mutex> lk(m_);
-        if (--pending_ == 0) done_.notify_one();
-      }
+      pending_.fetch_sub(1, std::memory_order_release);
     }
   }
   std::vector<std::thread> workers_;
   std::vector<Slice> slices_;
   std::mutex m_, use_;
-  std::condition_variable cv_, done_;
-  uint64_t gen_ = 0;
-  int pending_ = 0;
+  std::condition_variable cv_;
+  std::atomic<uint64_t> gen_{0};
+  std::atomic<int> pending_{0};
+  int sleeping_ = 0;   // workers blocked on cv_ (guarded by m_)
   bool stop_ = false;
 };
 

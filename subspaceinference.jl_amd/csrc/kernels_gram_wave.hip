@@ -51,8 +51,19 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int NT, int KS, int G>
+// NQ: width of the LAST column tile in 4-column blocks.  NQ = 4: a full 16-column tile (or one whose padding is not worth
+// a special case); NQ = 1, 2: a RAGGED last tile (K mod 16 in 1..4 / 5..8) -- its pairs (a, NT-1) are multiplied with
+// v_mfma_f64_4x4x4_4b_f64 instead of the 16x16x4 instruction: one instruction = four independent 4x4x4 blocks =
+// 16 rows of tile a against ONE 4-column block of the last tile, at ~0.3 of the issue time of a 16x16x4 (measured:
+// tools/mfma_f64_4x4_probe.hip, 39.9 against 132 cycles on the same clock).  At K = 100 the last column of tile pairs
+// costs 7 x 0.3 instead of 7 issue slots: 23.1 instead of 28 per k step.  Operand layout of the 4x4x4_4b instruction
+// (probed, the guide has no table for it): A_b[i][k] in lane i + 4b + 16k, B_b[k][j] in lane j + 4b + 16k, D_b[i][j] in
+// lane j + 4b + 16i -- so the ordinary fragment of tile a IS the A operand (block b = rows 4b..4b+3 of the tile), and the
+// B operand is a 4-column block of the last tile repeated in all four blocks (its own LDS read, `fr`).
+template <int NT, int KS, int G, int NQ = 4>
 struct GWave {
+  static constexpr bool RAG = NQ < 4;
+  static constexpr int NQR = RAG ? NQ : 1;
   static constexpr int PS = GW_WAVES / KS;
   static constexpr int P = NT * (NT + 1) / 2;
   static constexpr int LO = G * P / PS, HI = (G + 1) * P / PS, CNT = HI - LO;
@@ -65,17 +76,47 @@ struct GWave {
   // zero-initialisation would materialise 8 * CNT zeros in arch VGPRs before they move to the AGPRs the MFMAs use)
   // `hook(I)` runs right after MFMA I has been issued: the staging traffic of a slab is dealt out between the MFMAs, one
   // small piece at a time, so that it executes in the shadow of the matrix pipe instead of in one clump behind a group
+  // does this wave's chunk hold a pair of the ragged last column?
+  static constexpr bool has_rag() {
+    if (!RAG) return false;
+    for (int p = LO; p < HI; ++p)
+      if (tri_b(p, NT) == NT - 1) return true;
+    return false;
+  }
   template <int I, bool FIRST, class HOOK>
-  static __device__ __forceinline__ void mfma(const double (&f)[NT], d4 (&acc)[CNT > 0 ? CNT : 1], HOOK&& hook) {
+  static __device__ __forceinline__ void mfma(const double (&f)[NT], const double (&fr)[NQR], d4 (&acc)[CNT > 0 ? CNT : 1], HOOK&& hook) {
     if constexpr (I < CNT) {
       constexpr int a = tri_a(LO + I, NT), b = tri_b(LO + I, NT);
-      if constexpr (FIRST)
+      if constexpr (RAG && b == NT - 1) {
+        // ragged column: component jb of the accumulator holds rows of tile a x column block jb of the last tile
+        static_for<NQR>([&](auto JC) {
+          constexpr int jb = decltype(JC)::value;
+          if constexpr (FIRST)
+            acc[I][jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(f[a], fr[jb], 0.0, 0, 0, 0);
+          else
+            acc[I][jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(f[a], fr[jb], acc[I][jb], 0, 0, 0);
+        });
+      } else if constexpr (FIRST) {
         acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[a], f[b], (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-      else
+      } else {
         acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[a], f[b], acc[I], 0, 0, 0);
+      }
       hook(std::integral_constant<int, I>{});
-      mfma<I + 1, FIRST>(f, acc, hook);
+      mfma<I + 1, FIRST>(f, fr, acc, hook);
     }
+  }
+  // tile element (row + 16 * column) that component `comp` of pair I's accumulator holds in this lane
+  template <int I>
+  static __device__ __forceinline__ int tile_elem(int lane, int comp) {
+    constexpr int b = tri_b(LO + I, NT);
+    if constexpr (RAG && b == NT - 1)
+      return (4 * ((lane >> 2) & 3) + (lane >> 4)) + 16 * (4 * comp + (lane & 3));   // D_b[i][j]: lane j + 4b + 16i
+    else
+      return ((lane >> 4) + 4 * comp) + 16 * (lane & 15);
+  }
+  template <int I>
+  static constexpr int comps() {
+    return (RAG && tri_b(LO + I, NT) == NT - 1) ? NQR : 4;
   }
 };
 
@@ -94,10 +135,11 @@ struct GWave {
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-template <int NT, int KS, int KG, int G, int NB>
+template <int NT, int KS, int KG, int G, int NB, int NQ>
 __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int64_t ldA, int64_t N, int K,
                                                double* __restrict__ Gpart, double* sA) {
-  using GW = GWave<NT, KS, G>;
+  using GW = GWave<NT, KS, G, NQ>;
+  constexpr int NQR = GW::NQR;
   constexpr int NC = NT * 16;
   constexpr int BUF = NC * GR;            // doubles per LDS buffer (32 rows per column, unpadded)
   constexpr int H = (GR / 4) / KS;        // k steps of a slab owned by this wave
@@ -130,10 +172,23 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
     fb[i] = c * GR + 2 * ((2 * s + (q >> 1)) ^ c) + (q & 1);
     asm volatile("" : "+v"(fb[i]));   // keep the reads of neighbouring steps apart (no ds_read2_b64)
   }
+  // ragged last tile: B operand of the 4x4x4_4b instruction = column 16 (NT-1) + 4 jb + (c & 3), row 4s + q, the same in all
+  // four blocks (lanes that differ only in bits 2..3 read one address: an LDS broadcast)
+  int fbr[H][NQR];
+  if constexpr (GW::has_rag()) {
+#pragma unroll
+    for (int i = 0; i < H; ++i)
+#pragma unroll
+      for (int jb = 0; jb < NQR; ++jb) {
+        const int s = KG + KS * i, cj = 4 * jb + (c & 3);
+        fbr[i][jb] = (16 * (NT - 1) + cj) * GR + 2 * ((2 * s + (q >> 1)) ^ cj) + (q & 1);
+      }
+  }
   const int64_t nslab = (N + GR - 1) / GR;
   const int64_t stride = gridDim.x;
   int64_t slab = blockIdx.x;
   double f0[NT], f1[NT];
+  double r0[NQR], r1[NQR];
   double* out = Gpart + (int64_t)blockIdx.x * GW::P * 256;
   if (slab >= nslab) {  // (the launcher never starts more blocks than slabs; keep the partial defined anyway)
     for (int e = tid; e < GW::P * 256; e += 64 * GW_WAVES) out[e] = 0.0;
@@ -146,14 +201,22 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
   for (int b = 0; b < NB; ++b) issue(clamp(slab + b * stride), b);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * NT) : "memory");
   __builtin_amdgcn_s_barrier();
-  auto load_frags = [&](const double* buf, int b, double(&f)[NT]) {
+  auto load_frags_i = [&](const double* buf, auto IC, double(&f)[NT], double(&r)[NQR]) {
+    constexpr int ii = decltype(IC)::value;
+    const int b = fb[ii];
     static_for<NT>([&](auto TC) {
       constexpr int T = decltype(TC)::value;
       constexpr unsigned M = GW::mask();
-      if constexpr ((M >> T) & 1u) f[T] = buf[b + T * 16 * GR];
+      // (with a ragged last tile the ordinary fragment of tile NT-1 is only the A operand of its own diagonal pair)
+      constexpr bool need = ((M >> T) & 1u) && !(GW::RAG && T == NT - 1 && !(GW::LO <= GW::P - 1 && GW::P - 1 < GW::HI));
+      if constexpr (need) f[T] = buf[b + T * 16 * GR];
     });
+    if constexpr (GW::has_rag()) {
+#pragma unroll
+      for (int jb = 0; jb < NQR; ++jb) r[jb] = buf[fbr[ii][jb]];
+    }
   };
-  load_frags(sA, fb[0], f0);
+  load_frags_i(sA, std::integral_constant<int, 0>{}, f0, r0);
   d4 acc[CNT];
   int ring = 0;   // buffer of the current slab
   // With ONE wave per SIMD nothing hides an instruction that is not an MFMA: an LDS-DMA piece costs 60-190 cycles of issue
@@ -170,6 +233,8 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
       constexpr int i = decltype(IC)::value;
       double(&fc)[NT] = (i & 1) ? f1 : f0;
       double(&fn)[NT] = (i & 1) ? f0 : f1;
+      double(&rc)[NQR] = (i & 1) ? r1 : r0;
+      double(&rn)[NQR] = (i & 1) ? r0 : r1;
       if constexpr (i == H - 1) {
         // every LDS read of this buffer has been issued: retire them and this wave's pieces of the NEXT slab, meet the other
         // waves; afterwards this buffer belongs to the slab NB ahead
@@ -181,9 +246,9 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
         constexpr int I = decltype(MC)::value;
         if constexpr (I == FRAG_AT) {
           if constexpr (i + 1 < H)
-            load_frags(cur, fb[i + 1], fn);
+            load_frags_i(cur, std::integral_constant<int, i + 1>{}, fn, rn);
           else
-            load_frags(sA + nxt * BUF, fb[0], fn);
+            load_frags_i(sA + nxt * BUF, std::integral_constant<int, 0>{}, fn, rn);
         }
         if constexpr (i == H - 1 && I >= FRAG_AT + 1 && I - (FRAG_AT + 1) < NT) {
           issue_one(roff, pdst, std::integral_constant<int, I - (FRAG_AT + 1)>{});
@@ -191,15 +256,15 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
       };
       __builtin_amdgcn_s_setprio(1);
       if constexpr (first_slab && i == 0)
-        GW::template mfma<0, true>(fc, acc, hook);
+        GW::template mfma<0, true>(fc, rc, acc, hook);
       else
-        GW::template mfma<0, false>(fc, acc, hook);
+        GW::template mfma<0, false>(fc, rc, acc, hook);
       __builtin_amdgcn_s_setprio(0);
       if constexpr (GW::CNT == 0) {   // a wave without tile pairs still stages its share
         if constexpr (i + 1 < H)
-          load_frags(cur, fb[i + 1], fn);
+          load_frags_i(cur, std::integral_constant<int, i + 1>{}, fn, rn);
         else
-          load_frags(sA + nxt * BUF, fb[0], fn);
+          load_frags_i(sA + nxt * BUF, std::integral_constant<int, 0>{}, fn, rn);
       }
       if constexpr (i == H - 1) {     // pieces that found no MFMA to hide behind (small chunks)
         constexpr int done = GW::CNT - (FRAG_AT + 1) > 0 ? (GW::CNT - (FRAG_AT + 1) < NT ? GW::CNT - (FRAG_AT + 1) : NT) : 0;
@@ -209,6 +274,8 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
     if constexpr ((H & 1) == 1) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) f0[t] = f1[t];
+#pragma unroll
+      for (int t = 0; t < NQR; ++t) r0[t] = r1[t];
     }
     ring = nxt;
     slab += stride;
@@ -217,11 +284,14 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
   while (slab < nslab) one_slab(std::false_type{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail fetches must land before the buffers are reused
   // ---- partial sums of the KS waves of a chunk: through LDS, R tiles per round, fixed order ----
+  // (a pair of the ragged column fills only the tile elements of its valid 4-column blocks; the others keep whatever
+  // finite values were there and land in G entries >= K, which the second reduction stage never writes)
   if constexpr (KS == 1) {
+    static_for<GW::CNT>([&](auto IC) {
+      constexpr int i = decltype(IC)::value;
 #pragma unroll
-    for (int i = 0; i < GW::CNT; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) out[(GW::LO + i) * 256 + (q + 4 * r) + 16 * c] = acc[i][r];
+      for (int r = 0; r < GW::template comps<i>(); ++r) out[(GW::LO + i) * 256 + GW::template tile_elem<i>(lane, r)] = acc[i][r];
+    });
   } else {
     constexpr int PS = GW::PS;
     constexpr int CMAX = (GW::P + PS - 1) / PS;
@@ -234,8 +304,13 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
       for (int j = 0; j < R; ++j) {
         const int i = rd * R + j;
         if (i < GW::CNT) {
+          static_for<CNT>([&](auto IC) {   // the pair index selects the lane map at compile time
+            constexpr int ii = decltype(IC)::value;
+            if (ii == i) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sA[(wave * R + j) * 256 + (q + 4 * r) + 16 * c] = acc[i < CNT ? i : 0][r];
+              for (int r = 0; r < GW::template comps<ii>(); ++r) sA[(wave * R + j) * 256 + GW::template tile_elem<ii>(lane, r)] = acc[ii][r];
+            }
+          });
         }
       }
       __syncthreads();
@@ -256,15 +331,15 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
   }
 }
 
-template <int NT, int KS, int NB, int OCC>
+template <int NT, int KS, int NB, int OCC, int NQ>
 __global__ __launch_bounds__(64 * GW_WAVES, OCC) void gram_glds_kernel(const double* __restrict__ A, int64_t ldA, int64_t N, int K,
                                                                      double* __restrict__ Gpart) {
   extern __shared__ double sA[];  // [NB][NT*16][32]
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-    case 0: gram_glds_body<NT, KS, 0 % KS, 0 / KS, NB>(A, ldA, N, K, Gpart, sA); break;
-    case 1: gram_glds_body<NT, KS, 1 % KS, 1 / KS, NB>(A, ldA, N, K, Gpart, sA); break;
-    case 2: gram_glds_body<NT, KS, 2 % KS, 2 / KS, NB>(A, ldA, N, K, Gpart, sA); break;
-    default: gram_glds_body<NT, KS, 3 % KS, 3 / KS, NB>(A, ldA, N, K, Gpart, sA); break;
+    case 0: gram_glds_body<NT, KS, 0 % KS, 0 / KS, NB, NQ>(A, ldA, N, K, Gpart, sA); break;
+    case 1: gram_glds_body<NT, KS, 1 % KS, 1 / KS, NB, NQ>(A, ldA, N, K, Gpart, sA); break;
+    case 2: gram_glds_body<NT, KS, 2 % KS, 2 / KS, NB, NQ>(A, ldA, N, K, Gpart, sA); break;
+    default: gram_glds_body<NT, KS, 3 % KS, 3 / KS, NB, NQ>(A, ldA, N, K, Gpart, sA); break;
   }
 }
 
@@ -429,10 +504,11 @@ __device__ __forceinline__ void gram_spec_consumer(int64_t N, double* __restrict
           for (int z = 0; z < CNT; ++z) acc[z] = (d4){0.0, 0.0, 0.0, 0.0};
         }
       } else {
+        const double rdummy[1] = {0.0};
         if constexpr (first_slab && i == 0)
-          GW::template mfma<0, true>(fc, acc, hook);
+          GW::template mfma<0, true>(fc, rdummy, acc, hook);
         else
-          GW::template mfma<0, false>(fc, acc, hook);
+          GW::template mfma<0, false>(fc, rdummy, acc, hook);
         if constexpr (GW::CNT == 0) {
           if constexpr (i + 1 < H)
             load_frags(cur, fb[i + 1], fn);
@@ -538,15 +614,15 @@ static constexpr bool gram_two_per_cu() { return true; }
 #endif
 
 // KS / KS2: k-step split with one / two workgroups per CU (two per CU needs 8 * pairs-per-wave + ~90 registers <= 256)
-template <int NT, int KS, int KS2>
-static void launch_nt(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks, int num_cu) {
+template <int NT, int KS, int KS2, int NQ>
+static void launch_nt_q(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks) {
   if constexpr (KS2 > 0) {
     if (gram_two_per_cu()) {
       constexpr int NB = 2;
       constexpr size_t lds = (size_t)NB * NT * 16 * GR * sizeof(double);
       static LdsOptIn optin;
-      optin.ensure(reinterpret_cast<const void*>(gram_glds_kernel<NT, KS2, NB, 2>), lds);
-      hipLaunchKernelGGL((gram_glds_kernel<NT, KS2, NB, 2>), dim3(nblocks), dim3(64 * GW_WAVES), lds, st, A, ldA, N, K, tiles);
+      optin.ensure(reinterpret_cast<const void*>(gram_glds_kernel<NT, KS2, NB, 2, NQ>), lds);
+      hipLaunchKernelGGL((gram_glds_kernel<NT, KS2, NB, 2, NQ>), dim3(nblocks), dim3(64 * GW_WAVES), lds, st, A, ldA, N, K, tiles);
       return;
     }
   }
@@ -554,8 +630,22 @@ static void launch_nt(hipStream_t st, const double* A, int64_t ldA, int64_t N, i
   constexpr int NB = (150 * 1024) / (NT * 16 * GR * 8) >= 4 ? 4 : (150 * 1024) / (NT * 16 * GR * 8) >= 3 ? 3 : 2;
   constexpr size_t lds = (size_t)NB * NT * 16 * GR * sizeof(double);
   static LdsOptIn optin;
-  optin.ensure(reinterpret_cast<const void*>(gram_glds_kernel<NT, KS, NB, 1>), lds);
-  hipLaunchKernelGGL((gram_glds_kernel<NT, KS, NB, 1>), dim3(nblocks), dim3(64 * GW_WAVES), lds, st, A, ldA, N, K, tiles);
+  optin.ensure(reinterpret_cast<const void*>(gram_glds_kernel<NT, KS, NB, 1, NQ>), lds);
+  hipLaunchKernelGGL((gram_glds_kernel<NT, KS, NB, 1, NQ>), dim3(nblocks), dim3(64 * GW_WAVES), lds, st, A, ldA, N, K, tiles);
+}
+
+// the last column tile holds K - 16 (NT - 1) columns: 1..4 -> one 4-column block, 5..8 -> two (the ragged variants on the
+// 4x4x4_4b instruction); 9..16 -> the plain kernel (three blocks would save 10 % of one column of tile pairs: not built)
+template <int NT, int KS, int KS2>
+static void launch_nt(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks, int num_cu) {
+  (void)num_cu;
+  const int wl = K - 16 * (NT - 1);
+  if (wl <= 4)
+    launch_nt_q<NT, KS, KS2, 1>(st, A, ldA, N, K, tiles, nblocks);
+  else if (wl <= 8)
+    launch_nt_q<NT, KS, KS2, 2>(st, A, ldA, N, K, tiles, nblocks);
+  else
+    launch_nt_q<NT, KS, KS2, 4>(st, A, ldA, N, K, tiles, nblocks);
 }
 
 // workgroups per CU the launcher of this tile count will use (the caller sizes the grid and the partial-tile workspace)

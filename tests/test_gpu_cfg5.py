@@ -22,7 +22,7 @@ DIMS5, ACTS5 = [1024, 6656, 6656, 1], [1, 1, 0]
 @pytest.mark.timeout(900)
 def test_cfg5_real_shapes_construct_then_data_shard_density(si):
     import torch
-    from subspaceinference_jl_amd.dist import _dev_view
+    from gpu_helpers import dev_view as _dev_view
     table, n = so.layer_table(DIMS5, ACTS5)
     assert n == N5
     free, _ = torch.cuda.mem_get_info()

@@ -1,6 +1,7 @@
 // Development harness for K2 (Gram) and K3 (projection) at construct shapes.  Not shipped.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gram_bench.hip subspaceinference.jl_amd/csrc/build/kernels_gram_wave{0,1,2}.o -o tools/bin/gram_bench
 #include "../subspaceinference.jl_amd/csrc/kernels_gram.hip"
+#include <cmath>
 #include <cstdio>
 #include <vector>
 namespace si {
@@ -20,6 +21,21 @@ __global__ void fill(double* a, size_t n, unsigned long long seed) {
     unsigned long long s = (i + 1) * 6364136223846793005ull + seed; s ^= s >> 29; s *= 0xBF58476D1CE4E5B9ull; s ^= s >> 32;
     a[i] = (double)(s >> 11) / 9007199254740992.0 - 0.5;
   }
+}
+// reference: one workgroup per (i, j), plain fp64 dot product with a fixed-order tree (development check of the MFMA kernels)
+__global__ __launch_bounds__(256) void gram_naive(const double* A, int64_t ldA, int64_t N, int K, double* G) {
+  const int i = blockIdx.x, j = blockIdx.y;
+  if (i > j) return;
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int64_t r = threadIdx.x; r < N; r += 256) acc += A[r + (int64_t)i * ldA] * A[r + (int64_t)j * ldA];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) G[i + (int64_t)K * j] = G[j + (int64_t)K * i] = red[0];
 }
 int main(int argc, char** argv) {
   const int64_t N = argc > 1 ? atoll(argv[1]) : 1047361;
@@ -62,6 +78,20 @@ int main(int argc, char** argv) {
   }
 #endif
   std::vector<double> g((size_t)K * K); hipMemcpy(g.data(), G, g.size() * 8, hipMemcpyDeviceToHost);
+  {
+    double* Gn; hipMalloc(&Gn, (size_t)K * K * 8);
+    hipLaunchKernelGGL(gram_naive, dim3(K, K), dim3(256), 0, 0, A, ldA, N, K, Gn);
+    std::vector<double> gn((size_t)K * K); hipMemcpy(gn.data(), Gn, gn.size() * 8, hipMemcpyDeviceToHost);
+    double worst = 0.0; int wi = 0, wj = 0; bool sym = true;
+    for (int j = 0; j < K; ++j) for (int i = 0; i < K; ++i) {
+      const double sc = sqrt(gn[(size_t)i * K + i] * gn[(size_t)j * K + j]);
+      const double e = fabs(g[i + (size_t)K * j] - gn[i + (size_t)K * j]) / sc;
+      if (!(e <= worst)) { worst = e; wi = i; wj = j; }
+      if (g[i + (size_t)K * j] != g[j + (size_t)K * i]) sym = false;
+    }
+    printf("CHECK K=%d: max |G - G_naive| / sqrt(G_ii G_jj) = %.3e at (%d, %d), symmetric %d -> %s\n", K, worst, wi, wj, (int)sym,
+           (worst < 1e-12 && sym) ? "OK" : "FAIL");
+  }
   printf("G[0,0]=%.6f G[1,0]=%.6f G[K-1,K-1]=%.6f (expect ~N/12=%.1f on the diagonal)\n", g[0], g[1], g[(size_t)K * K - 1], N / 12.0);
   return 0;
 }
