@@ -440,9 +440,22 @@ def run_chains(args, rk, real_stdout):
             pruns.append(((tp - t0) * 1e3, (tq - t0) * 1e3))
         k = int(np.argsort(hruns)[1])
         push_ms = pruns[k][0]
+        # what the PCIe link itself delivers on this box: the same 100 x 4.19 MB from PINNED memory, no staging copy, no kernel
+        hp = torch.empty(n_par * 4, dtype=torch.uint8).pin_memory()
+        dv = torch.empty(n_par * 4, dtype=torch.uint8, device="cuda")
+        dv.copy_(hp, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K_SNAP):
+            dv.copy_(hp, non_blocking=True)
+        torch.cuda.synchronize()
+        link_gbs = K_SNAP * n_par * 4 / (time.perf_counter() - t0) / 1e9
+        del hp, dv
         host_push = {"construct_host_push_ms": hruns[k], "runs": [round(t, 3) for t in hruns], "push_phase_ms": push_ms,
                      "calls_returned_after_ms": pruns[k][1],
                      "host_push_GBs": K_SNAP * n_par * 4 / (push_ms * 1e-3) / 1e9, "pcie_peak_GBs": 63.0,
+                     "pinned_h2d_GBs_measured": link_gbs,
+                     "frac_of_measured_link": K_SNAP * n_par * 4 / (push_ms * 1e-3) / 1e9 / link_gbs,
                      "note": "100 x si_construct_push of a pageable 4.19 MB Float32 vector: host copy pool -> pinned double "
                              "buffer -> async H2D + K1, no synchronisation per push; then Gram + eig + projection"}
         del snaps_host

@@ -51,6 +51,33 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// The tile pairs are dealt to the PS chunks of a workgroup by ISSUE COST, not by count: a pair of a ragged last column
+// (NQ < 4, see GWave) costs 0.3 NQ of a full pair -- with equal counts at K = 100 one chunk held 12 full + 2 ragged pairs,
+// the other 9 + 5: 12.6 against 10.5 issue slots per k step.  (Free functions: a class cannot use its own constexpr members
+// in the initialisers of its static data members.)
+__host__ __device__ constexpr int gw_cost(int p, int nt, int nq) { return (nq < 4 && tri_b(p, nt) == nt - 1) ? 3 * nq : 10; }
+__host__ __device__ constexpr int gw_bound(int g, int nt, int ps, int nq) {   // first pair of chunk g; gw_bound(ps) = P
+  const int P = nt * (nt + 1) / 2;
+  if (g <= 0) return 0;
+  if (g >= ps) return P;
+  int total = 0;
+  for (int p = 0; p < P; ++p) total += gw_cost(p, nt, nq);
+  int cum = 0;
+  for (int p = 0; p < P; ++p) {
+    if (cum * ps >= total * g) return p;
+    cum += gw_cost(p, nt, nq);
+  }
+  return P;
+}
+__host__ __device__ constexpr int gw_cmax(int nt, int ps, int nq) {
+  int m = 0;
+  for (int g = 0; g < ps; ++g) {
+    const int c = gw_bound(g + 1, nt, ps, nq) - gw_bound(g, nt, ps, nq);
+    m = c > m ? c : m;
+  }
+  return m;
+}
+
 // NQ: width of the LAST column tile in 4-column blocks.  NQ = 4: a full 16-column tile (or one whose padding is not worth
 // a special case); NQ = 1, 2: a RAGGED last tile (K mod 16 in 1..4 / 5..8) -- its pairs (a, NT-1) are multiplied with
 // v_mfma_f64_4x4x4_4b_f64 instead of the 16x16x4 instruction: one instruction = four independent 4x4x4 blocks =
@@ -66,7 +93,13 @@ struct GWave {
   static constexpr int NQR = RAG ? NQ : 1;
   static constexpr int PS = GW_WAVES / KS;
   static constexpr int P = NT * (NT + 1) / 2;
-  static constexpr int LO = G * P / PS, HI = (G + 1) * P / PS, CNT = HI - LO;
+  static constexpr int cost(int p) { return gw_cost(p, NT, NQ); }
+  static constexpr int bound(int g) { return gw_bound(g, NT, PS, NQ); }
+  static constexpr int cmax() { return gw_cmax(NT, PS, NQ); }
+  static __device__ __forceinline__ int bound_rt(int g) {   // the same for a run-time chunk index (PS <= 4)
+    return g <= 0 ? 0 : g == 1 ? gw_bound(1, NT, PS, NQ) : g == 2 ? gw_bound(2, NT, PS, NQ) : g == 3 ? gw_bound(3, NT, PS, NQ) : P;
+  }
+  static constexpr int LO = gw_bound(G, NT, PS, NQ), HI = gw_bound(G + 1, NT, PS, NQ), CNT = HI - LO;
   static constexpr unsigned mask() {
     unsigned m = 0;
     for (int p = LO; p < HI; ++p) m |= (1u << tri_a(p, NT)) | (1u << tri_b(p, NT));
@@ -294,7 +327,7 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
     });
   } else {
     constexpr int PS = GW::PS;
-    constexpr int CMAX = (GW::P + PS - 1) / PS;
+    constexpr int CMAX = GW::cmax();
     constexpr int R = (NB * BUF) / (256 * GW_WAVES) > 0 ? (NB * BUF) / (256 * GW_WAVES) : 1;
     constexpr int ROUNDS = (CMAX + R - 1) / R;
     __syncthreads();
@@ -304,7 +337,7 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
       for (int j = 0; j < R; ++j) {
         const int i = rd * R + j;
         if (i < GW::CNT) {
-          static_for<CNT>([&](auto IC) {   // the pair index selects the lane map at compile time
+          static_for<GW::CNT>([&](auto IC) {   // the pair index selects the lane map at compile time (empty chunks: nothing)
             constexpr int ii = decltype(IC)::value;
             if (ii == i) {
 #pragma unroll
@@ -317,7 +350,7 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
       for (int e = tid; e < PS * R * 256; e += 64 * GW_WAVES) {
         const int g2 = e / (R * 256), rem = e - g2 * (R * 256);
         const int j = rem >> 8, el = rem & 255;
-        const int lo2 = g2 * GW::P / PS, cnt2 = (g2 + 1) * GW::P / PS - lo2;
+        const int lo2 = GW::bound_rt(g2), cnt2 = GW::bound_rt(g2 + 1) - lo2;
         const int i = rd * R + j;
         if (i < cnt2) {
           double sum = 0.0;
@@ -549,7 +582,7 @@ __device__ __forceinline__ void gram_spec_consumer(int64_t N, double* __restrict
       for (int e = tid; e < PS * R * 256; e += 64 * GW_WAVES) {
         const int g2 = e / (R * 256), rem = e - g2 * (R * 256);
         const int j = rem >> 8, el = rem & 255;
-        const int lo2 = g2 * GW::P / PS, cnt2 = (g2 + 1) * GW::P / PS - lo2;
+        const int lo2 = GW::bound_rt(g2), cnt2 = GW::bound_rt(g2 + 1) - lo2;
         const int i = rd * R + j;
         if (i < cnt2) {
           double sum = 0.0;

@@ -4,7 +4,7 @@
 `roofline.traffic` is read from.  The record carries the sha256 of the kernel source it was measured on; bench.py reports
 `traffic: null` as soon as that source changes.
 
-    python3 tools/make_pmc_json.py gpurun_out/r2prof/pmc_dense_summary.txt profiles/r02_pmc_dense_main.json
+    python3 tools/make_pmc_json.py gpurun_out/r3prof/pmc_dense_summary.txt profiles/r03_pmc_dense_main.json
 """
 import hashlib
 import json

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box (run through gpurun from the repository root):
 #   kernel-trace statistics of bench.py and of the cfg4 CNN bench, PMC passes for the dominant kernels (separate passes,
-#   --kernel-trace only, as gpurun requires), the bench lines of every mode.  Everything lands in gpurun_out/r2prof/;
+#   --kernel-trace only, as gpurun requires), the bench lines of every mode.  Everything lands in gpurun_out/${ROUND:-r3}prof/;
 #   the summaries worth judging are copied into profiles/ by hand.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r2prof
+O=$R/gpurun_out/${ROUND:-r3}prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 echo "[1] bench.py under rocprofv3 --kernel-trace --stats"
