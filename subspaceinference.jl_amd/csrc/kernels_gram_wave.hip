@@ -51,39 +51,31 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// The tile pairs are dealt to the PS chunks of a workgroup by ISSUE COST, not by count: a pair of a ragged last column
-// (NQ < 4, see GWave) costs 0.3 NQ of a full pair -- with equal counts at K = 100 one chunk held 12 full + 2 ragged pairs,
-// the other 9 + 5: 12.6 against 10.5 issue slots per k step.  (Free functions: a class cannot use its own constexpr members
-// in the initialisers of its static data members.)
-__host__ __device__ constexpr int gw_cost(int p, int nt, int nq) { return (nq < 4 && tri_b(p, nt) == nt - 1) ? 3 * nq : 10; }
-__host__ __device__ constexpr int gw_bound(int g, int nt, int ps, int nq) {   // first pair of chunk g; gw_bound(ps) = P
+// The tile pairs are dealt to the PS chunks of a workgroup by COUNT.  (Dealing them by issue cost -- a pair of a ragged last
+// column at 0.3 of a full one -- was built and measured: 13 / 15 pairs per chunk at K = 100 took 0.38 ms against 0.30 ms
+// for 14 / 14, and the same happened at K = 104 with 16 / 12: the time of this kernel follows the LARGEST PAIR COUNT of a
+// wave, not the MFMA issue cycles of its chunk; profiles/r03_gram_ragged_ab.log.)
+__host__ __device__ constexpr int gw_bound(int g, int nt, int ps) {   // first pair of chunk g; gw_bound(ps) = P
   const int P = nt * (nt + 1) / 2;
-  if (g <= 0) return 0;
-  if (g >= ps) return P;
-  int total = 0;
-  for (int p = 0; p < P; ++p) total += gw_cost(p, nt, nq);
-  int cum = 0;
-  for (int p = 0; p < P; ++p) {
-    if (cum * ps >= total * g) return p;
-    cum += gw_cost(p, nt, nq);
-  }
-  return P;
+  return g <= 0 ? 0 : g >= ps ? P : g * P / ps;
 }
-__host__ __device__ constexpr int gw_cmax(int nt, int ps, int nq) {
+__host__ __device__ constexpr int gw_cmax(int nt, int ps) {
   int m = 0;
   for (int g = 0; g < ps; ++g) {
-    const int c = gw_bound(g + 1, nt, ps, nq) - gw_bound(g, nt, ps, nq);
+    const int c = gw_bound(g + 1, nt, ps) - gw_bound(g, nt, ps);
     m = c > m ? c : m;
   }
   return m;
 }
 
 // NQ: width of the LAST column tile in 4-column blocks.  NQ = 4: a full 16-column tile (or one whose padding is not worth
-// a special case); NQ = 1, 2: a RAGGED last tile (K mod 16 in 1..4 / 5..8) -- its pairs (a, NT-1) are multiplied with
+// a special case); NQ = 1: a RAGGED last tile (K mod 16 in 1..4; NQ = 2 works too but measured slower than the plain
+// kernel at K = 104 and is not instantiated) -- its pairs (a, NT-1) are multiplied with
 // v_mfma_f64_4x4x4_4b_f64 instead of the 16x16x4 instruction: one instruction = four independent 4x4x4 blocks =
 // 16 rows of tile a against ONE 4-column block of the last tile, at ~0.3 of the issue time of a 16x16x4 (measured:
 // tools/mfma_f64_4x4_probe.hip, 39.9 against 132 cycles on the same clock).  At K = 100 the last column of tile pairs
-// costs 7 x 0.3 instead of 7 issue slots: 23.1 instead of 28 per k step.  Operand layout of the 4x4x4_4b instruction
+// costs 7 x 0.3 instead of 7 issue slots: 23.1 instead of 28 per k step (measured gain of the whole kernel at cfg2: 0.261
+// -> 0.240 ms, see gw_bound below for why not more).  Operand layout of the 4x4x4_4b instruction
 // (probed, the guide has no table for it): A_b[i][k] in lane i + 4b + 16k, B_b[k][j] in lane j + 4b + 16k, D_b[i][j] in
 // lane j + 4b + 16i -- so the ordinary fragment of tile a IS the A operand (block b = rows 4b..4b+3 of the tile), and the
 // B operand is a 4-column block of the last tile repeated in all four blocks (its own LDS read, `fr`).
@@ -93,13 +85,9 @@ struct GWave {
   static constexpr int NQR = RAG ? NQ : 1;
   static constexpr int PS = GW_WAVES / KS;
   static constexpr int P = NT * (NT + 1) / 2;
-  static constexpr int cost(int p) { return gw_cost(p, NT, NQ); }
-  static constexpr int bound(int g) { return gw_bound(g, NT, PS, NQ); }
-  static constexpr int cmax() { return gw_cmax(NT, PS, NQ); }
-  static __device__ __forceinline__ int bound_rt(int g) {   // the same for a run-time chunk index (PS <= 4)
-    return g <= 0 ? 0 : g == 1 ? gw_bound(1, NT, PS, NQ) : g == 2 ? gw_bound(2, NT, PS, NQ) : g == 3 ? gw_bound(3, NT, PS, NQ) : P;
-  }
-  static constexpr int LO = gw_bound(G, NT, PS, NQ), HI = gw_bound(G + 1, NT, PS, NQ), CNT = HI - LO;
+  static constexpr int cmax() { return gw_cmax(NT, PS); }
+  static __device__ __forceinline__ int bound_rt(int g) { return g <= 0 ? 0 : g >= PS ? P : g * P / PS; }
+  static constexpr int LO = gw_bound(G, NT, PS), HI = gw_bound(G + 1, NT, PS), CNT = HI - LO;
   static constexpr unsigned mask() {
     unsigned m = 0;
     for (int p = LO; p < HI; ++p) m |= (1u << tri_a(p, NT)) | (1u << tri_b(p, NT));
@@ -134,7 +122,13 @@ struct GWave {
       } else {
         acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[a], f[b], acc[I], 0, 0, 0);
       }
+      // The hand placement (fragment reads behind MFMA 1, LDS-DMA pieces behind the following ones) must survive the
+      // machine scheduler: with the two MFMA shapes of a ragged chunk it regrouped the MFMAs, hoisted every LDS-DMA piece
+      // in front of them and put an s_waitcnt lgkmcnt(0) between the fragment reads and their group (measured: 0.30 -> 0.44
+      // ms at K = 104).  A scheduling barrier after every MFMA and after its hook keeps the source order.
+      if constexpr (RAG) __builtin_amdgcn_sched_barrier(0);
       hook(std::integral_constant<int, I>{});
+      if constexpr (RAG) __builtin_amdgcn_sched_barrier(0);
       mfma<I + 1, FIRST>(f, fr, acc, hook);
     }
   }
@@ -178,7 +172,7 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
   constexpr int H = (GR / 4) / KS;        // k steps of a slab owned by this wave
   constexpr int CNT = GW::CNT > 0 ? GW::CNT : 1;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int wave = KG + KS * G;   // the ROLE of this wave (which hardware wave plays it: gram_glds_kernel)
   const int q = lane >> 4, c = lane & 15;
   // LDS-DMA piece p of a slab: the 4 columns 16p + 4*wave .. +3; lane -> (column u = lane >> 4, slot j = lane & 15)
   const double* src[NT];
@@ -368,6 +362,8 @@ template <int NT, int KS, int NB, int OCC, int NQ>
 __global__ __launch_bounds__(64 * GW_WAVES, OCC) void gram_glds_kernel(const double* __restrict__ A, int64_t ldA, int64_t N, int K,
                                                                      double* __restrict__ Gpart) {
   extern __shared__ double sA[];  // [NB][NT*16][32]
+  // (Reversing the roles of the second workgroup of a CU, so that every SIMD carries one heavy and one light chunk, was
+  // measured: no difference.)
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
     case 0: gram_glds_body<NT, KS, 0 % KS, 0 / KS, NB, NQ>(A, ldA, N, K, Gpart, sA); break;
     case 1: gram_glds_body<NT, KS, 1 % KS, 1 / KS, NB, NQ>(A, ldA, N, K, Gpart, sA); break;
@@ -667,16 +663,13 @@ static void launch_nt_q(hipStream_t st, const double* A, int64_t ldA, int64_t N,
   hipLaunchKernelGGL((gram_glds_kernel<NT, KS, NB, 1, NQ>), dim3(nblocks), dim3(64 * GW_WAVES), lds, st, A, ldA, N, K, tiles);
 }
 
-// the last column tile holds K - 16 (NT - 1) columns: 1..4 -> one 4-column block, 5..8 -> two (the ragged variants on the
-// 4x4x4_4b instruction); 9..16 -> the plain kernel (three blocks would save 10 % of one column of tile pairs: not built)
+// the last column tile holds K - 16 (NT - 1) columns: 1..4 -> the ragged variant (one 4-column block on the 4x4x4_4b
+// instruction), else the plain kernel
 template <int NT, int KS, int KS2>
 static void launch_nt(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, double* tiles, int nblocks, int num_cu) {
   (void)num_cu;
-  const int wl = K - 16 * (NT - 1);
-  if (wl <= 4)
+  if (K - 16 * (NT - 1) <= 4)
     launch_nt_q<NT, KS, KS2, 1>(st, A, ldA, N, K, tiles, nblocks);
-  else if (wl <= 8)
-    launch_nt_q<NT, KS, KS2, 2>(st, A, ldA, N, K, tiles, nblocks);
   else
     launch_nt_q<NT, KS, KS2, 4>(st, A, ldA, N, K, tiles, nblocks);
 }

@@ -27,9 +27,19 @@ __global__ __launch_bounds__(256) void rate(double* out, int iters, int which) {
       c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c1, 0, 0, 0);
       c2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c2, 0, 0, 0);
       c3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c3, 0, 0, 0);
-    } else {
+    } else if (which == 1) {
       e0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, e0, 0, 0, 0);
       e1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, e1, 0, 0, 0);
+    } else if (which == 2) {   // alternating shapes: big small big small
+      e0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, e0, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c0, 0, 0, 0);
+      e1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, e1, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c1, 0, 0, 0);
+    } else {                   // grouped: big big small small
+      e0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, e0, 0, 0, 0);
+      e1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, e1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c1, 0, 0, 0);
     }
   }
   out[blockIdx.x * 256 + threadIdx.x] = c0 + c1 + c2 + c3 + e0[0] + e0[1] + e0[2] + e0[3] + e1[0] + e1[1] + e1[2] + e1[3];
@@ -51,7 +61,7 @@ int main() {
   // issue rate: 1024 blocks x 4 waves, dependent chains of 4 (4x4x4) / 2 (16x16x4) accumulators
   double* o;
   hipMalloc(&o, 1024 * 256 * sizeof(double));
-  for (int which = 0; which < 2; ++which) {
+  for (int which = 0; which < 4; ++which) {
     const int iters = 20000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -63,6 +73,12 @@ int main() {
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
+    if (which >= 2) {
+      // per iteration and wave: 2 x 16x16x4 + 2 x 4x4x4_4b; 4 waves per SIMD
+      printf("%s: %.3f ms = %.1f cycles per (2 big + 2 small) per SIMD-wave slot at 2.4 GHz\n",
+             which == 2 ? "alternating big/small" : "grouped big big small small", ms, ms * 1e-3 * 2.4e9 / (4.0 * iters));
+      continue;
+    }
     const double n_inst = (double)1024 * 4 * iters * (which == 0 ? 4 : 2);
     const double macs = n_inst * (which == 0 ? 256.0 : 1024.0);
     printf("%s: %.3f ms, %.2f TFLOP/s, %.1f cycles per instruction per SIMD at 2.4 GHz (1024 SIMDs)\n",
