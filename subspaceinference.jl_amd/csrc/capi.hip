@@ -111,6 +111,9 @@ static void free_infer(Ctx* c) {
   dev_free(c->d_yhat);
   for (auto& h : c->d_hs) dev_free(h);
   c->d_hs.clear();
+  for (auto& h : c->d_pidx) dev_free(h);
+  c->d_pidx.clear();
+  c->g_scratch.pidx = nullptr;
   dev_free(c->d_delta[0]);
   dev_free(c->d_delta[1]);
   dev_free(c->d_gw);
@@ -443,12 +446,14 @@ int32_t si_construct_push_batch_dev(si_ctx* ctx, const void* w_dev, int32_t w_dt
 // into pinned memory with the host copy pool (host_copy.cpp), queues H2D + K1 on the stream and RETURNS -- the DMA and
 // the kernel overlap the caller's next gradient / update!; the only wait is for the staging buffer of two pushes ago.
 static void free_push_staging(si_ctx* ctx) {
+  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   for (int b = 0; b < 2; ++b) {
     if (ctx->h_wpin[b]) (void)hipHostFree(ctx->h_wpin[b]);
     ctx->h_wpin[b] = nullptr;
     dev_free(ctx->d_wpush[b]);
     if (ctx->ev_wpin[b]) (void)hipEventDestroy(ctx->ev_wpin[b]);
-    ctx->ev_wpin[b] = nullptr;
+    if (ctx->ev_wk1[b]) (void)hipEventDestroy(ctx->ev_wk1[b]);
+    ctx->ev_wpin[b] = ctx->ev_wk1[b] = nullptr;
     ctx->wpin_busy[b] = false;
   }
   ctx->wpin_bytes = 0;
@@ -462,27 +467,37 @@ int32_t si_construct_push(si_ctx* ctx, const void* w_host, int32_t w_dtype, doub
   if (ctx->max_cols == 0 && ctx->K >= ctx->Kcap) return fail(ctx, SI_ERR_STATE, "si_construct_push: more pushes than K_capacity");
   BIND(ctx);
   const size_t bytes = (size_t)ctx->N * (w_dtype == SI_F32 ? 4 : 8);
+  if (!ctx->stream2) SI_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
   if (ctx->wpin_bytes < bytes) {
     SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_push_staging(ctx);
     for (int b = 0; b < 2; ++b) {
       if (hipHostMalloc(&ctx->h_wpin[b], bytes, hipHostMallocDefault) != hipSuccess ||
           hipMalloc(&ctx->d_wpush[b], bytes) != hipSuccess ||
-          hipEventCreateWithFlags(&ctx->ev_wpin[b], hipEventDisableTiming) != hipSuccess) {
+          hipEventCreateWithFlags(&ctx->ev_wpin[b], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ctx->ev_wk1[b], hipEventDisableTiming) != hipSuccess) {
         free_push_staging(ctx);
         return fail(ctx, SI_ERR_NOMEM, "si_construct_push: staging allocation failed");
       }
     }
     ctx->wpin_bytes = bytes;
   }
+  // Three stages in flight: the host copy pool fills pinned buffer b (push i), the copy stream moves pinned -> device
+  // buffer b, the compute stream runs K1 on it.  Buffer b of two pushes ago must be done: its H2D (host side: the pinned
+  // buffer is rewritten) and its K1 (copy stream: the device buffer is rewritten).  The H2Ds of consecutive pushes run back
+  // to back on their own stream -- on ONE stream the 9 us K1 sat between them and the link idled 10 % of the time.
   const int b = (int)(ctx->wpin_next & 1);
   ctx->wpin_next += 1;
-  if (ctx->wpin_busy[b]) SI_HIP(ctx, hipEventSynchronize(ctx->ev_wpin[b]));  // the H2D of two pushes ago has read this buffer
+  if (ctx->wpin_busy[b]) SI_HIP(ctx, hipEventSynchronize(ctx->ev_wpin[b]));
   host_copy(ctx->h_wpin[b], w_host, bytes);
-  SI_HIP(ctx, hipMemcpyAsync(ctx->d_wpush[b], ctx->h_wpin[b], bytes, hipMemcpyHostToDevice, ctx->stream));
-  SI_HIP(ctx, hipEventRecord(ctx->ev_wpin[b], ctx->stream));
+  if (ctx->wpin_busy[b]) SI_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_wk1[b], 0));
+  SI_HIP(ctx, hipMemcpyAsync(ctx->d_wpush[b], ctx->h_wpin[b], bytes, hipMemcpyHostToDevice, ctx->stream2));
+  SI_HIP(ctx, hipEventRecord(ctx->ev_wpin[b], ctx->stream2));
+  SI_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_wpin[b], 0));
   ctx->wpin_busy[b] = true;
-  return push_common(ctx, ctx->d_wpush[b], w_dtype, n);  // K1 of this push is ordered before the H2D of push + 2 on the stream
+  const int32_t rc = push_common(ctx, ctx->d_wpush[b], w_dtype, n);
+  if (rc == SI_OK) SI_HIP(ctx, hipEventRecord(ctx->ev_wk1[b], ctx->stream));
+  return rc;
 }
 
 int32_t si_construct_gram(si_ctx* ctx) {
@@ -1044,8 +1059,8 @@ static int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out
     if (yhat_out) *yhat_out = last;
     return SI_OK;
   }
-  const size_t nl_all = ctx->layers.size();
 #ifdef SI_DEV_KNOBS   // development build only: measured 1 % slower, not shipped
+  const size_t nl_all = ctx->layers.size();
   if (ctx->overlap_halves && nc == 1 && ctx->fuse_tail && !yhat_out && B >= 4096) {
     // EXPERIMENT: the batch in two halves on two streams -- layer 1 of half B runs beside layer 2 of
     // half A, so the output-store drain of one overlaps the MFMAs of the other inside ONE chain.  The halves meet on whole
@@ -1207,8 +1222,15 @@ static int32_t ensure_grad(si_ctx* ctx) {
     size_t nb, nr, nw, nd;
     net_scratch_sizes(p, B, ctx->num_cu, &nb, &nr, &nw, &nd);
     ctx->d_hs.assign(p.L.size(), nullptr);
+    ctx->d_pidx.assign(p.L.size(), nullptr);
     bool ok = true;
-    for (size_t l = 0; l < p.L.size() && ok; ++l) ok = dev_alloc(&ctx->d_hs[l], (size_t)p.L[l].out_elems * B) == hipSuccess;
+    for (size_t l = 0; l < p.L.size() && ok; ++l) {
+      if (net_grad_fused(p, l))   // Conv + MaxPool as one kernel: a byte index instead of the un-pooled activation
+        ok = dev_alloc(&ctx->d_pidx[l], net_pidx_bytes(p, l, B)) == hipSuccess;
+      else
+        ok = dev_alloc(&ctx->d_hs[l], (size_t)p.L[l].out_elems * B) == hipSuccess;
+    }
+    ctx->g_scratch.pidx = ctx->d_pidx.data();
     ok = ok && dev_alloc(&ctx->d_delta[0], (size_t)p.max_elems * B) == hipSuccess &&
          dev_alloc(&ctx->d_delta[1], (size_t)p.max_elems * B) == hipSuccess &&
          dev_alloc(&ctx->d_gw, (size_t)pad_ld(ctx->iN)) == hipSuccess && dev_alloc(&ctx->g_scratch.bwpart, nb) == hipSuccess &&
@@ -1218,6 +1240,9 @@ static int32_t ensure_grad(si_ctx* ctx) {
     if (!ok) {
       for (auto& h : ctx->d_hs) dev_free(h);
       ctx->d_hs.clear();
+      for (auto& h : ctx->d_pidx) dev_free(h);
+      ctx->d_pidx.clear();
+      ctx->g_scratch.pidx = nullptr;
       dev_free(ctx->d_delta[0]); dev_free(ctx->d_delta[1]); dev_free(ctx->d_gw); dev_free(ctx->g_scratch.bwpart);
       dev_free(ctx->g_scratch.rspart); dev_free(ctx->g_scratch.wt); dev_free(ctx->g_scratch.dbtmp); dev_free(ctx->d_ptgpart);
       dev_free(ctx->d_gz);
@@ -1279,7 +1304,7 @@ int32_t si_logdensity_grad(si_ctx* ctx, const double* z, double* lp_out, double*
     // generic path: forward with every output kept, d lp / d yhat = (y - yhat) / sigma^2, reverse sweep, P' g_w
     const NetPlan& p = ctx->plan;
     const double* xin = p.input_spatial ? ctx->d_Xc : ctx->d_X;
-    if ((rc = net_forward(ctx, p, ctx->d_w, xin, B, ctx->d_hs.data(), ctx->d_wpack)) != SI_OK) return rc;
+    if ((rc = net_forward(ctx, p, ctx->d_w, xin, B, ctx->d_hs.data(), ctx->d_wpack, false, nullptr, ctx->d_pidx.data())) != SI_OK) return rc;
     const int64_t d = (int64_t)ctx->out_dim * B;
     const double* yhat = ctx->d_hs[nl - 1];
     launch_sse(ctx->stream, yhat, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse);

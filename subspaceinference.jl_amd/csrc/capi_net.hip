@@ -5,6 +5,7 @@
 // chain batching) and only pass through net_plan() for validation.  No arithmetic happens on the host.
 #include <algorithm>
 
+#include "kernels_gemm.h"
 #include "si_internal.h"
 
 namespace si {
@@ -128,12 +129,25 @@ int32_t net_plan(Ctx* c, const char* who, const si_layer* layers, int L, int64_t
   return SI_OK;
 }
 
+static bool net_pool_fusable(const NetPlan& p, size_t l) {
+  if (l + 1 >= p.L.size() || p.L[l].kind != SI_LAYER_CONV) return false;
+  const LayerPlan &q = p.L[l], &m = p.L[l + 1];
+  return m.kind == SI_LAYER_MAXPOOL && m.KW == 2 && m.KH == 2 && m.sw == 2 && m.sh == 2 && q.Wo % 2 == 0 && q.Ho % 2 == 0;
+}
+// (the four later activations are applied to the POOLED tensor by the fused kernel: their window index would be taken on
+// pre-activations, where NNlib's approximate-equality test can differ in the last bits -- they keep the un-fused route)
+bool net_grad_fused(const NetPlan& p, size_t l) { return net_pool_fusable(p, l) && !act_is_extra(p.L[l].act); }
+size_t net_pidx_bytes(const NetPlan& p, size_t l, int64_t B) {
+  const LayerPlan& q = p.L[l];
+  return (size_t)q.Cop * (size_t)(q.Wo / 2) * (size_t)(q.Ho / 2) * (size_t)B;
+}
+
 void net_input(Ctx* c, const NetPlan& p, const double* X, double* Xc, int64_t B) {
   launch_whcn_to_cwhn(c->stream, X, Xc, p.in_W, p.in_H, p.in_C, p.in_Cp, B);
 }
 
 int32_t net_forward(Ctx* c, const NetPlan& p, const double* w, const double* xin, int64_t B, double* const* outs, double* wpack,
-                    bool pingpong, double** final_out) {
+                    bool pingpong, double** final_out, uint8_t* const* pidx) {
   hipStream_t st = c->stream;
   const double* h = xin;
   size_t executed = 0;
@@ -160,8 +174,18 @@ int32_t net_forward(Ctx* c, const NetPlan& p, const double* w, const double* xin
           ProfScope ps(c, SI_K_CONV_AUX, 0.0, ((double)q.KW * q.KH * q.C * q.Co + (double)q.Cop * q.Kp) * 8.0);
           launch_conv_pack(st, w + q.w_off, w + q.b_off, wpack + q.wp_off, wpack + q.bp_off, q.KW, q.KH, q.C, q.Co, q.Cp, q.Cop, q.Kp);
         }
-        const bool fuse_pool = pingpong && l + 1 < p.L.size() && p.L[l + 1].kind == SI_LAYER_MAXPOOL && p.L[l + 1].KW == 2 &&
-                               p.L[l + 1].KH == 2 && p.L[l + 1].sw == 2 && p.L[l + 1].sh == 2 && q.Wo % 2 == 0 && q.Ho % 2 == 0;
+        if (!pingpong && pidx && pidx[l] && net_grad_fused(p, l)) {
+          // gradient mode: conv + pool in one kernel; the pooled output and a byte index are all the reverse sweep needs
+          o = outs[l + 1];
+          if (final_out) *final_out = o;
+          ProfScope ps(c, SI_K_CONV, 2.0 * (double)q.KW * q.KH * q.C * q.Co * (double)npos,
+                       ((double)q.in_elems + (double)p.L[l + 1].out_elems * 1.125) * (double)B * 8.0 + (double)q.Cop * q.Kp * 8.0);
+          launch_conv_forward_pool2_idx(st, wpack + q.wp_off, wpack + q.bp_off, h, o, pidx[l], q.g, q.Cop, q.Kp, npos, q.act);
+          ++l;
+          ++executed;
+          break;
+        }
+        const bool fuse_pool = pingpong && net_pool_fusable(p, l);
         if (fuse_pool) {   // the pooled tensor is all the next layer reads: skip the MaxPool layer
           ProfScope ps(c, SI_K_CONV, 2.0 * (double)q.KW * q.KH * q.C * q.Co * (double)npos,
                        ((double)q.in_elems + (double)p.L[l + 1].out_elems) * (double)B * 8.0 + (double)q.Cop * q.Kp * 8.0);
@@ -235,7 +259,12 @@ int32_t net_backward(Ctx* c, const NetPlan& p, const double* w, const double* xi
         launch_whcn_to_cwhn(st, g, gn, q.Wi, q.Hi, q.C, q.Cp, B);   // back to channel-fastest, pad channels zero
         break;
       case SI_LAYER_MAXPOOL:
-        if (li > 0 && p.L[li - 1].kind == SI_LAYER_CONV) {
+        if (li > 0 && s.pidx && s.pidx[li - 1] && net_grad_fused(p, li - 1)) {
+          // the pair ran fused in the forward pass: Delta of the conv layer from (pooled gradient, pooled output, byte index)
+          const LayerPlan& cv = p.L[li - 1];
+          launch_pool2_bwd_idx(st, g, hout, s.pidx[li - 1], gn, cv.Cop, q.Wo, q.Ho, B, cv.act, s.rspart, cv.Co, gw + cv.b_off);
+          delta_ready = true;
+        } else if (li > 0 && p.L[li - 1].kind == SI_LAYER_CONV) {
           // the pool's input is a conv layer's output: route the gradient to the window maxima, multiply by act' and sum
           // the conv layer's bias gradient in the same pass
           const LayerPlan& cv = p.L[li - 1];

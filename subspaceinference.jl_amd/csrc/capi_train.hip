@@ -79,6 +79,7 @@ void free_train(Ctx* c) {
   release(t->rspart); release(t->ssepart); release(t->sse); release(t->part); release(t->Xc); release(t->wpack);
   release(t->scratch.bwpart); release(t->scratch.rspart); release(t->scratch.wt); release(t->scratch.dbtmp);
   for (auto& h : t->hs) release(h);
+  for (auto& h : t->pidx) release(h);
   delete t;
   c->train = nullptr;
 }
@@ -142,7 +143,14 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
             alloc(&t->bwpart, maxpart) && alloc(&t->rspart, (size_t)rowsum_chunks() * maxw) &&
             alloc(&t->ssepart, (size_t)t->sse_blocks) && alloc(&t->sse, 1) &&
             (!fuse_tail || alloc(&t->part, (size_t)t->fuse_slots * out_dim * batch_max));
-  for (int l = 0; l < L && ok; ++l) ok = alloc(&t->hs[(size_t)l], (size_t)plan.L[(size_t)l].out_elems * batch_max);
+  t->pidx.assign((size_t)L, nullptr);
+  for (int l = 0; l < L && ok; ++l) {
+    if (plan.has_conv && net_grad_fused(plan, (size_t)l))   // Conv + MaxPool as one kernel: a byte index instead of the activation
+      ok = alloc(&t->pidx[(size_t)l], net_pidx_bytes(plan, (size_t)l, batch_max));
+    else
+      ok = alloc(&t->hs[(size_t)l], (size_t)plan.L[(size_t)l].out_elems * batch_max);
+  }
+  t->scratch.pidx = t->pidx.data();
   if (!ok) {
     free_train(ctx);
     return fail(ctx, SI_ERR_NOMEM, "si_train_setup: device allocation failed");
@@ -186,7 +194,7 @@ static int32_t train_gradient(si_ctx* ctx, const char* who, const int64_t* idx, 
       net_input(ctx, p, t->Xb, t->Xc, nb);
       xin = t->Xc;
     }
-    int32_t rc = net_forward(ctx, p, t->w64, xin, nb, t->hs.data(), t->wpack);
+    int32_t rc = net_forward(ctx, p, t->w64, xin, nb, t->hs.data(), t->wpack, false, nullptr, t->pidx.data());
     if (rc != SI_OK) return rc;
     const int64_t d = (int64_t)t->out_dim * nb;
     const double* yhat = t->hs[nl - 1];

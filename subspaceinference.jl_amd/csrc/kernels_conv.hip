@@ -42,6 +42,11 @@ __device__ __forceinline__ double conv_dact(double h, int act) {
   }
 }
 
+// `y ≈ x` of NNlib's ∇maxpool (Julia isapprox: rtol = sqrt(eps), atol = 0), see pool_chosen below
+__device__ __forceinline__ bool pool_approx(double x, double y) {
+  return x == y || (isfinite(x) && isfinite(y) && fabs(x - y) <= 1.4901161193847656e-08 * fmax(fabs(x), fabs(y)));
+}
+
 // ------------------------------------------------------------------------------------------------ gather stagers
 // B operand of the forward / data-gradient GEMM: B(k', pos) = T[cin + Cp*(wi + Wi*(hi + Hi*img))] with
 //   (wi, hi) = ((wo, ho) * snum - pad + (a, c) * dil) / sden   (zero when out of range or not divisible by sden).
@@ -280,11 +285,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_kernel(const dou
 // of pooling window r of a 16-position slice are the four lane groups q = 0..3 of accumulator register r: two cross-lane
 // maxima, then lane group q stores window q -- Out[m + Mp * window] is the pooled CWHN tensor (4x fewer bytes written,
 // and the MaxPool pass with its read of the full activation disappears: 2.1 + 2.7 GB at the first layer of the cfg4 CNN).
-template <int BM, int BN, int WM, int WN, int MINW, bool CELLU>
+// IDX (gradient mode): additionally stores, per pooled element, WHICH of the four window inputs the reverse sweep routes
+// the gradient to -- the first one (dx + 2 dy order = NNlib's kw-fastest scan) that is ≈ the maximum -- as one byte.
+// With it the un-pooled activation never has to exist: act'(chosen input) = act'(pooled output), so the Delta tensor
+// of the layer follows from (pooled gradient, pooled output, index) alone (pool2_bwd_idx_kernel).
+template <int BM, int BN, int WM, int WN, int MINW, bool CELLU, bool IDX>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_pool_kernel(const double* __restrict__ Wp, int Mp,
                                                                             const double* __restrict__ T, double* __restrict__ Out,
                                                                             const double* __restrict__ bias, ConvGeom g, int64_t npos,
-                                                                            int Kp, int act, int nMt, int64_t nNt) {
+                                                                            int Kp, int act, int nMt, int64_t nNt,
+                                                                            uint8_t* __restrict__ Idx) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   using SA = Stager<BM, 0, NT, true>;
@@ -326,16 +336,26 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_pool_kernel(cons
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       double v[4];
+      int ix[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        double t = conv_act(acc[a][b][r] + bv, act);
-        t = fmax(t, __shfl_xor(t, 16));
+        const double own = conv_act(acc[a][b][r] + bv, act);   // input q of window r
+        double t = fmax(own, __shfl_xor(own, 16));
         t = fmax(t, __shfl_xor(t, 32));
         v[r] = t;
+        if constexpr (IDX) {
+          int cand = pool_approx(t, own) ? q : 4;
+          cand = min(cand, __shfl_xor(cand, 16));
+          cand = min(cand, __shfl_xor(cand, 32));
+          ix[r] = cand;
+        }
       }
       const double o = q == 0 ? v[0] : q == 1 ? v[1] : q == 2 ? v[2] : v[3];
       const int64_t win = ((n0 + wn * (BN / WN) + b * 16) >> 2) + q;
-      if (gm < Mp && win < nwin) Out[gm + (int64_t)Mp * win] = o;
+      if (gm < Mp && win < nwin) {
+        Out[gm + (int64_t)Mp * win] = o;
+        if constexpr (IDX) Idx[gm + (int64_t)Mp * win] = (uint8_t)(q == 0 ? ix[0] : q == 1 ? ix[1] : q == 2 ? ix[2] : ix[3]);
+      }
     }
   }
 }
@@ -441,9 +461,9 @@ void launch_conv_forward(hipStream_t st, const double* Wp, const double* bp, con
   launch_conv_gemm<false, true>(st, Wp, COUTp, In, Out, bp, g, npos, Kp, act);
 }
 
-template <int BM, bool CELLU>
+template <int BM, bool CELLU, bool IDX>
 static void launch_conv_pool_bm(hipStream_t st, const double* Wp, int Mp, const double* T, double* Out, const double* bias,
-                                const ConvGeom& g, int64_t npos, int Kp, int act) {
+                                const ConvGeom& g, int64_t npos, int Kp, int act, uint8_t* Idx) {
   constexpr int BN = 128, WM = 2, WN = 4, NT = 512;
   using SA = Stager<BM, 0, NT, true>;
   using SB = GatherK<BN, NT, CELLU, false, true>;
@@ -451,10 +471,29 @@ static void launch_conv_pool_bm(hipStream_t st, const double* Wp, int Mp, const 
   const int nMt = (Mp + BM - 1) / BM;
   const int64_t nNt = (npos + BN - 1) / BN;
   const int64_t grid = nNt >= 8 ? (nNt + 7) / 8 * nMt * 8 : nNt * nMt;
-  auto kern = conv_gemm_pool_kernel<BM, BN, WM, WN, 4, CELLU>;
+  auto kern = conv_gemm_pool_kernel<BM, BN, WM, WN, 4, CELLU, IDX>;
   static LdsOptIn optin;
   optin.ensure(reinterpret_cast<const void*>(kern), lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, Wp, Mp, T, Out, bias, g, npos, Kp, act, nMt, nNt);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, Wp, Mp, T, Out, bias, g, npos, Kp, act, nMt, nNt, Idx);
+}
+template <bool IDX>
+static void launch_conv_pool_any(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, const ConvGeom& g,
+                                 int COUTp, int Kp, int64_t npos, int act, uint8_t* Idx) {
+  const bool cellu = g.Cp % 16 == 0;
+  const int bm = conv_pick_bm(COUTp);
+#define SI_POOL_CASE(BM)                                                                         \
+  if (cellu)                                                                                     \
+    launch_conv_pool_bm<BM, true, IDX>(st, Wp, COUTp, In, Out, bp, g, npos, Kp, act, Idx);      \
+  else                                                                                           \
+    launch_conv_pool_bm<BM, false, IDX>(st, Wp, COUTp, In, Out, bp, g, npos, Kp, act, Idx)
+  if (bm == 64) {
+    SI_POOL_CASE(64);
+  } else if (bm == 96) {
+    SI_POOL_CASE(96);
+  } else {
+    SI_POOL_CASE(128);
+  }
+#undef SI_POOL_CASE
 }
 // conv + bias + act + MaxPool((2, 2), stride 2) -> pooled CWHN tensor; needs even Wo and Ho (the caller checks)
 void launch_conv_forward_pool2(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, const ConvGeom& g,
@@ -464,21 +503,13 @@ void launch_conv_forward_pool2(hipStream_t st, const double* Wp, const double* b
     launch_act_inplace(st, Out, (int64_t)COUTp * (npos / 4), act);
     return;
   }
-  const bool cellu = g.Cp % 16 == 0;
-  const int bm = conv_pick_bm(COUTp);
-#define SI_POOL_CASE(BM)                                                              \
-  if (cellu)                                                                          \
-    launch_conv_pool_bm<BM, true>(st, Wp, COUTp, In, Out, bp, g, npos, Kp, act);     \
-  else                                                                                \
-    launch_conv_pool_bm<BM, false>(st, Wp, COUTp, In, Out, bp, g, npos, Kp, act)
-  if (bm == 64) {
-    SI_POOL_CASE(64);
-  } else if (bm == 96) {
-    SI_POOL_CASE(96);
-  } else {
-    SI_POOL_CASE(128);
-  }
-#undef SI_POOL_CASE
+  launch_conv_pool_any<false>(st, Wp, bp, In, Out, g, COUTp, Kp, npos, act, nullptr);
+}
+// the same in GRADIENT mode (identity / relu / tanh / sigmoid only): also the window index the reverse sweep needs (one byte per
+// pooled element, Idx[m + COUTp * window]); the un-pooled activation is neither stored nor read again
+void launch_conv_forward_pool2_idx(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, uint8_t* Idx,
+                                   const ConvGeom& g, int COUTp, int Kp, int64_t npos, int act) {
+  launch_conv_pool_any<true>(st, Wp, bp, In, Out, g, COUTp, Kp, npos, act, Idx);
 }
 
 void launch_conv_backward_data(hipStream_t st, const double* Wt, const double* Delta, double* dX, const ConvGeom& gT, int CINp,
@@ -676,9 +707,6 @@ void launch_maxpool(hipStream_t st, const double* In, double* Out, int Cp, int W
 // inputs are walked `for kh in 1:kernel_h, kw in 1:kernel_w` (kw fastest) and the window's gradient goes to the FIRST input
 // with `y ≈ x` (`maxpool_already_chosen`; isapprox: rtol = sqrt(eps), atol = 0) -- ONE element per window, not every
 // element equal to the maximum: exact ties (constant image regions -> conv output = bias) would otherwise count 4 times.
-__device__ __forceinline__ bool pool_approx(double x, double y) {
-  return x == y || (isfinite(x) && isfinite(y) && fabs(x - y) <= 1.4901161193847656e-08 * fmax(fabs(x), fabs(y)));
-}
 // does input (a, d) of the window whose first input is at `win0` (element stride `es`, row stride `rs`) receive the
 // window's gradient?  x = that input's value, ymax = the window's stored maximum
 __device__ __forceinline__ bool pool_chosen(const double* __restrict__ win0, int64_t es, int64_t rs, double x, double ymax, int a,
@@ -850,6 +878,72 @@ void launch_maxpool_bwd_dact_rowsum(hipStream_t st, const double* In, const doub
   const int64_t per = (ncols + nch - 1) / nch;
   hipLaunchKernelGGL(dact_rowsum_kernel<true>, dim3((Cp + 63) / 64, nch), dim3(256), 0, st, Gout, In, Out, Cp, ncols, per, act, D,
                      part, Wi, Hi, Wo, Ho, PW, PH, sw, sh);
+  hipLaunchKernelGGL(rowsum_chunks_final_kernel, dim3((nout + 63) / 64), dim3(1024), 0, st, part, Cp, nch, nout, db);
+}
+
+// Reverse sweep through Conv -> MaxPool((2, 2)) whose forward ran fused in gradient mode (conv_gemm_pool_kernel<IDX>): the Delta
+// tensor of the conv layer from the POOLED gradient, the POOLED output and the byte index alone --
+//   D[m, position k of window w] = (k == Idx[m, w]) ? G[m, w] * act'(Hp[m, w]) : 0,    db[m] = sum_w G[m, w] * act'(Hp[m, w])
+// (the chosen input equals the pooled output, so act' can be rebuilt from it).  Reads 2 * 8 + 1 bytes per pooled element and
+// writes the 4 * 8 bytes of D: 3.2 GB instead of 5.3 GB behind the first layer of the cfg4 CNN, and the forward no longer
+// writes (2.1 GB) and re-reads (MaxPool pass, 2.1 GB) the un-pooled activation.  Same block shape and fixed-order sums as
+// dact_rowsum_kernel: 64 rows x 4 window phases, chunks of windows in grid.y.
+__global__ __launch_bounds__(256) void pool2_bwd_idx_kernel(const double* __restrict__ G, const double* __restrict__ Hp,
+                                                            const uint8_t* __restrict__ Idx, int rows, int64_t nwin, int64_t per,
+                                                            int act, double* __restrict__ D, double* __restrict__ part, int W2,
+                                                            int H2) {
+  __shared__ double red[4][64];
+  const int il = threadIdx.x & 63, cl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + il;
+  const int64_t b0 = (int64_t)blockIdx.y * per;
+  int64_t b1 = b0 + per;
+  if (b1 > nwin) b1 = nwin;
+  double s = 0.0;
+  if (i < rows) {
+    int64_t b = b0 + cl;
+    // window (w2, h2, image n) of index b, advanced by 4 windows per iteration (one carry per digit)
+    int w2 = (int)(b % W2);
+    const int64_t t = b / W2;
+    int h2 = (int)(t % H2);
+    int64_t n = t / H2;
+    const int dw = 4 % W2, dh = (4 / W2) % H2;
+    const int64_t dn = 4 / ((int64_t)W2 * H2);
+    const int Wf = 2 * W2, Hf = 2 * H2;
+#pragma unroll 2
+    for (; b < b1; b += 4) {
+      const int64_t off = i + (int64_t)rows * b;
+      const double d = G[off] * conv_dact(Hp[off], act);
+      const int k = Idx[off];
+      s += k < 4 ? d : 0.0;   // (k = 4: no input was ≈ the maximum, e.g. a NaN -- nothing is routed, as in the reference)
+      const int64_t p00 = (2 * w2) + (int64_t)Wf * ((2 * h2) + (int64_t)Hf * n);
+      double* dst = D + i + (int64_t)rows * p00;
+      dst[0] = k == 0 ? d : 0.0;
+      dst[rows] = k == 1 ? d : 0.0;
+      dst[(int64_t)rows * Wf] = k == 2 ? d : 0.0;
+      dst[(int64_t)rows * (Wf + 1)] = k == 3 ? d : 0.0;
+      w2 += dw;
+      h2 += dh;
+      n += dn;
+      if (w2 >= W2) {
+        w2 -= W2;
+        ++h2;
+      }
+      if (h2 >= H2) {
+        h2 -= H2;
+        ++n;
+      }
+    }
+  }
+  red[cl][il] = s;
+  __syncthreads();
+  if (cl == 0 && i < rows) part[(int64_t)blockIdx.y * rows + i] = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
+}
+void launch_pool2_bwd_idx(hipStream_t st, const double* G, const double* Hp, const uint8_t* Idx, double* D, int Cp, int W2, int H2,
+                          int64_t B, int act, double* part, int nout, double* db) {
+  const int64_t nwin = (int64_t)W2 * H2 * B;
+  const int nch = dact_rowsum_chunks(Cp, nwin);
+  const int64_t per = (nwin + nch - 1) / nch;
+  hipLaunchKernelGGL(pool2_bwd_idx_kernel, dim3((Cp + 63) / 64, nch), dim3(256), 0, st, G, Hp, Idx, Cp, nwin, per, act, D, part, W2, H2);
   hipLaunchKernelGGL(rowsum_chunks_final_kernel, dim3((nout + 63) / 64), dim3(1024), 0, st, part, Cp, nch, nout, db);
 }
 

@@ -55,6 +55,8 @@ struct NetPlan {
 };
 struct NetScratch {             // reverse-sweep workspaces (sized by net_scratch_sizes)
   double *bwpart = nullptr, *rspart = nullptr, *wt = nullptr, *dbtmp = nullptr;
+  // gradient mode: pidx[l] = byte index tensor of conv layer l whose MaxPool ran fused with it (net_grad_fused), else nullptr
+  uint8_t* const* pidx = nullptr;
 };
 
 // on-device training (capi_train.hip)
@@ -80,6 +82,7 @@ struct TrainState {
   NetPlan plan;
   double *Xc = nullptr, *wpack = nullptr;
   NetScratch scratch;
+  std::vector<uint8_t*> pidx;   // per layer: window-index bytes of a Conv layer fused with its MaxPool (net_grad_fused)
 };
 
 struct Ctx {
@@ -131,7 +134,8 @@ struct Ctx {
   // pipelined host pushes (si_construct_push): two pinned host buffers -> two device buffers, events mark the H2D of each
   void* h_wpin[2] = {nullptr, nullptr};
   void* d_wpush[2] = {nullptr, nullptr};
-  hipEvent_t ev_wpin[2] = {nullptr, nullptr};
+  hipEvent_t ev_wpin[2] = {nullptr, nullptr};   // H2D of buffer b done (copy stream)
+  hipEvent_t ev_wk1[2] = {nullptr, nullptr};    // K1 on buffer b done (compute stream)
   bool wpin_busy[2] = {false, false};
   size_t wpin_bytes = 0;
   uint64_t wpin_next = 0;
@@ -196,6 +200,7 @@ struct Ctx {
   double* d_Xc = nullptr;      // X re-laid channel-fastest (input_spatial)
   double* d_wpack = nullptr;   // packed conv weights of the current evaluation
   NetScratch g_scratch;
+  std::vector<uint8_t*> d_pidx;  // per layer: window-index bytes of a Conv layer fused with its MaxPool (gradient workspace)
   // sampler state (device)
   double* d_zcur = nullptr;   // M x C
   double* d_zprop = nullptr;  // M x C
@@ -331,6 +336,10 @@ void launch_conv_forward(hipStream_t st, const double* Wp, const double* bp, con
                          int COUTp, int Kp, int64_t npos, int act);
 void launch_conv_forward_pool2(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, const ConvGeom& g,
                          int COUTp, int Kp, int64_t npos, int act);
+void launch_conv_forward_pool2_idx(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, uint8_t* Idx,
+                                   const ConvGeom& g, int COUTp, int Kp, int64_t npos, int act);
+void launch_pool2_bwd_idx(hipStream_t st, const double* G, const double* Hp, const uint8_t* Idx, double* D, int Cp, int W2, int H2,
+                          int64_t B, int act, double* part, int nout, double* db);
 void launch_conv_backward_data(hipStream_t st, const double* Wt, const double* Delta, double* dX, const ConvGeom& gT, int CINp,
                                int KpT, int64_t npos_in);
 int conv_dw_splits(int COUTp, int Kp, int64_t npos, int num_cu, int64_t* ksplit_out);
@@ -363,8 +372,14 @@ void net_input(Ctx* c, const NetPlan& p, const double* X, double* Xc, int64_t B)
 // `outs[l]` receives layer l's output.  pingpong = true (density path: nothing but the last output is needed): `outs` holds TWO
 // buffers used alternately per EXECUTED layer, a Conv directly followed by MaxPool((2, 2)) on even sizes runs as one fused
 // kernel, and *final_out is the buffer that holds the last layer's output.
+// pidx != nullptr (gradient mode, outs[l] per layer): a Conv layer with net_grad_fused(p, l) runs fused with its MaxPool, writes
+// outs[l + 1] and pidx[l] and leaves outs[l] untouched (it may be nullptr)
 int32_t net_forward(Ctx* c, const NetPlan& p, const double* w, const double* xin, int64_t B, double* const* outs, double* wpack,
-                    bool pingpong = false, double** final_out = nullptr);
+                    bool pingpong = false, double** final_out = nullptr, uint8_t* const* pidx = nullptr);
+// Conv layer l directly followed by MaxPool((2, 2), stride 2) on even sizes, activation carried by the GEMM epilogue: in
+// gradient mode the pair runs as one kernel that keeps a byte index instead of the un-pooled activation
+bool net_grad_fused(const NetPlan& p, size_t l);
+size_t net_pidx_bytes(const NetPlan& p, size_t l, int64_t B);
 void net_scratch_sizes(const NetPlan& p, int64_t B, int num_cu, size_t* bwpart, size_t* rspart, size_t* wt, size_t* dbtmp);
 // g0 holds d / d(output of the last layer) (out_feat x B) on entry; g0 / g1: max_elems * B doubles each; hs[l]: kept outputs
 int32_t net_backward(Ctx* c, const NetPlan& p, const double* w, const double* xin, int64_t B, double* const* hs, double* g0,
