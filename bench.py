@@ -60,7 +60,7 @@ B, M, K_SNAP = 100000, 20, 100
 SIGMA_Z, SIGMA_M = 0.1, 1.0
 PEAK_F64_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet; the guide's table has no f64 row -- DESIGN.md section 4)
 PEAK_HBM_GBS = 8000.0
-PMC_PROFILE = "r02_pmc_dense_main.json"   # rocprofv3 --pmc passes of the dominant kernel (sha-keyed to kernels_gemm.hip)
+PMC_PROFILE = "r03_pmc_dense_main.json"   # rocprofv3 --pmc passes of the dominant kernel (sha-keyed to kernels_gemm.hip)
 CFG = {  # construct-only configurations
     "cfg2": dict(n=1047361, k=100, m=20),
     "cfg4": dict(n=5200266, k=200, m=20),
@@ -146,8 +146,12 @@ def glorot_flat(seed, dims=DIMS):
 
 
 def _sha16(path):
-    with open(path, "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    """sha256 of the CODE of a kernel source: `//` comments and blank lines are dropped first, so that a comment edit does
+    not orphan a PMC profile of the same machine code (tools/make_pmc_json.py hashes the same way)"""
+    import re
+    with open(path) as f:
+        code = "\n".join(ln for ln in (re.sub(r"//.*", "", raw).rstrip() for raw in f) if ln)
+    return hashlib.sha256(code.encode()).hexdigest()[:16]
 
 
 def pmc_traffic(profile, kernel_sources):
@@ -158,7 +162,7 @@ def pmc_traffic(profile, kernel_sources):
     if not os.path.exists(path):
         return None, "no PMC profile committed"
     rec = json.load(open(path))
-    want = rec.get("kernel_source_sha16", {})
+    want = rec.get("kernel_code_sha16", {})
     have = {s: _sha16(os.path.join(ROOT, "subspaceinference.jl_amd", "csrc", s)) for s in kernel_sources}
     if not want or any(want.get(s) != have[s] for s in kernel_sources):
         return None, "profiles/%s was taken on other kernel sources (sha mismatch): re-run tools/profile_round.sh + tools/make_pmc_json.py" % profile

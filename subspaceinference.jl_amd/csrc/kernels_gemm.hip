@@ -86,8 +86,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f64_kernel(
   double* sW = smem;                  // [2][BK][BMP]
   double* sH = smem + 2 * BK * BMP;   // [2][BN][BKP]
 
-  // XCD-aware block -> tile map: blocks b and b+8 share an XCD (its L2); give the nMt feature tiles of one
-  // batch panel to consecutive blocks of ONE XCD so the Hin panel is fetched into that L2 once.
+  // XCD-aware block -> tile map: blocks b and b+8 share an XCD (its L2); the nMt feature tiles of one batch panel go to
+  // consecutive blocks of ONE XCD so that they find the panel's k tiles in that L2 while they walk it together.  That is a
+  // locality HINT, not a guarantee: 64 resident workgroups per XCD span ~6.4 panels, and W (7.4 MB at 960 x 960) is
+  // re-streamed by every round of workgroups -- the PMC passes count 2.76 GB per launch against 0.79 GB algorithmic (3.5x;
+  // profiles/*_pmc_dense_main.json), served at ~1 TB/s mostly out of the Infinity Cache while the kernel is MFMA-bound.
   const int64_t bid = blockIdx.x;
   const int xcd = (int)(bid & 7);
   const int64_t j = bid >> 3;

@@ -28,7 +28,8 @@ for line in open(src):
         if m:
             vals[m.group(1)] = float(m.group(2))
 fetch_kb, write_kb = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
-sha = hashlib.sha256(open(os.path.join(ROOT, "subspaceinference.jl_amd", "csrc", "kernels_gemm.hip"), "rb").read()).hexdigest()[:16]
+_code = "\n".join(ln for ln in (re.sub(r"//.*", "", raw).rstrip() for raw in open(os.path.join(ROOT, "subspaceinference.jl_amd", "csrc", "kernels_gemm.hip"))) if ln)
+sha = hashlib.sha256(_code.encode()).hexdigest()[:16]   # code only: `//` comments and blank lines dropped (bench.py _sha16)
 # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
 busy = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (vals["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
 dur = sorted(vals["duration_ms_med"])[len(vals["duration_ms_med"]) // 2]
@@ -43,7 +44,7 @@ rec = {
     "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
     # W 960x960 + bias + head weights, the H panel 960 x B read once, the 8 head-partial slots x B written
     "algorithmic_bytes_per_launch": 791380480,
-    "kernel_source_sha16": {"kernels_gemm.hip": sha},
+    "kernel_code_sha16": {"kernels_gemm.hip": sha},
     "mfma_busy_fraction": busy,
     "effective_clock_ghz": vals["GRBM_GUI_ACTIVE"] / 8.0 / (dur * 1e-3) / 1e9,
     "lds_bank_conflict_cycles": vals.get("SQ_LDS_BANK_CONFLICT"),
