@@ -284,11 +284,31 @@ class Rank:
 
     def attach(self, ctx):
         """join the in-library RCCL communicator (one rank per GPU); under SI_BENCH_SHARE_GPU the ranks share a device,
-        which RCCL refuses, so the rehearsal stays on the gloo test double of dist.py"""
+        which RCCL refuses, so the rehearsal stays on the gloo test double of dist.py.  Should the communicator fail to
+        come up on ANY rank (it has never met more than one GPU before the driver's 8-GPU run), every rank drops it and
+        the run goes on over the gloo control plane -- the headline mode exchanges nothing per step -- with the error
+        reported in the line (`comm_error`) instead of a lost scaling curve."""
+        self.comm_error = None
         if self.dist is not None and not self.share_gpu:
+            import torch
             from subspaceinference_jl_amd import dist as sd
-            sd.comm_init(ctx)
-            self.ctx = ctx
+            err = ""
+            try:
+                sd.comm_init(ctx)
+                ctx.comm_barrier()
+            except Exception as e:   # noqa: BLE001 -- reported, not hidden
+                err = repr(e)
+            flags = [None] * self.world
+            self.dist.all_gather_object(flags, err)
+            if any(flags):
+                self.comm_error = "; ".join("rank %d: %s" % (r, f) for r, f in enumerate(flags) if f)
+                log("bench.py: in-library RCCL communicator unavailable (%s): continuing over gloo" % self.comm_error)
+                try:
+                    ctx.comm_destroy()
+                except Exception:   # noqa: BLE001
+                    pass
+            else:
+                self.ctx = ctx
         return ctx
 
     def count_ranks(self, device=None):
@@ -577,6 +597,9 @@ def run_chains(args, rk, real_stdout):
                                "sample (8.4 MB) streamed to a fresh pageable host array under the following transitions; "
                                "bit-identical to si_reconstruct: %s" % (args.steps, map_ok),
             "chain_1000_steps_samples_per_s": n_seen * 1000 / dt_1000,
+            "comm": ("in-library RCCL (si_comm_*), world %d" % n_seen) if rk.ctx is not None else
+                    ("none (one rank)" if rk.dist is None else "gloo control plane only"),
+            "comm_error": getattr(rk, "comm_error", None),
             "per_rank_ms_per_step": [round(t, 4) for t in per_rank_ms], "lp_last_per_rank": lp_per_rank,
             "chains_are_independent": bool(len(set(lp_per_rank)) == len(lp_per_rank)),
             "construct_wall_ms": construct_ms, "construct_wall_ms_runs": construct_runs,
