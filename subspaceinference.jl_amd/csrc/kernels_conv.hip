@@ -520,12 +520,19 @@ void launch_conv_backward_data(hipStream_t st, const double* Wt, const double* D
     launch_conv_gemm<false, false>(st, Wt, CINp, Delta, dX, nullptr, gT, npos_in, KpT, 0);
 }
 
+// A FIRST conv layer (few input channels: Kp <= 64 taps, COUTp <= 64 rows) gives the weight-gradient GEMM ONE output tile
+// and a k range of millions of positions: it is a stream over Delta, bound by the latency of one workgroup's two-deep
+// pipeline (1.19 ms at 1.9 TB/s at the cfg4 CNN with two 128-column workgroups per CU).  Such a layer takes 64-column
+// tiles (41 KB of LDS, half the idle MFMA columns) at THREE workgroups per CU.
+static bool conv_dw_narrow(int COUTp, int Kp) { return Kp <= 64 && COUTp <= 64; }
+
 int conv_dw_splits(int COUTp, int Kp, int64_t npos, int num_cu, int64_t* ksplit_out) {
   const int bm = conv_pick_bm(COUTp);
-  const int64_t tiles = (int64_t)((COUTp + bm - 1) / bm) * ((Kp + 127) / 128);
-  // two workgroups per CU are resident: round DOWN so that tiles * splits fits one residency round (rounding up left
-  // 3..28 workgroups for a second round that ran almost alone -- 515 / 522 / 540 workgroups on 512 slots at cfg4)
-  int64_t ns = ((int64_t)num_cu * 2) / tiles;
+  const bool narrow = conv_dw_narrow(COUTp, Kp);
+  const int64_t tiles = (int64_t)((COUTp + bm - 1) / bm) * (narrow ? 1 : (Kp + 127) / 128);
+  // two (narrow: three) workgroups per CU are resident: round DOWN so that tiles * splits fits one residency round (rounding
+  // up left 3..28 workgroups for a second round that ran almost alone -- 515 / 522 / 540 workgroups on 512 slots at cfg4)
+  int64_t ns = ((int64_t)num_cu * (narrow ? 3 : 2)) / tiles;
   const int64_t maxsplit = (npos + 255) / 256;
   ns = std::max<int64_t>(1, std::min(ns, maxsplit));
   const int64_t ks = ((npos + ns - 1) / ns + 15) / 16 * 16;
@@ -533,22 +540,22 @@ int conv_dw_splits(int COUTp, int Kp, int64_t npos, int num_cu, int64_t* ksplit_
   return (int)((npos + ks - 1) / ks);
 }
 
-template <int BM>
+template <int BM, int BN, int MINW>
 static void launch_conv_dw_bm(hipStream_t st, const double* Delta, int Mp, const double* In, double* part, const ConvGeom& g,
                               int64_t npos, int Kp, int nsplit, int64_t ksplit) {
-  constexpr int BN = 128, WM = 2, WN = 4, NT = 512;
+  constexpr int WM = 2, WN = 4, NT = 512;
   using SA = Stager<BM, 0, NT, true>;
   using SB = GatherN<BN, NT>;
   constexpr size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(double);
   const int nMt = (Mp + BM - 1) / BM, nNt = (Kp + BN - 1) / BN;
   if (npos % 16 == 0) {   // (ksplit is a multiple of 16 by construction)
-    auto kern = conv_dw_kernel<BM, BN, WM, WN, 4, true>;
+    auto kern = conv_dw_kernel<BM, BN, WM, WN, MINW, true>;
     static LdsOptIn optin;
     optin.ensure(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(nMt * nNt), (unsigned)nsplit), dim3(NT), lds, st, Delta, Mp, In, part, g, npos, Kp,
                        ksplit, nMt, nNt);
   } else {
-    auto kern = conv_dw_kernel<BM, BN, WM, WN, 4, false>;
+    auto kern = conv_dw_kernel<BM, BN, WM, WN, MINW, false>;
     static LdsOptIn optin;
     optin.ensure(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(nMt * nNt), (unsigned)nsplit), dim3(NT), lds, st, Delta, Mp, In, part, g, npos, Kp,
@@ -558,10 +565,14 @@ static void launch_conv_dw_bm(hipStream_t st, const double* Delta, int Mp, const
 
 void launch_conv_backward_weight(hipStream_t st, const double* Delta, const double* In, double* part, const ConvGeom& g,
                                  int COUTp, int Kp, int64_t npos, int nsplit, int64_t ksplit) {
+  if (conv_dw_narrow(COUTp, Kp)) {
+    launch_conv_dw_bm<64, 64, 6>(st, Delta, COUTp, In, part, g, npos, Kp, nsplit, ksplit);
+    return;
+  }
   switch (conv_pick_bm(COUTp)) {
-    case 64: launch_conv_dw_bm<64>(st, Delta, COUTp, In, part, g, npos, Kp, nsplit, ksplit); break;
-    case 96: launch_conv_dw_bm<96>(st, Delta, COUTp, In, part, g, npos, Kp, nsplit, ksplit); break;
-    default: launch_conv_dw_bm<128>(st, Delta, COUTp, In, part, g, npos, Kp, nsplit, ksplit); break;
+    case 64: launch_conv_dw_bm<64, 128, 4>(st, Delta, COUTp, In, part, g, npos, Kp, nsplit, ksplit); break;
+    case 96: launch_conv_dw_bm<96, 128, 4>(st, Delta, COUTp, In, part, g, npos, Kp, nsplit, ksplit); break;
+    default: launch_conv_dw_bm<128, 128, 4>(st, Delta, COUTp, In, part, g, npos, Kp, nsplit, ksplit); break;
   }
 }
 
