@@ -424,35 +424,59 @@ void launch_tail_bwd(hipStream_t st, const double* W, const double* Delta, const
 }
 
 // grad_z[m] = sum_r P[r + ldP*m] * g[r]   (HBM-bound: P is read once, N*M*8 bytes)
+// Four columns of P per sweep over a block's rows (g read once per four columns, one reduction round per four), fixed
+// summation order: thread-strided partial sums, xor-free shuffle tree, the four wave sums in order.
 constexpr int PTG_BLOCKS = 1024;
+constexpr int PTG_MT = 4;
 __global__ __launch_bounds__(256) void ptg_partial_kernel(const double* __restrict__ P, int64_t ldP, int64_t N, int M,
                                                           const double* __restrict__ g, double* __restrict__ part) {
-  __shared__ double red[4];
+  __shared__ double red[4][PTG_MT];
   const int64_t per = ((N + PTG_BLOCKS - 1) / PTG_BLOCKS + 1) / 2 * 2;
   const int64_t r0 = (int64_t)blockIdx.x * per;
   int64_t r1 = r0 + per;
   if (r1 > N) r1 = N;
-  for (int m = 0; m < M; ++m) {
-    double s = 0.0;
-    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) s += P[r + ldP * m] * g[r];
+  for (int m0 = 0; m0 < M; m0 += PTG_MT) {
+    double s[PTG_MT];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    for (int j = 0; j < PTG_MT; ++j) s[j] = 0.0;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+      const double gv = g[r];
+#pragma unroll
+      for (int j = 0; j < PTG_MT; ++j)
+        if (m0 + j < M) s[j] += P[r + ldP * (m0 + j)] * gv;
+    }
+#pragma unroll
+    for (int j = 0; j < PTG_MT; ++j) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s[j] += __shfl_down(s[j], off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int j = 0; j < PTG_MT; ++j) red[threadIdx.x >> 6][j] = s[j];
+    }
     __syncthreads();
-    if (threadIdx.x == 0) part[(int64_t)blockIdx.x * M + m] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x < PTG_MT && m0 + threadIdx.x < M)
+      part[(int64_t)blockIdx.x * M + m0 + threadIdx.x] =
+          (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     __syncthreads();
   }
 }
-__global__ void ptg_final_kernel(const double* __restrict__ part, int M, double* __restrict__ gz) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
+// one workgroup per m: 256 threads stride over the PTG_BLOCKS partials, fixed tree (a serial loop over 1024 dependent loads
+// per thread took 58 us)
+__global__ __launch_bounds__(256) void ptg_final_kernel(const double* __restrict__ part, int M, double* __restrict__ gz) {
+  __shared__ double red[4];
+  const int m = blockIdx.x;
   double s = 0.0;
-  for (int b = 0; b < PTG_BLOCKS; ++b) s += part[(int64_t)b * M + m];
-  gz[m] = s;
+  for (int b = threadIdx.x; b < PTG_BLOCKS; b += 256) s += part[(int64_t)b * M + m];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) gz[m] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 void launch_ptg(hipStream_t st, const double* P, int64_t ldP, int64_t N, int M, const double* g, double* part, double* gz) {
   hipLaunchKernelGGL(ptg_partial_kernel, dim3(PTG_BLOCKS), dim3(256), 0, st, P, ldP, N, M, g, part);
-  hipLaunchKernelGGL(ptg_final_kernel, dim3((M + 63) / 64), dim3(64), 0, st, part, M, gz);
+  hipLaunchKernelGGL(ptg_final_kernel, dim3(M), dim3(256), 0, st, part, M, gz);
 }
 int ptg_blocks() { return PTG_BLOCKS; }
 
