@@ -5,7 +5,8 @@ directly; `import subspaceinference_jl_amd` (the shim module at the repository r
 
 Layout: csrc/ (HIP kernels + the C ABI of include/subspace_hip.h), _capi.py (ctypes binding), api.py (the
 reference's exported functions), flux.py (caller-side stand-ins for the Flux objects the API takes),
-dist.py (one-process-per-GPU plumbing over torch.distributed / RCCL), julia/ (the ccall wrapper).
+dist.py (thin caller of the library's own RCCL communicator, si_comm_*; torch.distributed only ships the id and
+serves as the CPU test double), julia/ (the ccall wrapper).
 """
 from . import flux  # noqa: F401
 from ._capi import BoundsError, Context, SubspaceError, host_sym_eig, host_sym_eig_top, load  # noqa: F401

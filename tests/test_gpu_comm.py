@@ -3,7 +3,6 @@ in the collective path.  The test box has one GPU and RCCL refuses two ranks on 
 world 1 (several in one process, each its own id): every in-library collective must then be the identity and the
 sharded flows must give the SAME BITS as the single-GPU entry points -- same kernels, same order, only the exchange
 differs.  World 2 of the same host flows runs over the gloo test double in tests/test_dist_cpu.py."""
-import os
 
 import numpy as np
 import pytest

@@ -2,9 +2,6 @@
 round 1 are the reference here -- the device paths must give the SAME BITS (same kernels, same order; only the staging
 differs).  The in-library RCCL collectives are in tests/test_gpu_comm.py."""
 import os
-import socket
-import subprocess
-import sys
 
 import numpy as np
 import pytest

@@ -32,7 +32,8 @@ print("N=%d K=%d M=%d (%s): projection %.3f ms = %.2f TB/s algorithmic, %.1f TFL
     N, K, M, "GEMM" if os.environ.get("SI_PROJECT_GEMM") == "1" else "slab stream", st["ms"],
     st["bytes"] / st["ms"] / 1e9, st["flops"] / st["ms"] / 1e9, s[0], s[-1]))
 wptr, pptr, ld, _ = ctx.construct_result_ptr()
-from subspaceinference_jl_amd.dist import _dev_view  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+from gpu_helpers import dev_view as _dev_view  # noqa: E402
 p_t = _dev_view(pptr, (M, ld))
 ptp = (p_t @ p_t.T).cpu().numpy()
 print("  max |P'P - diag(s^2)| / s1^2 = %.2e" % (np.abs(ptp - np.diag(s ** 2)).max() / s[0] ** 2))
