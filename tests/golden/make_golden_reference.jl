@@ -7,7 +7,7 @@
 # see identical bits), with every quantity computed by the reference's own code:
 #
 #     julia --project=/path/to/SubspaceInference.jl tests/golden/make_golden_reference.jl
-#     python -m pytest tests/test_oracle.py -k reference          # compares *_reference.npz with the oracle when present
+#     python -m pytest tests/test_oracle.py -k reference_fixtures   # holds the oracle against *_reference.npz when present
 #
 # What can be pinned this way (deterministic parts): W_swa, A (bit for bit), P up to column sign and s (psvd, rtol 1e-8),
 # log-density values, forward outputs, the gradient of the log-density, the optimiser steps.  What cannot: the RWMH chain
