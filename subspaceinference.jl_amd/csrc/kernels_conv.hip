@@ -360,6 +360,151 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_pool_kernel(cons
   }
 }
 
+// ------------------------------------------------------------------------------------------------ first layers
+// A FIRST conv layer (few input channels: Kvalid = Cp*KW*KH <= 36 taps, COUTp <= 64) fused with MaxPool((2, 2)).  In the
+// GEMM pipeline above such a layer is all prologue and epilogue: 3 k tiles per 64 x 128 output tile, 32 768 workgroups
+// at the cfg4 CNN, 0.72 ms against 0.25 ms of matrix-pipe time.  Here a WAVE owns 16 positions x all output channels:
+//   * the packed weights (<= 41 KB) sit in LDS for the whole kernel ([k'][COUT16 + 16]: conflict-free operand reads);
+//   * the patch operand needs NO staging at all: k' = cin + Cp*tap, so MFMA k step s, lane (q, c) wants input channel /
+//     tap (4s + q) of position c -- ONE 8-byte global load per lane and k step, coalesced over the 4 channels of a pixel
+//     and the neighbouring pixels, the next slice's fragments in flight under this slice's MFMAs;
+//   * no barrier after the weights are in; waves walk the position slices grid-stride (window-major order, so the pooling
+//     epilogue is the one of conv_gemm_pool_kernel: two cross-lane maxima per accumulator register).
+// The k steps run in the same order with the same 4-wide grouping as the GEMM pipeline and skipped steps only ever added
+// zeros, so the results are bit-identical to conv_gemm_pool_kernel's.
+template <int NS, int NTM, bool IDX>
+__global__ __launch_bounds__(256, 2) void conv_first_pool_kernel(const double* __restrict__ Wp, int Mp, const double* __restrict__ T,
+                                                              double* __restrict__ Out, const double* __restrict__ bias, ConvGeom g,
+                                                              int64_t npos, int Kp, int act, uint8_t* __restrict__ Idx) {
+  constexpr int MP = NTM * 16 + 16;   // LDS row pitch
+  extern __shared__ double sW[];      // [4 * NS][MP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, c = lane & 15;
+  for (int e = tid; e < 4 * NS * MP; e += 256) {
+    const int k = e / MP, m = e - k * MP;
+    sW[e] = (k < Kp && m < Mp) ? Wp[m + (int64_t)Mp * k] : 0.0;
+  }
+  // tap (a, c) and input channel of this lane's k index in every k step: position-independent, packed into one register
+  // per k step (offsets biased by 128; bit 31 = a padded k index, reads as zero)
+  unsigned tp[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int kp = 4 * s + q;
+    const int tap = kp / g.Cp, cc = tap / g.KW;
+    const int aw = (tap - cc * g.KW) * g.dil_w - g.pad_w + 128, ch = cc * g.dil_h - g.pad_h + 128;
+    tp[s] = (unsigned)(kp - tap * g.Cp) | ((unsigned)(aw & 0xff) << 8) | ((unsigned)(ch & 0xff) << 16) |
+            (kp < g.Kvalid ? 0u : 0x80000000u);
+  }
+  __syncthreads();
+  const int W2 = g.Wo >> 1, wh2 = W2 * (g.Ho >> 1);
+  const int64_t nslice = (npos + 15) >> 4, nwin = npos >> 2;
+  const int64_t sstride = (int64_t)gridDim.x * 4;
+  auto gather = [&](int64_t sl, double(&f)[NS]) {
+    int64_t pos = 16 * sl + c;
+    if (pos > npos - 1) pos = npos - 1;   // (npos is a multiple of 4; clamped positions feed windows that are never stored)
+    const int64_t win = pos >> 2;
+    const int e = (int)(pos & 3);
+    const int img = (int)(win / wh2), sp = (int)(win - (int64_t)img * wh2);
+    const int ho2 = sp / W2, wo2 = sp - ho2 * W2;
+    const int wb = (2 * wo2 + (e & 1)) * g.snum_w, hb = (2 * ho2 + (e >> 1)) * g.snum_h;
+    const double* base = T + (int64_t)img * g.img_stride;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int wi = wb + (int)((tp[s] >> 8) & 0xff) - 128, hi = hb + (int)((tp[s] >> 16) & 0xff) - 128;
+      const bool ok = (int)tp[s] >= 0 && wi >= 0 && hi >= 0 && wi < g.Wi && hi < g.Hi;
+      const double v = base[ok ? g.Cp * (wi + g.Wi * hi) + (int)(tp[s] & 0xff) : 0];
+      f[s] = ok ? v : 0.0;
+    }
+  };
+  double bv[NTM];
+#pragma unroll
+  for (int t = 0; t < NTM; ++t) bv[t] = 16 * t + c < Mp ? bias[16 * t + c] : 0.0;
+  const double* wfrag = sW + q * MP + c;
+  int64_t sl = (int64_t)blockIdx.x * 4 + wave;
+  double fcur[NS], fnext[NS];
+  if (sl < nslice) gather(sl, fcur);
+  for (; sl < nslice; sl += sstride) {
+    const bool more = sl + sstride < nslice;
+    if (more) gather(sl + sstride, fnext);   // in flight under the MFMAs below
+    d4 acc[NTM];
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int t = 0; t < NTM; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fcur[s], wfrag[4 * s * MP + 16 * t], acc[t], 0, 0, 0);
+    }
+    // D[position q + 4r][channel c]: window r of the slice, input q of the window
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) {
+      const int gm = 16 * t + c;
+      double v[4];
+      int ix[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double own = conv_act(acc[t][r] + bv[t], act);
+        double mx = fmax(own, __shfl_xor(own, 16));
+        mx = fmax(mx, __shfl_xor(mx, 32));
+        v[r] = mx;
+        if constexpr (IDX) {
+          int cand = pool_approx(mx, own) ? q : 4;
+          cand = min(cand, __shfl_xor(cand, 16));
+          cand = min(cand, __shfl_xor(cand, 32));
+          ix[r] = cand;
+        }
+      }
+      const double o = q == 0 ? v[0] : q == 1 ? v[1] : q == 2 ? v[2] : v[3];
+      const int64_t win = 4 * sl + q;
+      if (gm < Mp && win < nwin) {
+        Out[gm + (int64_t)Mp * win] = o;
+        if constexpr (IDX) Idx[gm + (int64_t)Mp * win] = (uint8_t)(q == 0 ? ix[0] : q == 1 ? ix[1] : q == 2 ? ix[2] : ix[3]);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) fcur[s] = fnext[s];
+    }
+  }
+}
+
+static bool conv_first_applies(const ConvGeom& g, int COUTp) {
+  // (tap offsets are packed into a byte each, biased by 128; up to 9 k steps: the compiler keeps the loop-invariant weight
+  // fragments in registers, 8 per k step and channel tile -- at 16 k steps the kernel spilled)
+  return g.Kvalid <= 36 && COUTp <= 64 && g.sden_w == 1 && g.sden_h == 1 && g.Cp <= 64 && g.pad_w < 100 && g.pad_h < 100 &&
+         (g.KW - 1) * g.dil_w < 100 && (g.KH - 1) * g.dil_h < 100;
+}
+
+template <int NS, bool IDX>
+static void launch_conv_first_ns(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, uint8_t* Idx,
+                                 const ConvGeom& g, int COUTp, int Kp, int64_t npos, int act) {
+  const int ntm = (COUTp + 15) / 16;
+  const int64_t nslice = (npos + 15) / 16;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, (nslice + 3) / 4));
+#define SI_FIRST_CASE(NTM)                                                                                                  \
+  {                                                                                                                         \
+    constexpr size_t lds = (size_t)4 * NS * (NTM * 16 + 16) * sizeof(double);                                               \
+    hipLaunchKernelGGL((conv_first_pool_kernel<NS, NTM, IDX>), dim3(grid), dim3(256), lds, st, Wp, COUTp, In, Out, bp, g,   \
+                       npos, Kp, act, Idx);                                                                                 \
+  }
+  switch (ntm) {
+    case 1: SI_FIRST_CASE(1) break;
+    case 2: SI_FIRST_CASE(2) break;
+    case 3: SI_FIRST_CASE(3) break;
+    default: SI_FIRST_CASE(4) break;
+  }
+#undef SI_FIRST_CASE
+}
+template <bool IDX>
+static void launch_conv_first(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, uint8_t* Idx,
+                              const ConvGeom& g, int COUTp, int Kp, int64_t npos, int act) {
+  const int ns = (g.Kvalid + 3) / 4;   // k steps that carry taps; the instantiation rounds up, the surplus reads zeros
+  if (ns <= 5)
+    launch_conv_first_ns<5, IDX>(st, Wp, bp, In, Out, Idx, g, COUTp, Kp, npos, act);
+  else
+    launch_conv_first_ns<9, IDX>(st, Wp, bp, In, Out, Idx, g, COUTp, Kp, npos, act);
+}
+
 // part[split][m + Mp*k'] = sum over the split's positions of Delta[m + Mp*pos] * patch[k', pos]
 // NOEDGE: npos % 16 == 0, so every split is a whole number of k tiles (the ragged-tile code is not compiled in)
 template <int BM, int BN, int WM, int WN, int MINW, bool NOEDGE>
@@ -503,12 +648,20 @@ void launch_conv_forward_pool2(hipStream_t st, const double* Wp, const double* b
     launch_act_inplace(st, Out, (int64_t)COUTp * (npos / 4), act);
     return;
   }
+  if (conv_first_applies(g, COUTp)) {
+    launch_conv_first<false>(st, Wp, bp, In, Out, nullptr, g, COUTp, Kp, npos, act);
+    return;
+  }
   launch_conv_pool_any<false>(st, Wp, bp, In, Out, g, COUTp, Kp, npos, act, nullptr);
 }
 // the same in GRADIENT mode (identity / relu / tanh / sigmoid only): also the window index the reverse sweep needs (one byte per
 // pooled element, Idx[m + COUTp * window]); the un-pooled activation is neither stored nor read again
 void launch_conv_forward_pool2_idx(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, uint8_t* Idx,
                                    const ConvGeom& g, int COUTp, int Kp, int64_t npos, int act) {
+  if (conv_first_applies(g, COUTp)) {
+    launch_conv_first<true>(st, Wp, bp, In, Out, Idx, g, COUTp, Kp, npos, act);
+    return;
+  }
   launch_conv_pool_any<true>(st, Wp, bp, In, Out, g, COUTp, Kp, npos, act, Idx);
 }
 
