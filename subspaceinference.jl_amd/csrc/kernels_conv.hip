@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_pool_kernel(cons
 // The k steps run in the same order with the same 4-wide grouping as the GEMM pipeline and skipped steps only ever added
 // zeros, so the results are bit-identical to conv_gemm_pool_kernel's.
 template <int NS, int NTM, bool IDX>
-__global__ __launch_bounds__(256, 2) void conv_first_pool_kernel(const double* __restrict__ Wp, int Mp, const double* __restrict__ T,
+__global__ __launch_bounds__(256, 3) void conv_first_pool_kernel(const double* __restrict__ Wp, int Mp, const double* __restrict__ T,
                                                               double* __restrict__ Out, const double* __restrict__ bias, ConvGeom g,
                                                               int64_t npos, int Kp, int act, uint8_t* __restrict__ Idx) {
   constexpr int MP = NTM * 16 + 16;   // LDS row pitch
@@ -429,11 +429,17 @@ __global__ __launch_bounds__(256, 2) void conv_first_pool_kernel(const double* _
     d4 acc[NTM];
 #pragma unroll
     for (int t = 0; t < NTM; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    // the weight fragments are re-read from LDS for every slice (4 cycles of LDS time per MFMA of 64): kept in registers --
+    // where the compiler puts loop-invariant loads by itself -- they cost 8 registers per k step and channel tile and
+    // the kernel ran at two waves per SIMD instead of three
+    int woff = 0;
+    asm volatile("" : "+v"(woff));
+    const double* wf = wfrag + woff;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
       for (int t = 0; t < NTM; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fcur[s], wfrag[4 * s * MP + 16 * t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fcur[s], wf[4 * s * MP + 16 * t], acc[t], 0, 0, 0);
     }
     // D[position q + 4r][channel c]: window r of the slice, input q of the window
 #pragma unroll
@@ -469,8 +475,8 @@ __global__ __launch_bounds__(256, 2) void conv_first_pool_kernel(const double* _
 }
 
 static bool conv_first_applies(const ConvGeom& g, int COUTp) {
-  // (tap offsets are packed into a byte each, biased by 128; up to 9 k steps: the compiler keeps the loop-invariant weight
-  // fragments in registers, 8 per k step and channel tile -- at 16 k steps the kernel spilled)
+  // (tap offsets are packed into a byte each, biased by 128; up to 9 k steps = 36 taps: two slices of patch fragments live in
+  // registers, 13 k steps spilled at the three-waves-per-SIMD budget)
   return g.Kvalid <= 36 && COUTp <= 64 && g.sden_w == 1 && g.sden_h == 1 && g.Cp <= 64 && g.pad_w < 100 && g.pad_h < 100 &&
          (g.KW - 1) * g.dil_w < 100 && (g.KH - 1) * g.dil_h < 100;
 }
