@@ -52,8 +52,9 @@ __device__ __forceinline__ bool pool_approx(double x, double y) {
 //   (wi, hi) = ((wo, ho) * snum - pad + (a, c) * dil) / sden   (zero when out of range or not divisible by sden).
 // LDS image "k-fast" [pos][18] like Stager<.., LAY = 1>.  Each thread owns NREG (position, k-pair) slots; the position
 // part of the address is fixed per slot, the tap part changes per k tile -- block-uniform when Cp % 16 == 0 (CELLU).
-// POOLP: the position index runs window-major over 2 x 2 / stride-2 pooling windows -- pos = 4 * (pooled pixel) + (dx + 2 dy)
-// -- so that the four inputs of a window sit in four lanes of one accumulator register (conv_gemm_pool_kernel).
+// POOLP: the position index runs over 2 x 2 / stride-2 pooling windows, four windows per aligned slice of 16 positions,
+// input-major inside the slice -- pos = 16 * slice + (window & 3) + 4 * (dx + 2 dy) -- so that the four inputs of a window
+// are the four accumulator registers of ONE lane: the pooling epilogue needs no cross-lane traffic (conv_gemm_pool_kernel).
 template <int R, int NT, bool CELLU, bool DEN, bool POOLP = false>
 struct GatherK {
   static constexpr int LAY = 1;
@@ -86,8 +87,10 @@ struct GatherK {
       if (pos > npos - 1) pos = npos - 1;  // clamped positions only feed outputs that are never stored
       int img, ho, wo;
       if constexpr (POOLP) {
-        const int64_t win = pos >> 2;
-        const int e = (int)(pos & 3), W2 = g.Wo >> 1, wh2 = W2 * (g.Ho >> 1);
+        // inside every aligned slice of 16 positions: position j = (window j & 3) + 4 * (input j >> 2) -- the four inputs of a
+        // window then are the four accumulator REGISTERS of one lane (D[n = q + 4r][m = c]: window q, input r)
+        const int64_t win = ((pos & ~(int64_t)15) >> 2) + (pos & 3);
+        const int e = (int)((pos >> 2) & 3), W2 = g.Wo >> 1, wh2 = W2 * (g.Ho >> 1);
         img = (int)(win / wh2);
         const int sp = (int)(win - (int64_t)img * wh2);
         const int ho2 = sp / W2, wo2 = sp - ho2 * W2;
@@ -281,9 +284,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_kernel(const dou
 }
 
 // Forward convolution + bias + activation + MaxPool((2, 2)) in one kernel (sampling path: the un-pooled activation is
-// never needed).  Positions run window-major (GatherK<POOLP>), so in the MFMA output D[n = q + 4r][m = c] the four inputs
-// of pooling window r of a 16-position slice are the four lane groups q = 0..3 of accumulator register r: two cross-lane
-// maxima, then lane group q stores window q -- Out[m + Mp * window] is the pooled CWHN tensor (4x fewer bytes written,
+// never needed).  Positions run input-major inside every slice of 16 (GatherK<POOLP>), so in the MFMA output
+// D[n = q + 4r][m = c] the four inputs of pooling window q of the slice are the four accumulator registers r of one lane:
+// three fmax, no cross-lane traffic (round 2 had them in four lane groups: two ds_bpermute pairs per value), and lane group
+// q stores window q -- Out[m + Mp * window] is the pooled CWHN tensor (4x fewer bytes written,
 // and the MaxPool pass with its read of the full activation disappears: 2.1 + 2.7 GB at the first layer of the cfg4 CNN).
 // IDX (gradient mode): additionally stores, per pooled element, WHICH of the four window inputs the reverse sweep routes
 // the gradient to -- the first one (dx + 2 dy order = NNlib's kw-fastest scan) that is ≈ the maximum -- as one byte.
@@ -335,26 +339,20 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_pool_kernel(cons
     const double bv = gm < Mp ? bias[gm] : 0.0;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      double v[4];
-      int ix[4];
+      // D[n = q + 4r][m = c]: window q of the slice, its input r (dx + 2 dy: NNlib's kw-fastest scan order)
+      double vin[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double own = conv_act(acc[a][b][r] + bv, act);   // input q of window r
-        double t = fmax(own, __shfl_xor(own, 16));
-        t = fmax(t, __shfl_xor(t, 32));
-        v[r] = t;
-        if constexpr (IDX) {
-          int cand = pool_approx(t, own) ? q : 4;
-          cand = min(cand, __shfl_xor(cand, 16));
-          cand = min(cand, __shfl_xor(cand, 32));
-          ix[r] = cand;
-        }
+      for (int r = 0; r < 4; ++r) vin[r] = conv_act(acc[a][b][r] + bv, act);
+      const double o = fmax(fmax(vin[0], vin[1]), fmax(vin[2], vin[3]));
+      int oi = 4;
+      if constexpr (IDX) {
+#pragma unroll
+        for (int r = 3; r >= 0; --r) oi = pool_approx(o, vin[r]) ? r : oi;   // the FIRST input that is ≈ the maximum
       }
-      const double o = q == 0 ? v[0] : q == 1 ? v[1] : q == 2 ? v[2] : v[3];
       const int64_t win = ((n0 + wn * (BN / WN) + b * 16) >> 2) + q;
       if (gm < Mp && win < nwin) {
         Out[gm + (int64_t)Mp * win] = o;
-        if constexpr (IDX) Idx[gm + (int64_t)Mp * win] = (uint8_t)(q == 0 ? ix[0] : q == 1 ? ix[1] : q == 2 ? ix[2] : ix[3]);
+        if constexpr (IDX) Idx[gm + (int64_t)Mp * win] = (uint8_t)oi;
       }
     }
   }
@@ -368,8 +366,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_pool_kernel(cons
 //   * the patch operand needs NO staging at all: k' = cin + Cp*tap, so MFMA k step s, lane (q, c) wants input channel /
 //     tap (4s + q) of position c -- ONE 8-byte global load per lane and k step, coalesced over the 4 channels of a pixel
 //     and the neighbouring pixels, the next slice's fragments in flight under this slice's MFMAs;
-//   * no barrier after the weights are in; waves walk the position slices grid-stride (window-major order, so the pooling
-//     epilogue is the one of conv_gemm_pool_kernel: two cross-lane maxima per accumulator register).
+//   * no barrier after the weights are in; waves walk the position slices grid-stride (input-major inside a slice, so the
+//     pooling epilogue is lane-local like conv_gemm_pool_kernel's).
 // The k steps run in the same order with the same 4-wide grouping as the GEMM pipeline and skipped steps only ever added
 // zeros, so the results are bit-identical to conv_gemm_pool_kernel's.
 template <int NS, int NTM, bool IDX>
@@ -400,11 +398,12 @@ __global__ __launch_bounds__(256, 3) void conv_first_pool_kernel(const double* _
   const int64_t nslice = (npos + 15) >> 4, nwin = npos >> 2;
   const int64_t sstride = (int64_t)gridDim.x * 4;
   auto gather = [&](int64_t sl, double(&f)[NS]) {
-    int64_t pos = 16 * sl + c;
-    if (pos > npos - 1) pos = npos - 1;   // (npos is a multiple of 4; clamped positions feed windows that are never stored)
-    const int64_t win = pos >> 2;
-    const int e = (int)(pos & 3);
-    const int img = (int)(win / wh2), sp = (int)(win - (int64_t)img * wh2);
+    // lane c of the patch operand = position c of the slice = window (c & 3), input (c >> 2) of it (see GatherK<POOLP>);
+    // 32-bit index arithmetic: the caller guarantees fewer than 2^31 positions
+    int win = 4 * (int)sl + (c & 3);
+    if (win > (int)nwin - 1) win = (int)nwin - 1;   // clamped windows are never stored
+    const int e = c >> 2;
+    const int img = win / wh2, sp = win - img * wh2;
     const int ho2 = sp / W2, wo2 = sp - ho2 * W2;
     const int wb = (2 * wo2 + (e & 1)) * g.snum_w, hb = (2 * ho2 + (e >> 1)) * g.snum_h;
     const double* base = T + (int64_t)img * g.img_stride;
@@ -441,30 +440,23 @@ __global__ __launch_bounds__(256, 3) void conv_first_pool_kernel(const double* _
       for (int t = 0; t < NTM; ++t)
         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fcur[s], wf[4 * s * MP + 16 * t], acc[t], 0, 0, 0);
     }
-    // D[position q + 4r][channel c]: window r of the slice, input q of the window
+    // D[position q + 4r][channel c]: window q of the slice, input r of the window -- the maximum is lane-local
 #pragma unroll
     for (int t = 0; t < NTM; ++t) {
       const int gm = 16 * t + c;
-      double v[4];
-      int ix[4];
+      double vin[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double own = conv_act(acc[t][r] + bv[t], act);
-        double mx = fmax(own, __shfl_xor(own, 16));
-        mx = fmax(mx, __shfl_xor(mx, 32));
-        v[r] = mx;
-        if constexpr (IDX) {
-          int cand = pool_approx(mx, own) ? q : 4;
-          cand = min(cand, __shfl_xor(cand, 16));
-          cand = min(cand, __shfl_xor(cand, 32));
-          ix[r] = cand;
-        }
+      for (int r = 0; r < 4; ++r) vin[r] = conv_act(acc[t][r] + bv[t], act);
+      const double o = fmax(fmax(vin[0], vin[1]), fmax(vin[2], vin[3]));
+      int oi = 4;
+      if constexpr (IDX) {
+#pragma unroll
+        for (int r = 3; r >= 0; --r) oi = pool_approx(o, vin[r]) ? r : oi;
       }
-      const double o = q == 0 ? v[0] : q == 1 ? v[1] : q == 2 ? v[2] : v[3];
       const int64_t win = 4 * sl + q;
       if (gm < Mp && win < nwin) {
         Out[gm + (int64_t)Mp * win] = o;
-        if constexpr (IDX) Idx[gm + (int64_t)Mp * win] = (uint8_t)(q == 0 ? ix[0] : q == 1 ? ix[1] : q == 2 ? ix[2] : ix[3]);
+        if constexpr (IDX) Idx[gm + (int64_t)Mp * win] = (uint8_t)oi;
       }
     }
     if (more) {
