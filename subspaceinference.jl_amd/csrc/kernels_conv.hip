@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256, 3) void conv_first_pool_kernel(const double* _
     for (int t = 0; t < NTM; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
     // the weight fragments are re-read from LDS for every slice (4 cycles of LDS time per MFMA of 64): kept in registers --
     // where the compiler puts loop-invariant loads by itself -- they cost 8 registers per k step and channel tile and
-    // the kernel ran at two waves per SIMD instead of three
+    // the kernel ran at two waves per SIMD instead of three (measured: 6.52 against 6.46 ms of conv time per transition)
     int woff = 0;
     asm volatile("" : "+v"(woff));
     const double* wf = wfrag + woff;
@@ -781,24 +781,36 @@ void launch_conv_pack_t(hipStream_t st, const double* w, double* Wt, int KW, int
 // gw[(KW-1-a) + KW*((KH-1-c) + KH*(cin + CIN*co))] = sum_split part[split][co + COUTp*k'],  fixed order
 __global__ __launch_bounds__(256) void conv_unpack_dw_kernel(const double* __restrict__ part, int nsplit, double* __restrict__ gw,
                                                              int KW, int KH, int CIN, int COUT, int CINp, int COUTp, int Kp) {
-  // walks the SOURCE order (co fastest: coalesced reads of the nsplit partial planes, which are 14-28x the bytes of the
-  // result) and scatters the 8-byte results; in destination order every read touched its own cache line (0.6 TB/s)
+  // walks the SOURCE order (co fastest: coalesced reads of the nsplit partial planes, which are 14-768x the bytes of the
+  // result) and scatters the 8-byte results; in destination order every read touched its own cache line (0.6 TB/s).
+  // Block = 32 source elements x 8 split phases: phase j adds splits j, j + 8, ... in order, the eight phase sums are added
+  // in a fixed tree (a first layer has 3072 elements and 768 splits: one thread per element was 768 dependent loads).
+  __shared__ double red[8][33];
   const int64_t plane = (int64_t)COUTp * Kp;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t src = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; src < plane; src += stride) {
-    const int co = (int)(src % COUTp), kp = (int)(src / COUTp);
-    const int cell = kp / CINp, cin = kp - cell * CINp;
-    const int c = cell / KW, a = cell - c * KW;
-    if (co >= COUT || cin >= CIN || c >= KH) continue;   // pad channel / pad taps
+  const int il = threadIdx.x & 31, cl = threadIdx.x >> 5;
+  for (int64_t s0 = (int64_t)blockIdx.x * 32; s0 < plane; s0 += (int64_t)gridDim.x * 32) {
+    const int64_t src = s0 + il;
     double s = 0.0;
-    for (int sp = 0; sp < nsplit; ++sp) s += part[(int64_t)sp * plane + src];
-    gw[(KW - 1 - a) + KW * ((KH - 1 - c) + KH * (cin + (int64_t)CIN * co))] = s;
+    if (src < plane)
+      for (int sp = cl; sp < nsplit; sp += 8) s += part[(int64_t)sp * plane + src];
+    red[cl][il] = s;
+    __syncthreads();
+    if (cl == 0 && src < plane) {
+      const double t = ((red[0][il] + red[1][il]) + (red[2][il] + red[3][il])) + ((red[4][il] + red[5][il]) + (red[6][il] + red[7][il]));
+      const int co = (int)(src % COUTp), kp = (int)(src / COUTp);
+      const int cell = kp / CINp, cin = kp - cell * CINp;
+      const int c = cell / KW, a = cell - c * KW;
+      if (co < COUT && cin < CIN && c < KH)   // (else: pad channel / pad taps)
+        gw[(KW - 1 - a) + KW * ((KH - 1 - c) + KH * (cin + (int64_t)CIN * co))] = t;
+    }
+    __syncthreads();
   }
 }
 void launch_conv_unpack_dw(hipStream_t st, const double* part, int nsplit, double* gw, int KW, int KH, int CIN, int COUT,
                            int CINp, int COUTp, int Kp) {
-  hipLaunchKernelGGL(conv_unpack_dw_kernel, dim3(idx_grid((int64_t)COUTp * Kp)), dim3(256), 0, st, part, nsplit, gw,
-                     KW, KH, CIN, COUT, CINp, COUTp, Kp);
+  const int64_t blocks = std::min<int64_t>(8192, ((int64_t)COUTp * Kp + 31) / 32);
+  hipLaunchKernelGGL(conv_unpack_dw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, nsplit, gw, KW, KH, CIN, COUT, CINp,
+                     COUTp, Kp);
 }
 
 // (W, H, C, N) column-major  ->  channel-fastest with pitch Cp (pad channels zero)
