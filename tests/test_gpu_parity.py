@@ -430,6 +430,38 @@ def test_density_full_size_cfg2(gpu_ctx):
     assert np.isclose(gpu_ctx.logdensity(z[:, :1])[0], lp[0], rtol=1e-12)
 
 
+@pytest.mark.parametrize("dims,acts,b", [
+    ([12, 192, 200, 2], [1, 2, 0], 33001),    # stored layer (nMt = 2) + fused tail; 516 tiles = one round + 4 tiles
+    ([16, 960, 960, 1], [1, 1, 0], 7000),     # cfg2's widths: 550 tiles, 14 half-width panels, the last one ragged
+    ([12, 192, 40, 8], [3, 1, 0], 33001),     # stored layers only (unfused wide head)
+])
+def test_narrow_last_round_of_the_dense_kernel(gpu_ctx, dims, acts, b):
+    """kernels_gemm.hip: a last round of workgroups that fills less than half the chip runs as half-width tiles.  The
+    k order of every output element is unchanged, so the columns computed by narrow tiles carry the SAME BITS as when
+    they are computed by full-width tiles (a second set-up on just those columns), and all agree with the oracle."""
+    m = 3
+    table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=b + dims[1])
+    z = np.asfortranarray(0.3 * np.random.default_rng(5).standard_normal((m, 1)))
+    gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=0.9)
+    yh = gpu_ctx.forward(z[:, 0])
+    lp = gpu_ctx.logdensity(z)[0]
+    yref = so.forward(table, so.reconstruct(w_swa, p, z[:, 0]), x)
+    assert np.allclose(yh, yref, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(yref).max()))
+    assert np.isclose(lp, so.logdensity(table, w_swa, p, x, y, 0.9, z[:, 0]), rtol=1e-11)
+    cut = b - 700                      # inside the main part for every case: the tail below spans main AND narrow columns
+    gpu_ctx.infer_setup(table, n, m, w_swa, p, np.asfortranarray(x[:, cut:]), np.asfortranarray(y[:, cut:]), 0.9)
+    assert np.array_equal(gpu_ctx.forward(z[:, 0]), yh[:, cut:])
+    gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=0.9)
+    lp_g, g = gpu_ctx.logdensity_grad(z[:, 0])      # the gradient-mode forward (keeps every layer) takes the same launch
+    assert np.isclose(lp_g, lp, rtol=1e-12)
+    eps = 1e-6
+    zp, zm = z.copy(), z.copy()
+    zp[0, 0] += eps
+    zm[0, 0] -= eps
+    fd = (gpu_ctx.logdensity(zp)[0] - gpu_ctx.logdensity(zm)[0]) / (2 * eps)
+    assert np.isclose(g[0], fd, rtol=1e-5, atol=1e-6 * abs(lp))
+
+
 # ----------------------------------------------------------------------------------------------- gradient samplers
 @pytest.mark.parametrize("alg", ["mala", "hmc", "nuts"])
 def test_gradient_samplers_match_oracle_driven_run(si, gpu_ctx, alg):
