@@ -61,9 +61,16 @@ def comm_init(ctx, rank=None, world=None, id_file=None, timeout_s=120.0):
     if world is None:
         world = d.get_world_size() if d else int(os.environ.get("WORLD_SIZE", "1"))
     if d is not None and id_file is None:
-        box = [_capi.comm_unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:   # a failure on rank 0 must still reach the broadcast: the other ranks are waiting in it
+            try:
+                box = [_capi.comm_unique_id()]
+            except _capi.SubspaceError as e:
+                box = [("error", str(e))]
         d.broadcast_object_list(box, src=0)
         uid = box[0]
+        if isinstance(uid, tuple):
+            raise _capi.SubspaceError("comm_init: rank 0 could not create the RCCL id: %s" % uid[1], _capi.SI_ERR_COMM)
     elif id_file is not None:
         if rank == 0:
             uid = _capi.comm_unique_id()

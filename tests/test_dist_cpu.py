@@ -130,6 +130,20 @@ def _worker(rank, world, port, q):
                 self.got = (world, rank, uid)
         rec = Rec()
         assert sd.comm_init(rec) == (rank, world) and rec.got[:2] == (world, rank) and len(rec.got[2]) == 128
+        # a rank 0 that cannot create the id (no RCCL to dlopen) must not leave the others waiting in the broadcast:
+        # every rank gets the error
+        real_id = si._capi.comm_unique_id
+        if rank == 0:
+            def broken():
+                raise si.SubspaceError("librccl.so.1 not found (test)", si._capi.SI_ERR_COMM)
+            sd._capi.comm_unique_id = broken
+        try:
+            sd.comm_init(Rec())
+            raise AssertionError("comm_init must fail on every rank")
+        except si.SubspaceError as e:
+            assert "rank 0 could not create the RCCL id" in str(e) and e.code == si._capi.SI_ERR_COMM
+        finally:
+            sd._capi.comm_unique_id = real_id
         import torch.distributed as td
         ids = [None] * world
         td.all_gather_object(ids, rec.got[2])
