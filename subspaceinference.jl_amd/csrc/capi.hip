@@ -174,6 +174,39 @@ void construct_install(Ctx* c, int64_t N, int32_t M, double* w_swa, double* P) {
   c->c_finished = true;
 }
 
+// The reverse sweep of a Dense chain, shared by si_logdensity_grad and the training step (capi_train.hip).
+// Measured and not kept (round 3, tools/bwd_side_ab.py): the weight-gradient GEMM of a layer on a side stream beside the
+// data-gradient GEMM of the critical path (nothing in the sweep reads dW; the split-K dW launch fills 480 of 512 slots)
+// -- 3 % SLOWER at cfg2 (10.2-10.9 -> 10.5-11.1 ms per value + gradient): two GEMMs sharing the CUs lose more in the
+// caches than the idle slots and the fill / drain phases return.
+int32_t dense_reverse_sweep(Ctx* ctx, hipStream_t st, const DenseSweep& s) {
+  int cur = 0;
+  size_t top = s.nl;          // layers [0, top) go through the generic sweep
+  bool have_db = false;       // db of layer top-1 already produced by the fused tail
+  if (s.fuse_tail) {
+    // narrow head: Delta_{L-1}, dW_L and db_{L-1} in one pass over H_{L-1}
+    const si_layer& ll = s.layers[s.nl - 1];
+    const si_layer& lp = s.layers[s.nl - 2];
+    launch_rowsum(st, s.delta[cur], ll.out, s.B, s.rspart, s.gw + ll.b_off);
+    launch_tail_bwd(st, s.w + ll.w_off, s.delta[cur], s.hs[s.nl - 2], ll.out, ll.in, s.B, lp.act, s.delta[cur ^ 1], s.bwpart,
+                    s.gw + ll.w_off, s.gw + lp.b_off);
+    cur ^= 1;
+    top = s.nl - 1;
+    have_db = true;
+  }
+  for (size_t li = top; li-- > 0;) {
+    const si_layer& ly = s.layers[li];
+    const double* hprev = li > 0 ? s.hs[li - 1] : s.X;
+    if (!(have_db && li + 1 == top)) launch_rowsum(st, s.delta[cur], ly.out, s.B, s.rspart, s.gw + ly.b_off);
+    launch_backward_weight(st, s.delta[cur], hprev, s.bwpart, ly.out, ly.in, s.B, ctx->num_cu, s.gw + ly.w_off);
+    if (li > 0) {
+      launch_backward_data(st, s.w + ly.w_off, s.delta[cur], hprev, s.delta[cur ^ 1], ly.out, ly.in, s.B, s.layers[li - 1].act);
+      cur ^= 1;
+    }
+  }
+  return SI_OK;
+}
+
 }  // namespace si
 
 using namespace si;
@@ -1258,9 +1291,7 @@ static int32_t ensure_grad(si_ctx* ctx) {
   for (size_t l = 0; l < ctx->layers.size() && ok; ++l) {
     const si_layer& ly = ctx->layers[l];
     maxw = std::max<int64_t>(maxw, ly.out);
-    int64_t ks;
-    const int ns = backward_weight_splits(ly.out, ly.in, B, ctx->num_cu, &ks);
-    maxpart = std::max(maxpart, (size_t)ns * ly.out * ly.in);
+    maxpart = std::max(maxpart, backward_weight_part_elems(ly.out, ly.in, B, ctx->num_cu));
     ok = dev_alloc(&ctx->d_hs[l], (size_t)ly.out * B) == hipSuccess;
   }
   if (ctx->fuse_tail) maxpart = std::max(maxpart, tail_bwd_part_elems(ctx->layers.back().out, ctx->layers.back().in));
@@ -1368,36 +1399,12 @@ int32_t si_logdensity_grad(si_ctx* ctx, const double* z, double* lp_out, double*
     for (const auto& ly : ctx->layers) bflops += 4.0 * (double)ly.in * ly.out * (double)B;
     ProfScope ps(ctx, SI_K_BACKWARD, bflops, 0.0);
     SI_HIP(ctx, hipMemsetAsync(ctx->d_gw, 0, (size_t)pad_ld(N) * sizeof(double), ctx->stream));
-    int cur = 0;
     // d lp / d yhat = (y - yhat) / sigma^2
-    launch_delta_out(ctx->stream, ctx->d_Y, h, d, 1.0 / s2, ctx->layers[nl - 1].act, ctx->d_delta[cur]);
-    size_t top = nl;          // layers [0, top) still go through the generic sweep
-    bool have_db = false;     // db of layer top-1 already produced by the fused tail
-    if (ctx->fuse_tail) {
-      // narrow head: Delta_{L-1}, dW_L and db_{L-1} in one pass over H_{L-1}
-      const si_layer& ll = ctx->layers[nl - 1];
-      const si_layer& lp = ctx->layers[nl - 2];
-      launch_rowsum(ctx->stream, ctx->d_delta[cur], ll.out, B, ctx->d_rspart, ctx->d_gw + ll.b_off);
-      launch_tail_bwd(ctx->stream, ctx->d_w + ll.w_off, ctx->d_delta[cur], ctx->d_hs[nl - 2], ll.out, ll.in, B, lp.act,
-                      ctx->d_delta[cur ^ 1], ctx->d_bwpart, ctx->d_gw + ll.w_off, ctx->d_gw + lp.b_off);
-      cur ^= 1;
-      top = nl - 1;
-      have_db = true;
-    }
-    for (size_t li = top; li-- > 0;) {
-      const si_layer& ly = ctx->layers[li];
-      const double* hprev = li > 0 ? ctx->d_hs[li - 1] : ctx->d_X;
-      if (!(have_db && li + 1 == top)) launch_rowsum(ctx->stream, ctx->d_delta[cur], ly.out, B, ctx->d_rspart, ctx->d_gw + ly.b_off);
-      int64_t ks;
-      const int ns = backward_weight_splits(ly.out, ly.in, B, ctx->num_cu, &ks);
-      launch_backward_weight(ctx->stream, ctx->d_delta[cur], hprev, ctx->d_bwpart, ly.out, ly.in, B, ns, ks, ctx->num_cu);
-      launch_split_reduce(ctx->stream, ctx->d_bwpart, ns, (int64_t)ly.out * ly.in, ctx->d_gw + ly.w_off);
-      if (li > 0) {
-        launch_backward_data(ctx->stream, ctx->d_w + ly.w_off, ctx->d_delta[cur], hprev, ctx->d_delta[cur ^ 1], ly.out,
-                             ly.in, B, ctx->layers[li - 1].act);
-        cur ^= 1;
-      }
-    }
+    launch_delta_out(ctx->stream, ctx->d_Y, h, d, 1.0 / s2, ctx->layers[nl - 1].act, ctx->d_delta[0]);
+    DenseSweep sw{ctx->layers.data(), nl, ctx->fuse_tail, ctx->d_w, ctx->d_X, ctx->d_hs.data(), {ctx->d_delta[0], ctx->d_delta[1]},
+                  ctx->d_gw, ctx->d_rspart, ctx->d_bwpart, B};
+    const int32_t rcs = dense_reverse_sweep(ctx, ctx->stream, sw);
+    if (rcs != SI_OK) return rcs;
     if (prior) launch_prior_grad(ctx->stream, ctx->d_gw, ctx->d_w, N, 1.0 / (ctx->sigma_p * ctx->sigma_p), ctx->num_cu);
     launch_ptg(ctx->stream, ctx->i_P, ctx->ldP, N, M, ctx->d_gw, ctx->d_ptgpart, ctx->d_gz);
   }

@@ -221,8 +221,7 @@ void net_scratch_sizes(const NetPlan& p, int64_t B, int num_cu, size_t* bwpart, 
   for (const LayerPlan& q : p.L) {
     int64_t ks;
     if (q.kind == SI_LAYER_DENSE) {
-      const int ns = backward_weight_splits(q.out_feat, q.in_feat, B, num_cu, &ks);
-      part = std::max(part, (size_t)ns * q.out_feat * q.in_feat);
+      part = std::max(part, backward_weight_part_elems(q.out_feat, q.in_feat, B, num_cu));
     } else if (q.kind == SI_LAYER_CONV) {
       const int ns = conv_dw_splits(q.Cop, q.Kp, (int64_t)q.Wo * q.Ho * B, num_cu, &ks);
       part = std::max(part, (size_t)ns * q.Cop * q.Kp);
@@ -248,10 +247,7 @@ int32_t net_backward(Ctx* c, const NetPlan& p, const double* w, const double* xi
       case SI_LAYER_DENSE: {
         // Delta = g .* act'(h) (in place) and db = its row sums, one pass
         launch_mul_dact_rowsum(st, g, hout, q.out_feat, B, q.act, g, s.rspart, q.out_feat, gw + q.b_off);
-        int64_t ks;
-        const int ns = backward_weight_splits(q.out_feat, q.in_feat, B, c->num_cu, &ks);
-        launch_backward_weight(st, g, hin, s.bwpart, q.out_feat, q.in_feat, B, ns, ks, c->num_cu);
-        launch_split_reduce(st, s.bwpart, ns, (int64_t)q.out_feat * q.in_feat, gw + q.w_off);   // dW
+        launch_backward_weight(st, g, hin, s.bwpart, q.out_feat, q.in_feat, B, c->num_cu, gw + q.w_off);   // dW
         if (li > 0) launch_backward_data(st, w + q.w_off, g, hin, gn, q.out_feat, q.in_feat, B, SI_ACT_IDENTITY);  // W' Delta
         break;
       }

@@ -109,9 +109,7 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
     for (int l = 0; l < L; ++l) {
       const si_layer& ly = layers[l];
       maxw = std::max<int64_t>(maxw, ly.out);
-      int64_t ks;
-      const int ns = backward_weight_splits(ly.out, ly.in, batch_max, ctx->num_cu, &ks);
-      maxpart = std::max(maxpart, (size_t)ns * ly.out * ly.in);
+      maxpart = std::max(maxpart, backward_weight_part_elems(ly.out, ly.in, batch_max, ctx->num_cu));
     }
   }
   const bool fuse_tail = !plan.has_conv && (L >= 2) && layers[L - 1].out <= SI_FUSE_MAX_OUT &&
@@ -238,35 +236,12 @@ static int32_t train_gradient(si_ctx* ctx, const char* who, const int64_t* idx, 
     for (const auto& ly : t->layers) bflops += 4.0 * (double)ly.in * ly.out * (double)nb;
     ProfScope ps(ctx, SI_K_BACKWARD, bflops, 0.0);
     SI_HIP(ctx, hipMemsetAsync(t->gw, 0, (size_t)pad_ld(N) * sizeof(double), st));
-    int cur = 0;
     // d mse / d yhat = 2 (yhat - y) / d
-    launch_delta_out(st, t->Yb, h, d, -2.0 / d_total, t->layers[nl - 1].act, t->delta[cur]);
-    size_t top = nl;
-    bool have_db = false;
-    if (t->fuse_tail) {  // narrow head: Delta_{L-1}, dW_L and db_{L-1} in one pass over H_{L-1}
-      const si_layer& ll = t->layers[nl - 1];
-      const si_layer& lp = t->layers[nl - 2];
-      launch_rowsum(st, t->delta[cur], ll.out, nb, t->rspart, t->gw + ll.b_off);
-      launch_tail_bwd(st, t->w64 + ll.w_off, t->delta[cur], t->hs[nl - 2], ll.out, ll.in, nb, lp.act, t->delta[cur ^ 1],
-                      t->bwpart, t->gw + ll.w_off, t->gw + lp.b_off);
-      cur ^= 1;
-      top = nl - 1;
-      have_db = true;
-    }
-    for (size_t li = top; li-- > 0;) {
-      const si_layer& ly = t->layers[li];
-      const double* hprev = li > 0 ? t->hs[li - 1] : t->Xb;
-      if (!(have_db && li + 1 == top)) launch_rowsum(st, t->delta[cur], ly.out, nb, t->rspart, t->gw + ly.b_off);
-      int64_t ks;
-      const int ns = backward_weight_splits(ly.out, ly.in, nb, ctx->num_cu, &ks);
-      launch_backward_weight(st, t->delta[cur], hprev, t->bwpart, ly.out, ly.in, nb, ns, ks, ctx->num_cu);
-      launch_split_reduce(st, t->bwpart, ns, (int64_t)ly.out * ly.in, t->gw + ly.w_off);
-      if (li > 0) {
-        launch_backward_data(st, t->w64 + ly.w_off, t->delta[cur], hprev, t->delta[cur ^ 1], ly.out, ly.in, nb,
-                             t->layers[li - 1].act);
-        cur ^= 1;
-      }
-    }
+    launch_delta_out(st, t->Yb, h, d, -2.0 / d_total, t->layers[nl - 1].act, t->delta[0]);
+    DenseSweep sw{t->layers.data(), nl, t->fuse_tail, t->w64, t->Xb, t->hs.data(), {t->delta[0], t->delta[1]}, t->gw, t->rspart,
+                  t->bwpart, nb};
+    const int32_t rcs = dense_reverse_sweep(ctx, st, sw);
+    if (rcs != SI_OK) return rcs;
   }
   SI_HIP(ctx, hipGetLastError());
   t->grad_ready = true;

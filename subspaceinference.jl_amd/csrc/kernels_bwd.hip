@@ -164,9 +164,15 @@ void launch_backward_data(hipStream_t st, const double* W, const double* Delta, 
   }
 }
 
-// Plan of the split-K weight gradient  dW[out x in] = Delta * Hprev'  (K = B): the row tile and the split count that
-// waste least -- padding of `out` to the tile, and unfilled slots of the ONE round of 2 x CU workgroups (two 8-wave
-// workgroups per CU) the launch is sized for.  cfg2 layer 2: 96-row tiles, 80 tiles x 6 splits = 480 of 512 slots.
+// ---- weight gradient  dW[out x in] = Delta * Hprev'  (K = B: a handful of output tiles, a very long contraction)
+// Plan of the split-K launch: the row tile and the split count that waste least -- padding of `out` to the tile, and
+// unfilled slots of the ONE round of 2 x CU workgroups (two 8-wave workgroups per CU) the launch is sized for.
+// cfg2 layer 2: 96-row tiles, 80 tiles x 6 splits = 480 of 512 slots.
+// Measured and not kept (round 3, tools/bwd_bench.hip, profiles/r03_dw_streamk.log): a "stream-K" cut -- the k tiles of
+// all output tiles as one sequence dealt out in 512 equal contiguous ranges, a workgroup finishing one tile and going
+// on in the next -- fills every slot but is SLOWER (3.46 against 3.32 ms): neighbouring workgroups then walk different
+// k ranges of the SAME tile and share no operand data, where the 80 tiles of one split walk the same k range of Delta
+// and H together and find it in the L2 / Infinity Cache.
 struct DwPlan {
   int bm;
   int nsplit;
@@ -202,20 +208,22 @@ static DwPlan plan_dw(int32_t out, int32_t in, int64_t B, int num_cu) {
   return best;
 }
 
-int backward_weight_splits(int32_t out, int32_t in, int64_t B, int num_cu, int64_t* ksplit_out) {
-  const DwPlan p = plan_dw(out, in, B, num_cu);
-  *ksplit_out = p.ks;
-  return p.nsplit;
+// doubles of scratch launch_backward_weight needs for this layer
+size_t backward_weight_part_elems(int32_t out, int32_t in, int64_t B, int num_cu) {
+  return (size_t)plan_dw(out, in, B, num_cu).nsplit * out * in;
 }
 
+// dW[out x in] = Delta * Hprev' into dW: split-K GEMM into `part`, then the splits added in fixed order
 void launch_backward_weight(hipStream_t st, const double* Delta, const double* Hprev, double* part, int32_t out,
-                            int32_t in, int64_t B, int nsplit, int64_t ksplit, int num_cu) {
+                            int32_t in, int64_t B, int num_cu, double* dW) {
+  const DwPlan p = plan_dw(out, in, B, num_cu);
   // A(m = out idx, k = b) = Delta[m + out*k]: row-fast;  B(k = b, n = in idx) = Hprev[n + in*k]: row-fast
-  switch (plan_dw(out, in, B, num_cu).bm) {
-    case 96: launch_gemm<96, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0); break;
-    case 128: launch_gemm<128, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0); break;
-    default: launch_gemm<64, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, nsplit, ksplit, nullptr, 0); break;
+  switch (p.bm) {
+    case 96: launch_gemm<96, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, p.nsplit, p.ks, nullptr, 0); break;
+    case 128: launch_gemm<128, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, p.nsplit, p.ks, nullptr, 0); break;
+    default: launch_gemm<64, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, p.nsplit, p.ks, nullptr, 0); break;
   }
+  launch_split_reduce(st, part, p.nsplit, (int64_t)out * in, dW);
 }
 
 // K3 for wide subspaces (M > 32), on the matrix cores:  P[N x M] = A[N x K] * V[K x M]  with  A(m = row, k) = A[m + ldA*k]

@@ -314,9 +314,27 @@ void launch_sse(hipStream_t st, const double* yhat, const double* y, int64_t d, 
 // backward pass (kernels_bwd.hip): gradient of the log-density w.r.t. the flat weights and its pull-back P' g
 void launch_backward_data(hipStream_t st, const double* W, const double* Delta, const double* Hprev, double* DeltaPrev,
                           int32_t out, int32_t in, int64_t B, int32_t act_prev);
-int backward_weight_splits(int32_t out, int32_t in, int64_t B, int num_cu, int64_t* ksplit_out);
+// Reverse sweep through a Dense chain shared by si_logdensity_grad (capi.hip) and the training step (capi_train.hip).
+// On entry delta[0] holds Delta_L (launch_delta_out) and gw is zeroed, both on `st`; on return every dW / db of the
+// chain is in gw.
+struct DenseSweep {
+  const si_layer* layers;
+  size_t nl;
+  bool fuse_tail;
+  const double* w;          // flat fp64 weights
+  const double* X;          // input of layer 0, in_0 x B
+  double* const* hs;        // kept outputs of every layer
+  double* delta[2];
+  double* gw;
+  double* rspart;
+  double* bwpart;
+  int64_t B;
+};
+int32_t dense_reverse_sweep(Ctx* ctx, hipStream_t st, const DenseSweep& s);
+// dW[out x in] = Delta * Hprev' into dW, through `part` (backward_weight_part_elems doubles): stream-K / split-K GEMM + fixed-order reduction
+size_t backward_weight_part_elems(int32_t out, int32_t in, int64_t B, int num_cu);
 void launch_backward_weight(hipStream_t st, const double* Delta, const double* Hprev, double* part, int32_t out,
-                            int32_t in, int64_t B, int nsplit, int64_t ksplit, int num_cu);
+                            int32_t in, int64_t B, int num_cu, double* dW);
 void launch_split_reduce(hipStream_t st, const double* part, int nsplit, int64_t elems, double* dst);
 void launch_delta_out(hipStream_t st, const double* Y, const double* Yhat, int64_t d, double scale, int act, double* delta);
 void launch_rowsum(hipStream_t st, const double* D, int32_t out, int64_t B, double* part, double* db);

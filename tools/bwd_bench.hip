@@ -12,6 +12,7 @@ namespace si {
 int32_t fail(Ctx*, int32_t c, const std::string&) { return c; }
 ProfScope::ProfScope(Ctx*, int, double, double) {}
 ProfScope::~ProfScope() {}
+void launch_mul_dact(hipStream_t, const double*, const double*, int64_t, int, double*) {}   // extra activations: not timed here
 }
 using namespace si;
 
@@ -51,20 +52,18 @@ int main(int argc, char** argv) {
   for (auto& v : hH) v = rnd();
   for (auto& v : hW) v = rnd() * 0.1;
   double *dD, *dH, *dW, *dPart, *dG, *dDp;
-  int64_t ks;
-  const int ns = backward_weight_splits(out, in, B, ncu, &ks);
   hipMalloc(&dD, hD.size() * 8); hipMalloc(&dH, hH.size() * 8); hipMalloc(&dW, hW.size() * 8);
-  hipMalloc(&dPart, (size_t)ns * out * in * 8); hipMalloc(&dG, (size_t)out * in * 8); hipMalloc(&dDp, (size_t)in * B * 8);
+  hipMalloc(&dPart, backward_weight_part_elems(out, in, B, ncu) * 8); hipMalloc(&dG, (size_t)out * in * 8); hipMalloc(&dDp, (size_t)in * B * 8);
   hipMemcpy(dD, hD.data(), hD.size() * 8, hipMemcpyHostToDevice);
   hipMemcpy(dH, hH.data(), hH.size() * 8, hipMemcpyHostToDevice);
   hipMemcpy(dW, hW.data(), hW.size() * 8, hipMemcpyHostToDevice);
   const double flops = 2.0 * out * in * (double)B;
-  printf("out %d in %d B %lld  CUs %d  dW: nsplit %d ksplit %lld\n", out, in, (long long)B, ncu, ns, (long long)ks);
-
-  float ms = best_ms([&] { launch_backward_weight(0, dD, dH, dPart, out, in, B, ns, ks, ncu); });
-  printf("dW   split-K gemm      %8.3f ms  %6.2f TFLOP/s\n", ms, flops / (ms * 1e-3) / 1e12);
-  float ms2 = best_ms([&] { launch_split_reduce(0, dPart, ns, (int64_t)out * in, dG); });
-  printf("dW   split reduce      %8.3f ms\n", ms2);
+  {
+    const DwPlan p = plan_dw(out, in, B, ncu);
+    printf("out %d in %d B %lld  CUs %d  dW: %d-row tiles, nsplit %d ksplit %lld\n", out, in, (long long)B, ncu, p.bm, p.nsplit, (long long)p.ks);
+  }
+  float ms = best_ms([&] { launch_backward_weight(0, dD, dH, dPart, out, in, B, ncu, dG); });
+  printf("dW   gemm + reduce     %8.3f ms  %6.2f TFLOP/s\n", ms, flops / (ms * 1e-3) / 1e12);
   // check dW against a host dot product on a few entries
   {
     std::vector<double> g((size_t)out * in);
