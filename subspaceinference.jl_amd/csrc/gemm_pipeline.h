@@ -119,7 +119,9 @@ struct Stager {
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
       int o = go(r);
-      if (kk(r) > kmax) o -= (int)(LAY == 0 ? ld : 1) * (int)(kk(r) - (kmax > 0 ? kmax : 0));
+      // (LAY 0: a slot past the tile (k >= 16) is not live: it points at k = 0 of the tile already and is never stored --
+      // moved like a live one it would read up to 21 k values BEFORE a first tile, i.e. outside the operand)
+      if ((LAY == 1 || live(r)) && kk(r) > kmax) o -= (int)(LAY == 0 ? ld : 1) * (int)(kk(r) - (kmax > 0 ? kmax : 0));
       if constexpr (VEC) {
         const double2 v = *reinterpret_cast<const double2*>(p + o);
         reg[r][0] = v.x;

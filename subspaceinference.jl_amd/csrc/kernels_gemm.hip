@@ -118,8 +118,10 @@ __device__ __forceinline__ void dense_tile(const double* __restrict__ W, const d
     for (int r = 0; r < WREGS; ++r) {
       int o = w_go[r];
       if constexpr (KEDGE) {  // clamp the k index of a ragged last tile to a legal column
+        // (slots past the tile -- WRAG, k >= BK -- already point at k = 0 and are never stored: moving them as well
+        // would put them up to (BK + 5 - in) columns BEFORE W, outside the weight vector for a first layer)
         const int kmax = in - 1 - kt * BK;
-        if (w_k[r] > kmax) o -= out * (w_k[r] - kmax);
+        if (w_k[r] > kmax && w_k[r] < BK) o -= out * (w_k[r] - kmax);
       }
       if constexpr (VEC) {
         const double2 v = *reinterpret_cast<const double2*>(wp + o);

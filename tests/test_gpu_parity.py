@@ -182,6 +182,8 @@ def _random_problem(dims, acts, b, m, seed):
     ([6, 40, 8], [1, 0], 300, 3),                         # wide head (out > 4): unfused tail
     ([10, 5], [2], 77, 2),                                # single Dense layer
     ([3, 100, 97, 2], [1, 2, 3], 130, 4),                 # odd widths: scalar staging path, activated head
+    ([12, 192, 2], [1, 0], 90, 2),                        # FIRST layer on 96-row tiles with in < 16: the staging slots past
+                                                          # the tile once read in front of the weight vector (GPU fault)
 ])
 def test_forward_and_logdensity(gpu_ctx, dims, acts, b, m):
     table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=sum(dims) + b)
