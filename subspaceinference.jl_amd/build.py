@@ -64,7 +64,7 @@ def build(force=False, verbose=False, dev=False):
     os.makedirs(os.path.dirname(lib), exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs, jobs = [], []
-    for entry in SOURCES:
+    for entry in SOURCES + ([("guard_alloc.hip", [])] if dev else []):   # (guard-page allocator: development build only)
         src, extra = entry[0], entry[1]
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, (entry[2] if len(entry) > 2 else os.path.splitext(src)[0]) + ".o")

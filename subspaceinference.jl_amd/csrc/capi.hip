@@ -12,6 +12,15 @@
 
 #include "si_internal.h"
 
+#ifdef SI_DEV_KNOBS   // development build: the library's own buffers through the guard-page allocator (guard_alloc.hip; SI_GUARD_ALLOC=end|begin)
+namespace si {
+hipError_t guard_malloc(void** out, size_t bytes);
+hipError_t guard_free(void* p);
+}
+#define hipMalloc(p, n) si::guard_malloc((void**)(p), (n))
+#define hipFree(p) si::guard_free((void*)(p))
+#endif
+
 namespace si {
 
 static thread_local std::string g_create_err;

@@ -34,6 +34,9 @@ def si():
     """The product package; builds libsubspace_hip.so in-tree when it is missing (hipcc cross-compiles)."""
     import subspaceinference_jl_amd as pkg
     from subspaceinference_jl_amd import build
+    dev_lib = os.environ.get("SI_TEST_LIB")   # the development build under test (guard-page runs: csrc/guard_alloc.hip)
+    if dev_lib:
+        pkg._capi.LIB_PATH = os.path.abspath(dev_lib)
     if not os.path.exists(pkg._capi.LIB_PATH):
         build.build()
     pkg.load()
