@@ -10,6 +10,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import subspaceinference_jl_amd as si  # noqa: E402
 
+if os.environ.get("SI_PROBE_DEV"):   # the development build (guard-page runs: SI_GUARD_ALLOC=end|begin)
+    si._capi.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bin",
+                                     "libsubspace_hip_dev.so")
+
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 M = 20
 SPEC = [("conv", 64), ("pool",), ("conv", 128), ("pool",), ("conv", 256), ("pool",), ("conv", 256), ("pool",), ("flatten",),
