@@ -289,24 +289,43 @@ class Rank:
         the run goes on over the gloo control plane -- the headline mode exchanges nothing per step -- with the error
         reported in the line (`comm_error`) instead of a lost scaling curve."""
         self.comm_error = None
+        self.comm_hung = False
         if self.dist is not None and not self.share_gpu:
-            import torch
+            import threading
+            import torch  # noqa: F401
+            import subspaceinference_jl_amd as si
             from subspaceinference_jl_amd import dist as sd
-            err = ""
-            try:
-                sd.comm_init(ctx)
-                ctx.comm_barrier()
-            except Exception as e:   # noqa: BLE001 -- reported, not hidden
-                err = repr(e)
+            box = {"err": ""}
+
+            def bring_up():
+                try:
+                    sd.comm_init(ctx)
+                    ctx.comm_barrier()
+                except Exception as e:   # noqa: BLE001 -- reported, not hidden
+                    box["err"] = repr(e)
+            # in a thread with a deadline: a communicator that never comes up (one rank failed before it joined) must not
+            # take the run with it.  ctypes releases the GIL during the call.
+            limit = float(os.environ.get("SI_BENCH_COMM_TIMEOUT", "120"))
+            th = threading.Thread(target=bring_up, daemon=True)
+            th.start()
+            th.join(limit)
+            err = box["err"]
+            if th.is_alive():
+                err = "si_comm_init_rank did not return within %.0f s" % limit
+                self.comm_hung = True
             flags = [None] * self.world
             self.dist.all_gather_object(flags, err)
             if any(flags):
                 self.comm_error = "; ".join("rank %d: %s" % (r, f) for r, f in enumerate(flags) if f)
                 log("bench.py: in-library RCCL communicator unavailable (%s): continuing over gloo" % self.comm_error)
-                try:
-                    ctx.comm_destroy()
-                except Exception:   # noqa: BLE001
-                    pass
+                if self.comm_hung:
+                    # the stuck call still owns that ctx: leave it alone for good and carry on with a fresh one
+                    ctx = si.Context(self.local_rank)
+                else:
+                    try:
+                        ctx.comm_destroy()
+                    except Exception:   # noqa: BLE001
+                        pass
             else:
                 self.ctx = ctx
         return ctx
@@ -347,6 +366,10 @@ class Rank:
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()
+        if getattr(self, "comm_hung", False):   # a thread is still inside the RCCL bring-up: do not wait for it at exit
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
 
 
 def emit(real_stdout, out):
