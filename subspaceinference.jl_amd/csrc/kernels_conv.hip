@@ -84,12 +84,16 @@ struct GatherK {
     for (int r = 0; r < NREG; ++r) {
       const int rr = (tid >> 3) + (NT / 8) * r;
       int64_t pos = n0 + rr;
-      if (pos > npos - 1) pos = npos - 1;  // clamped positions only feed outputs that are never stored
       int img, ho, wo;
       if constexpr (POOLP) {
         // inside every aligned slice of 16 positions: position j = (window j & 3) + 4 * (input j >> 2) -- the four inputs of a
-        // window then are the four accumulator REGISTERS of one lane (D[n = q + 4r][m = c]: window q, input r)
-        const int64_t win = ((pos & ~(int64_t)15) >> 2) + (pos & 3);
+        // window then are the four accumulator REGISTERS of one lane (D[n = q + 4r][m = c]: window q, input r).
+        // The clamp is on the WINDOW: in the last slice of a tensor whose window count is not a multiple of 4 the inputs
+        // 1..3 of the valid windows sit at positions >= npos (clamping the position there handed them the first input of a
+        // window past the end -- wrong maxima in the last windows, and a read behind the input tensor).
+        int64_t win = ((pos & ~(int64_t)15) >> 2) + (pos & 3);
+        const int64_t nwin = npos >> 2;
+        if (win > nwin - 1) win = nwin - 1;  // clamped windows only feed outputs that are never stored
         const int e = (int)((pos >> 2) & 3), W2 = g.Wo >> 1, wh2 = W2 * (g.Ho >> 1);
         img = (int)(win / wh2);
         const int sp = (int)(win - (int64_t)img * wh2);
@@ -97,6 +101,7 @@ struct GatherK {
         wo = 2 * wo2 + (e & 1);
         ho = 2 * ho2 + (e >> 1);
       } else {
+        if (pos > npos - 1) pos = npos - 1;  // clamped positions only feed outputs that are never stored
         img = (int)(pos / wh);
         const int sp = (int)(pos - (int64_t)img * wh);
         ho = sp / g.Wo;

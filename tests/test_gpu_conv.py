@@ -33,6 +33,11 @@ CASES = [
     ((7, 5, 2), [("conv", (3, 3), 5, R, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("flatten",), ("dense", 2, I)], 13),
     # ... and on even sizes with a batch that leaves the last 128-position tile ragged (6 * 4 * 37 = 888 positions)
     ((6, 4, 3), [("conv", (3, 3), 18, T, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("flatten",), ("dense", 2, I)], 37),
+    # window counts that are NOT a multiple of 4 through the general fused conv + pool kernel (70 channels keep the direct
+    # first-layer kernel out): 3 * 3 * 5 = 45 and 5 * 2 * 5 = 50 windows -- the last 16-position slice holds 1 / 2 valid windows
+    # whose inputs 1..3 lie past the last position (found by tools/guard_fuzz_cnn.py: wrong maxima in those windows)
+    ((8, 8, 2), [("conv", (3, 3), 70, T), ("maxpool", (2, 2)), ("flatten",), ("dense", 3, I)], 5),
+    ((8, 8, 2), [("conv", (3, 3), 70, T, (1, 2), (2, 1)), ("maxpool", (2, 2)), ("flatten",), ("dense", 3, I)], 5),
     # the four later activations (leakyrelu 4, elu 5, softplus 6, selu 7) in conv layers, fused and un-fused pools, a Dense layer
     ((8, 8, 2), [("conv", (3, 3), 6, so.ACT_ELU, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("conv", (3, 3), 5, so.ACT_SOFTPLUS, (1, 1), (1, 1)),
                  ("conv", (2, 2), 4, so.ACT_SELU, (2, 2)), ("flatten",), ("dense", 7, so.ACT_LEAKYRELU), ("dense", 2, I)], 21),

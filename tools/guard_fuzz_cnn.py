@@ -1,0 +1,79 @@
+"""Random Conv / MaxPool / flatten / Dense chains through forward / log-density / gradient / training step, meant to run
+over the DEVELOPMENT library with the guard-page allocator (see tools/guard_fuzz.py).
+usage: SI_PROBE_DEV=1 SI_GUARD_ALLOC=end|begin python3 tools/guard_fuzz_cnn.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import subspaceinference_jl_amd as si  # noqa: E402
+from oracle import subspace_oracle as so  # noqa: E402
+
+if os.environ.get("SI_PROBE_DEV"):
+    si._capi.LIB_PATH = os.path.join(ROOT, "tools", "bin", "libsubspace_hip_dev.so")
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+osz = si._capi.conv_out_size
+
+
+def random_spec():
+    w, h, c = int(rng.integers(3, 15)), int(rng.integers(3, 15)), int(rng.choice([1, 2, 3, 4, 16]))
+    whc = (w, h, c)
+    spec = []
+    for _ in range(int(rng.integers(1, 4))):
+        for _try in range(20):
+            k = (int(rng.choice([1, 2, 3, 5])), int(rng.choice([1, 2, 3, 5])))
+            s = (int(rng.choice([1, 1, 2])), int(rng.choice([1, 1, 2])))
+            pd = (int(rng.choice([0, 1, 2])), int(rng.choice([0, 1, 2])))
+            d = (int(rng.choice([1, 1, 2])), int(rng.choice([1, 1, 2])))
+            wo, ho = osz(w, k[0], s[0], pd[0], d[0]), osz(h, k[1], s[1], pd[1], d[1])
+            if wo >= 1 and ho >= 1:
+                break
+        else:
+            break
+        cout = int(rng.choice([1, 2, 5, 16, 18, 32, 64, 70]))
+        spec.append(("conv", k, cout, int(rng.integers(0, 8)), s, pd, d))
+        w, h = wo, ho
+        if rng.random() < 0.5:
+            pk = (2, 2) if rng.random() < 0.7 else (3, 2)
+            if w >= pk[0] and h >= pk[1]:
+                spec.append(("maxpool", pk))
+                w, h = osz(w, pk[0], pk[0], 0, 1), osz(h, pk[1], pk[1], 0, 1)
+    spec.append(("flatten",))
+    for _ in range(int(rng.integers(0, 2))):
+        spec.append(("dense", int(rng.choice([3, 16, 33, 96])), int(rng.integers(0, 8))))
+    spec.append(("dense", int(rng.choice([1, 2, 3, 10])), 0))
+    return whc, spec
+
+
+ctx = si.Context(0)
+for case in range(cases):
+    whc, spec = random_spec()
+    b = int(rng.choice([1, 5, 37, 130]))
+    m = int(rng.integers(1, 6))
+    print("case %d input %s B %d M %d spec %s" % (case, whc, b, m, spec), flush=True)
+    table, n = so.conv_table(spec, whc)
+    w_swa = 0.3 * rng.standard_normal(n)
+    p = np.asfortranarray(0.1 * rng.standard_normal((n, m)))
+    x = np.asfortranarray(rng.standard_normal((whc[0] * whc[1] * whc[2], b)))
+    yref0 = so.forward(table, w_swa, x)
+    y = np.asfortranarray(rng.standard_normal(yref0.shape))
+    ctx.infer_setup(table, n, m, w_swa, p, x, y, 0.8)
+    zs = np.asfortranarray(0.3 * rng.standard_normal((m, 2)))
+    yref = so.forward(table, so.reconstruct(w_swa, p, zs[:, 0]), x)
+    assert np.allclose(ctx.forward(zs[:, 0]), yref, rtol=1e-9, atol=1e-10 * max(1.0, np.abs(yref).max()))
+    lp_ref = np.array([so.logdensity(table, w_swa, p, x, y, 0.8, zs[:, j]) for j in range(2)])
+    assert np.allclose(ctx.logdensity(zs), lp_ref, rtol=1e-9)
+    lp, g = ctx.logdensity_grad(zs[:, 1])
+    lpr, gr, _ = so.logdensity_grad(table, w_swa, p, x, y, 0.8, zs[:, 1])
+    assert np.isclose(lp, lp_ref[1], rtol=1e-9) and np.allclose(g, gr, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(gr).max()))
+    ctx.sample_rwmh(3, 0.05, seed=case)
+    nb = int(rng.integers(1, b + 1))
+    ctx.train_setup(table, n, w_swa.astype(np.float32), x, y, b, int(rng.integers(0, 3)), 0.01, 0.9, 0.999)
+    ctx.train_step(rng.choice(b, nb, replace=False).astype(np.int64))
+    assert np.all(np.isfinite(ctx.train_get_weights()))
+print("guard_fuzz_cnn: %d cases done" % cases, flush=True)
+ctx.close()
