@@ -43,26 +43,45 @@ for case in range(cases):
     lp, g = ctx.logdensity_grad(zs[:, 1])
     lpr, gr, _ = so.logdensity_grad(table, w_swa, p, x, y, 0.8, zs[:, 1])
     assert np.isclose(lp, lpr, rtol=1e-9) and np.allclose(g, gr, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(gr).max()))
-    zc, lpc, _ = ctx.sample_rwmh(4, 0.1, seed=case, nchains=int(rng.integers(1, 4)))
-    assert np.all(np.isfinite(lpc))
-    # training step on a random batch (values: the step must leave finite weights; the gradient itself is compared in tests/)
+    # chains stacked in one launch == one chain at a time, bit for bit; the streamed output map == si_reconstruct
+    nch = int(rng.integers(1, 4))
+    zc, lpc, _ = ctx.sample_rwmh(4, 0.1, seed=case, nchains=nch)
+    z1, lp1, _ = ctx.sample_rwmh(4, 0.1, seed=case, chain_id0=nch - 1, nchains=1)
+    assert np.array_equal(zc[:, :, nch - 1], z1[:, :, 0]) and np.array_equal(lpc[:, nch - 1], lp1[:, 0])
+    zw, lpw, _, wmap = ctx.sample_rwmh_weights(5, 0.1, seed=case + 1, nchains=nch)
+    assert np.array_equal(wmap[:, :, 0], ctx.reconstruct(np.asfortranarray(zw[:, :, 0])))
+    # training gradient on a random batch against the restatement of Zygote's, then one optimiser step
     nb = int(rng.integers(1, b + 1))
-    ctx.train_setup(table, n, w_swa.astype(np.float32), x, y, b, int(rng.integers(0, 3)), 0.01, 0.9, 0.999)
+    opt_kind = int(rng.integers(0, 3))
+    w32 = w_swa.astype(np.float32)
+    ctx.train_setup(table, n, w32, x, y, b, opt_kind, 0.01, 0.9, 0.999)
     ids = rng.choice(b, nb, replace=False).astype(np.int64)
+    sse = ctx.train_grad(ids, nb)
+    loss, gref = so.mse_value_and_grad(table, w32.astype(np.float64), x[:, ids], y[:, ids])
+    assert np.isclose(sse / (dims[-1] * nb), loss, rtol=1e-9)
+    assert np.allclose(ctx.train_grad_get(), gref, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(gref).max()))
+    ctx.train_apply()
     ctx.train_step(ids)
     assert np.all(np.isfinite(ctx.train_get_weights()))
-    # construction on the same N: K pushes of fp32 / fp64 vectors, ragged K
+    # construction on the same N: K pushes of fp32 / fp64 vectors, ragged K; W_swa bit-exact, P'P = diag(s^2), s vs LAPACK
     k = int(rng.integers(2, 40))
     mm = int(rng.integers(1, min(k, 8) + 1))
     ctx.construct_begin(n, k)
     dt = np.float32 if rng.random() < 0.7 else np.float64
     base = w_swa.copy()
+    snaps = []
     for j in range(k):
         base = base + 0.05 * rng.standard_normal(n)
-        ctx.construct_push(base.astype(dt), float(1 + j))
+        snaps.append(base.astype(dt))
+        ctx.construct_push(snaps[-1], float(1 + j))
+    w_ref, a_ref = so.construct_stream(snaps, [float(1 + j) for j in range(k)])
     try:
-        ctx.construct_finish(mm)
+        w_got, p_got, s_got, _ = ctx.construct_finish(mm)
+        assert np.array_equal(w_got, w_ref)
+        s_ref = np.linalg.svd(a_ref, compute_uv=False)[:mm]
+        assert np.allclose(s_got, s_ref, rtol=1e-5, atol=1e-9 * s_ref[0]), (s_got, s_ref)
+        assert np.allclose(p_got.T @ p_got, np.diag(s_got ** 2), rtol=1e-6, atol=1e-7 * s_got[0] ** 2)
     except si.BoundsError:
-        pass
+        assert min(n, k) < mm or np.linalg.svd(a_ref, compute_uv=False)[mm - 1] < 1e-6 * np.linalg.norm(a_ref, 2)
 print("guard_fuzz: %d cases done" % cases, flush=True)
 ctx.close()

@@ -72,8 +72,15 @@ for case in range(cases):
     assert np.isclose(lp, lp_ref[1], rtol=1e-9) and np.allclose(g, gr, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(gr).max()))
     ctx.sample_rwmh(3, 0.05, seed=case)
     nb = int(rng.integers(1, b + 1))
-    ctx.train_setup(table, n, w_swa.astype(np.float32), x, y, b, int(rng.integers(0, 3)), 0.01, 0.9, 0.999)
-    ctx.train_step(rng.choice(b, nb, replace=False).astype(np.int64))
+    w32 = w_swa.astype(np.float32)
+    ctx.train_setup(table, n, w32, x, y, b, int(rng.integers(0, 3)), 0.01, 0.9, 0.999)
+    ids = rng.choice(b, nb, replace=False).astype(np.int64)
+    sse = ctx.train_grad(ids, nb)
+    loss, gref = so.mse_value_and_grad(table, w32.astype(np.float64), x[:, ids], y[:, ids])
+    assert np.isclose(sse / (y.shape[0] * nb), loss, rtol=1e-9)
+    assert np.allclose(ctx.train_grad_get(), gref, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(gref).max()))
+    ctx.train_apply()
+    ctx.train_step(ids)
     assert np.all(np.isfinite(ctx.train_get_weights()))
 print("guard_fuzz_cnn: %d cases done" % cases, flush=True)
 ctx.close()
