@@ -65,6 +65,8 @@ for case in range(cases):
     else:
         assert np.allclose(g, g_ref, rtol=1e-10, atol=1e-12 * max(1e-300, np.abs(g_ref).max()))
     m = int(rng.integers(1, min(kk, 12) + 1))
+    if kk > 40 and rng.random() < 0.3:
+        m = int(rng.integers(33, min(kk, 80) + 1))   # wide subspaces: the projection on the matrix cores (M > 32)
     s_ref = np.linalg.svd(a_ref, compute_uv=False)
     try:
         w_got, p_got, s_got, _ = ctx.construct_finish(m)
