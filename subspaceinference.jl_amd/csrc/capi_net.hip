@@ -219,12 +219,10 @@ int32_t net_forward(Ctx* c, const NetPlan& p, const double* w, const double* xin
 void net_scratch_sizes(const NetPlan& p, int64_t B, int num_cu, size_t* bwpart, size_t* rspart, size_t* wt, size_t* dbtmp) {
   size_t part = 1;
   for (const LayerPlan& q : p.L) {
-    int64_t ks;
     if (q.kind == SI_LAYER_DENSE) {
       part = std::max(part, backward_weight_part_elems(q.out_feat, q.in_feat, B, num_cu));
     } else if (q.kind == SI_LAYER_CONV) {
-      const int ns = conv_dw_splits(q.Cop, q.Kp, (int64_t)q.Wo * q.Ho * B, num_cu, &ks);
-      part = std::max(part, (size_t)ns * q.Cop * q.Kp);
+      part = std::max(part, (size_t)conv_dw_max_splits(q.Cop, q.Kp, (int64_t)q.Wo * q.Ho * B, num_cu) * q.Cop * q.Kp);
     }
   }
   *bwpart = part;

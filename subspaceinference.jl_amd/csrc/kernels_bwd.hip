@@ -208,9 +208,21 @@ static DwPlan plan_dw(int32_t out, int32_t in, int64_t B, int num_cu) {
   return best;
 }
 
-// doubles of scratch launch_backward_weight needs for this layer
+// doubles of scratch launch_backward_weight needs for this layer at ANY batch of up to B columns.  The plan of a smaller
+// batch can hold MORE splits than the plan of B itself (the k range of a split is rounded up to whole 16-deep tiles, so
+// the split count is not monotonic in the batch: out = 95, in = 33 takes 243 splits at B = 66 003 and 256 at 65 536) and
+// can pick another row tile -- a training step on a last, smaller batch of an epoch wrote behind a buffer sized from
+// the plan of the full batch (found by tools/guard_fuzz.py under the guard-page allocator, round 3).  The bound: no plan
+// exceeds min(slots / tiles, ceil(B / 256)) splits for its row tile.
 size_t backward_weight_part_elems(int32_t out, int32_t in, int64_t B, int num_cu) {
-  return (size_t)plan_dw(out, in, B, num_cu).nsplit * out * in;
+  const int64_t slots = (int64_t)num_cu * 2, maxsplit = (B + 255) / 256;
+  int64_t worst = 1;
+  const int bms[3] = {96, 128, 64};
+  for (int bm : bms) {
+    const int64_t tiles = (int64_t)((out + bm - 1) / bm) * ((in + 127) / 128);
+    worst = std::max(worst, std::max<int64_t>(1, std::min(slots / tiles, maxsplit)));
+  }
+  return (size_t)worst * out * in;
 }
 
 // dW[out x in] = Delta * Hprev' into dW: split-K GEMM into `part`, then the splits added in fixed order

@@ -696,6 +696,16 @@ int conv_dw_splits(int COUTp, int Kp, int64_t npos, int num_cu, int64_t* ksplit_
   return (int)((npos + ks - 1) / ks);
 }
 
+// upper bound of conv_dw_splits over every position count up to npos (scratch sizing: the split count is not monotonic in
+// npos, see backward_weight_part_elems)
+int conv_dw_max_splits(int COUTp, int Kp, int64_t npos, int num_cu) {
+  const int bm = conv_pick_bm(COUTp);
+  const bool narrow = conv_dw_narrow(COUTp, Kp);
+  const int64_t tiles = (int64_t)((COUTp + bm - 1) / bm) * (narrow ? 1 : (Kp + 127) / 128);
+  const int64_t ns = ((int64_t)num_cu * (narrow ? 3 : 2)) / tiles;
+  return (int)std::max<int64_t>(1, std::min(ns, (npos + 255) / 256));
+}
+
 template <int BM, int BN, int MINW>
 static void launch_conv_dw_bm(hipStream_t st, const double* Delta, int Mp, const double* In, double* part, const ConvGeom& g,
                               int64_t npos, int Kp, int nsplit, int64_t ksplit) {

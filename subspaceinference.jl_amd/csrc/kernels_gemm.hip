@@ -41,14 +41,36 @@ __device__ __forceinline__ double apply_act(double v, int act) {
   }
 }
 
-// One output tile: BM features [mt*BM, ...) x BN batch columns [b0, b0+BN).  LDSD = doubles of LDS the launch provides
-// (a narrow tile of the last round runs inside the allocation of the full-width one).
-template <int BM, int BN, int WM, int WN, bool VEC, bool KEDGE, bool FUSE, int LDSD>
-__device__ __forceinline__ void dense_tile(const double* __restrict__ W, const double* __restrict__ bias,
-                                           const double* __restrict__ Hin, double* __restrict__ Hout, int out, int in,
-                                           int64_t B, int act, const double* __restrict__ Wlast, int out_last,
-                                           double* __restrict__ part, int64_t part_ld, int mt, int64_t b0, double* smem,
-                                           int dbg) {
+// FUSE: the layer's output is not stored.  The NEXT (last) layer of the chain, out_last <= 4 wide, is applied in the
+// epilogue: every wave reduces  sum_i Wlast[o][i] * act(H[i][b])  over its own features and writes one partial per
+// (feature slot, o, b) to `part`; tail_sse_kernel adds the slots in fixed order.  This removes the out x B store, the
+// whole GEMV-shaped last layer and its out x B re-read (cfg2: 768 MB written + 768 MB read per sample).
+template <int BM, int BN, int WM, int WN, int MINW, bool VEC, bool KEDGE, bool FUSE>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f64_kernel(
+    const double* __restrict__ W, const double* __restrict__ bias, const double* __restrict__ Hin,
+    double* __restrict__ Hout, int out, int in, int64_t B, int act, int nMt, int64_t nNt,
+    const double* __restrict__ Wlast, int out_last, double* __restrict__ part, ChainBatch cb) {
+  // chain batching: blockIdx.y is the chain slot; every operand that differs per chain moves by its slot stride
+  // (block-uniform scalar arithmetic; for a single chain all strides are unused)
+  if (blockIdx.y != 0) {
+    const int64_t ch = blockIdx.y;
+    W += ch * cb.w;
+    bias += ch * cb.w;
+    Hin += ch * cb.hin;
+    if constexpr (FUSE) {
+      Wlast += ch * cb.w;
+      part += ch * cb.part;
+      if (Hout != nullptr) Hout += ch * cb.hout;
+    } else {
+      Hout += ch * cb.hout;
+    }
+  }
+#ifdef SI_GEMM_DEBUG_KNOB
+  const int dbg = si_gemm_dbg;  // harness only, bit mask: 1 = every block loads tile (0,0) (L2-hot), 2 = no global loads in the k loop,
+                                // 4 = no barrier in the k loop, 8 = no LDS stores in the k loop (4 and 8 give wrong results: timing only)
+#else
+  constexpr int dbg = 0;
+#endif
   constexpr int NT = 64 * WM * WN;
   constexpr int BK = 16;
   constexpr int BMP = BM + 16;
@@ -60,14 +82,32 @@ __device__ __forceinline__ void dense_tile(const double* __restrict__ W, const d
   constexpr int HREGS = (BK * BN + NT * E - 1) / (NT * E);
   constexpr bool WRAG = (BK * BM) % (NT * E) != 0, HRAG = (BK * BN) % (NT * E) != 0;
   static_assert(BM % 32 == 0 && (BM / WM) % 16 == 0 && (BN / WN) % 16 == 0, "tile shape");
-  static_assert(2 * (BK * BMP + BN * BKP) <= LDSD, "LDS allocation");
+  extern __shared__ double smem[];
   double* sW = smem;                  // [2][BK][BMP]
   double* sH = smem + 2 * BK * BMP;   // [2][BN][BKP]
+
+  // XCD-aware block -> tile map: blocks b and b+8 share an XCD (its L2); the nMt feature tiles of one batch panel go to
+  // consecutive blocks of ONE XCD so that they find the panel's k tiles in that L2 while they walk it together.  That is a
+  // locality HINT, not a guarantee: 64 resident workgroups per XCD span ~6.4 panels, and W (7.4 MB at 960 x 960) is
+  // re-streamed by every round of workgroups -- the PMC passes count 2.76 GB per launch against 0.79 GB algorithmic (3.5x;
+  // profiles/*_pmc_dense_main.json), served at ~1 TB/s mostly out of the Infinity Cache while the kernel is MFMA-bound.
+  const int64_t bid = blockIdx.x;
+  const int xcd = (int)(bid & 7);
+  const int64_t j = bid >> 3;
+  const int mt = (int)(j % nMt);
+  const int64_t nt = (j / nMt) * 8 + xcd;
+  if (nt >= nNt) return;  // uniform per block: whole workgroup exits before any barrier
   SI_STAMP(0);
+  if ((dbg & 32) && bid < 512) {  // harness: stagger the first round of workgroups over ~one block time
+    const int n = (int)((bid * 2654435761u) >> 24) & 31;
+    const int unit = (dbg >> 8) ? (dbg >> 8) : 127;  // sleep quantum in 64-cycle units (dbg bits 8..)
+    for (int i = 0; i < n * unit; ++i) __builtin_amdgcn_s_sleep(1);
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
   const int i0 = mt * BM;
+  const int64_t b0 = nt * BN;
   const int q = lane >> 4, c = lane & 15;
 
   d4 acc[TM][TN];
@@ -263,7 +303,7 @@ __device__ __forceinline__ void dense_tile(const double* __restrict__ W, const d
   // consecutive lanes on consecutive features: every store instruction covers whole rows of the output tile.
   constexpr int WI = BM / WM;  // features per wave
   constexpr bool WIDE = VEC && (64 % (WI / 2) == 0 || (WI / 2) % 64 == 0) &&
-                        (WM * WN * 16 * WI <= LDSD);
+                        (WM * WN * 16 * WI <= 2 * (BK * BMP + BN * BKP));
   const int iw0 = i0 + wm * WI;
   const int64_t bw0 = b0 + wn * (BN / WN);
   auto finish = [&](double v) -> double {
@@ -314,7 +354,7 @@ __device__ __forceinline__ void dense_tile(const double* __restrict__ W, const d
           p += __shfl_xor(p, 2, 16);
           p += __shfl_xor(p, 1, 16);
           const int64_t gb = bw0 + b * 16 + q + 4 * r;
-          if (c == 0 && gb < B) part[(slot * out_last + o) * part_ld + gb] = p;
+          if (c == 0 && gb < B) part[(slot * out_last + o) * (cb.part_ld ? cb.part_ld : B) + gb] = p;
         }
       }
     }
@@ -366,92 +406,6 @@ __device__ __forceinline__ void dense_tile(const double* __restrict__ W, const d
   SI_STAMP(3);
 }
 
-// FUSE: the layer's output is not stored.  The NEXT (last) layer of the chain, out_last <= 4 wide, is applied in the
-// epilogue: every wave reduces  sum_i Wlast[o][i] * act(H[i][b])  over its own features and writes one partial per
-// (feature slot, o, b) to `part`; tail_sse_kernel adds the slots in fixed order.  This removes the out x B store, the
-// whole GEMV-shaped last layer and its out x B re-read (cfg2: 768 MB written + 768 MB read per sample).
-//
-// Grid: blocks [0, main_blocks) own the BN-wide panels [0, nNt) through the XCD-aware map below.  Blocks behind them
-// (NARROW launches only) own BN/2-wide panels of the columns from main_cols on: the launcher cuts the LAST, less than
-// half filled round of workgroups into half-width tiles so that it covers the whole chip for half as long instead of
-// half the chip for a whole tile time (cfg2: 7820 tiles on 512 slots = 15 rounds + 140 tiles; measured
-// tools/tail_quant_probe.py: 1.8 % of the kernel).  Workgroups are dispatched in block order, so the narrow ones come last.
-template <int BM, int BN, int WM, int WN, int MINW, bool VEC, bool KEDGE, bool FUSE, bool NARROW>
-__global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f64_kernel(
-    const double* __restrict__ W, const double* __restrict__ bias, const double* __restrict__ Hin,
-    double* __restrict__ Hout, int out, int in, int64_t B, int act, int nMt, int64_t nNt,
-    const double* __restrict__ Wlast, int out_last, double* __restrict__ part, ChainBatch cb, int64_t main_blocks,
-    int64_t main_cols) {
-  // chain batching: blockIdx.y is the chain slot; every operand that differs per chain moves by its slot stride
-  // (block-uniform scalar arithmetic; for a single chain all strides are unused)
-  if (blockIdx.y != 0) {
-    const int64_t ch = blockIdx.y;
-    W += ch * cb.w;
-    bias += ch * cb.w;
-    Hin += ch * cb.hin;
-    if constexpr (FUSE) {
-      Wlast += ch * cb.w;
-      part += ch * cb.part;
-      if (Hout != nullptr) Hout += ch * cb.hout;
-    } else {
-      Hout += ch * cb.hout;
-    }
-  }
-#ifdef SI_GEMM_DEBUG_KNOB
-  const int dbg = si_gemm_dbg;  // harness only, bit mask: 1 = every block loads tile (0,0) (L2-hot), 2 = no global loads in the k loop,
-                                // 4 = no barrier in the k loop, 8 = no LDS stores in the k loop (4 and 8 give wrong results: timing only)
-#else
-  constexpr int dbg = 0;
-#endif
-  constexpr int LDSD = 2 * (16 * (BM + 16) + BN * 18);
-  extern __shared__ double smem[];
-  const int64_t part_ld = cb.part_ld ? cb.part_ld : B;
-  const int64_t bid = blockIdx.x;
-  if (!NARROW || bid < main_blocks) {
-    // XCD-aware block -> tile map: blocks b and b+8 share an XCD (its L2); the nMt feature tiles of one batch panel go
-    // to consecutive blocks of ONE XCD so that they find the panel's k tiles in that L2 while they walk it together.
-    // That is a locality HINT, not a guarantee: 64 resident workgroups per XCD span ~6.4 panels, and W (7.4 MB at
-    // 960 x 960) is re-streamed by every round of workgroups -- the PMC passes count 2.76 GB per launch against 0.79 GB
-    // algorithmic (3.5x; profiles/*_pmc_dense_main.json), served at ~1 TB/s mostly out of the Infinity Cache while the
-    // kernel is MFMA-bound.
-    const int xcd = (int)(bid & 7);
-    const int64_t j = bid >> 3;
-    const int mt = (int)(j % nMt);
-    const int64_t nt = (j / nMt) * 8 + xcd;
-    if (nt >= nNt) return;  // uniform per block: whole workgroup exits before any barrier
-#ifdef SI_GEMM_DEBUG_KNOB
-    if ((dbg & 32) && bid < 512) {  // harness: stagger the first round of workgroups over ~one block time
-      const int n = (int)((bid * 2654435761u) >> 24) & 31;
-      const int unit = (dbg >> 8) ? (dbg >> 8) : 127;  // sleep quantum in 64-cycle units (dbg bits 8..)
-      for (int i = 0; i < n * unit; ++i) __builtin_amdgcn_s_sleep(1);
-    }
-#endif
-    dense_tile<BM, BN, WM, WN, VEC, KEDGE, FUSE, LDSD>(W, bias, Hin, Hout, out, in, B, act, Wlast, out_last, part,
-                                                       part_ld, mt, nt * BN, smem, dbg);
-  } else if constexpr (NARROW) {
-    const int64_t j = bid - main_blocks;
-    const int mt = (int)(j % nMt);
-    const int64_t b0 = main_cols + (j / nMt) * (BN / 2);
-    if (b0 >= B) return;
-    dense_tile<BM, BN / 2, WM, WN, VEC, KEDGE, FUSE, LDSD>(W, bias, Hin, Hout, out, in, B, act, Wlast, out_last, part,
-                                                           part_ld, mt, b0, smem, dbg);
-  }
-}
-
-// compute units of the current device (every GPU of a node is the same part: asked once per process)
-static int device_cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-      cus = n;
-    else
-      cus = 256;
-  }
-  return cus;
-}
-
 struct FuseArgs {
   const double* Wlast = nullptr;  // out_last x out, column-major (the last layer's weights inside the flat vector)
   int out_last = 0;
@@ -459,6 +413,17 @@ struct FuseArgs {
   ChainBatch cb;                  // chain slots in grid.y
 };
 
+// The last round of workgroups (measured in round 3 and left alone).  cfg2's layers are 7820 tiles on 512 slots (two
+// 8-wave workgroups per CU) = 15 rounds + 140 tiles: the last round keeps 140 CUs busy for a whole tile time and 116 idle
+// -- 1.7 % of the kernel at 15.27 rounds, 2.6 % at 10.2 (tools/tail_quant_probe.py).  Cutting that round into half-width
+// tiles was built twice, bit-identical both times (same k order, same per-wave feature slots of the fused head):
+//   * both widths in ONE kernel through a shared tile function: +2.2 % at 10.2 rounds, +0.3 % at cfg2 against itself --
+//     but the combined kernel's k loop came out with a different block structure and ran 1.8 % SLOWER at cfg2 than the
+//     kernel below (A/B against the library of the commit before, same box);
+//   * a second launch of the same template at BN = 64 on pointers shifted to the first column behind the last full
+//     round: +0.4 % at 10.2 rounds, 0.8 % slower at cfg2 (270 half tiles still pair up on 14 CUs, and the extra kernel
+//     boundary costs more than the idle CUs did).
+// profiles/r03_tail_round_ab.log.
 template <int BM, int BN, int WM, int WN, int MINW, bool VEC, bool KEDGE, bool FUSE>
 static void launch_dense_inst(hipStream_t st, const double* W, const double* bias, const double* Hin, double* Hout,
                               int32_t out, int32_t in, int64_t B, int32_t act, const FuseArgs& fa) {
@@ -469,40 +434,13 @@ static void launch_dense_inst(hipStream_t st, const double* W, const double* bia
   constexpr int NT = 64 * WM * WN;
   const int nMt = (out + BM - 1) / BM;
   const int64_t nNt = (B + BN - 1) / BN;
-  // The last round of workgroups: when it fills less than half of the chip's slots (two 8-wave workgroups per CU), the
-  // panels behind the last FULL round are cut into BN/2-wide tiles (see the kernel).  One chain per launch only; the
-  // main part keeps whole groups of 8 panels (the XCD map's unit).
-  if constexpr (WM * WN == 8 && BN == 128 && (BN / 2 / WN) % 16 == 0) {
-    const int64_t slots = 2 * (int64_t)device_cu_count();
-    const int64_t tiles = nNt * nMt, rem = tiles % slots;
-#ifdef SI_DEV_KNOBS   // development build: SI_GEMM_NO_NARROW=1 keeps full-width tiles in the last round (A/B runs)
-    const bool allow = getenv("SI_GEMM_NO_NARROW") == nullptr;
-#else
-    constexpr bool allow = true;
-#endif
-    if (allow && fa.cb.n == 1 && tiles > slots && rem > 0 && rem <= slots / 2) {
-      const int64_t main_panels = ((tiles - rem) / nMt) / 8 * 8;
-      const int64_t main_cols = main_panels * BN;
-      const int64_t narrow_panels = (B - main_cols + BN / 2 - 1) / (BN / 2);
-      if (main_panels > 0 && narrow_panels * nMt <= slots) {
-        const int64_t main_blocks = main_panels * nMt;   // whole groups of 8 panels: the map covers them exactly
-        auto kern = dense_f64_kernel<BM, BN, WM, WN, MINW, VEC, KEDGE, FUSE, true>;
-        static LdsOptIn optin;
-        optin.ensure(reinterpret_cast<const void*>(kern), lds);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(main_blocks + narrow_panels * nMt), 1u), dim3(NT), lds, st, W, bias, Hin,
-                           Hout, (int)out, (int)in, B, (int)act, nMt, main_panels, fa.Wlast, fa.out_last, fa.part, fa.cb,
-                           main_blocks, main_cols);
-        return;
-      }
-    }
-  }
   const int64_t groups = (nNt + 7) / 8;  // batch panels per XCD lane
   const int64_t grid = groups * nMt * 8;
-  auto kern = dense_f64_kernel<BM, BN, WM, WN, MINW, VEC, KEDGE, FUSE, false>;
+  auto kern = dense_f64_kernel<BM, BN, WM, WN, MINW, VEC, KEDGE, FUSE>;
   static LdsOptIn optin;
   optin.ensure(reinterpret_cast<const void*>(kern), lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)fa.cb.n), dim3(NT), lds, st, W, bias, Hin, Hout, (int)out,
-                     (int)in, B, (int)act, nMt, nNt, fa.Wlast, fa.out_last, fa.part, fa.cb, (int64_t)0, (int64_t)0);
+                     (int)in, B, (int)act, nMt, nNt, fa.Wlast, fa.out_last, fa.part, fa.cb);
 }
 
 template <int BM, int BN, int WM, int WN, int MINW, bool FUSE = false>

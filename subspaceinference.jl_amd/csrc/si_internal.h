@@ -360,6 +360,7 @@ void launch_pool2_bwd_idx(hipStream_t st, const double* G, const double* Hp, con
                           int64_t B, int act, double* part, int nout, double* db);
 void launch_conv_backward_data(hipStream_t st, const double* Wt, const double* Delta, double* dX, const ConvGeom& gT, int CINp,
                                int KpT, int64_t npos_in);
+int conv_dw_max_splits(int COUTp, int Kp, int64_t npos, int num_cu);   // bound over every position count up to npos (scratch sizing)
 int conv_dw_splits(int COUTp, int Kp, int64_t npos, int num_cu, int64_t* ksplit_out);
 void launch_conv_backward_weight(hipStream_t st, const double* Delta, const double* In, double* part, const ConvGeom& g, int COUTp,
                                  int Kp, int64_t npos, int nsplit, int64_t ksplit);

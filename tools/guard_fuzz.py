@@ -26,7 +26,7 @@ for case in range(cases):
     dims = [int(rng.choice([1, 2, 3, 7, 12, 15, 16, 17, 20, 31, 33, 40]))] + [int(rng.choice(WIDTHS)) for _ in range(nl - 1)] + \
            [int(rng.choice([1, 1, 2, 3, 4, 5, 8, 17, 96]))]
     acts = [int(rng.integers(0, 8)) for _ in range(nl)]
-    b = int(rng.choice(BATCH)) if rng.random() < 0.93 else int(rng.choice([7000, 22001, 33001, 66003]))   # a few with more than 512 tiles (narrow last round)
+    b = int(rng.choice(BATCH)) if rng.random() < 0.93 else int(rng.choice([7000, 22001, 33001, 66003]))   # a few with more than 512 tiles per layer (a second round of workgroups)
     m = int(rng.integers(1, 9)) if rng.random() < 0.85 else int(rng.integers(20, 71))
     print("case %d dims %s acts %s B %d M %d" % (case, dims, acts, b, m), flush=True)
     table, n = so.layer_table(dims, acts)

@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = sys.argv[1], sys.argv[2]
-KERNEL = "true, false, true, true>"   # dense_f64_kernel<96,128,2,4,4,VEC,KEDGE=false,FUSE=true,NARROW=true>: layer 2 + fused tail (cfg2 launches the narrow-last-round instance)
+KERNEL = "true, false, true>"   # dense_f64_kernel<96,128,2,4,4,VEC,KEDGE=false,FUSE=true>: layer 2 + fused tail
 vals, launches, cur = {}, None, None
 for line in open(src):
     if line.startswith("void si::") or line.startswith("si::"):
@@ -34,7 +34,7 @@ sha = hashlib.sha256(_code.encode()).hexdigest()[:16]   # code only: `//` commen
 busy = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (vals["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
 dur = sorted(vals["duration_ms_med"])[len(vals["duration_ms_med"]) // 2]
 rec = {
-    "kernel": "si::dense_f64_kernel<96,128,2,4,4,true,false,true,true> (layer 960x960 + fused 960->1 tail), cfg2",
+    "kernel": "si::dense_f64_kernel<96,128,2,4,4,true,false,true> (layer 960x960 + fused 960->1 tail), cfg2",
     "source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
               "bench.py --steps 10 --warmup 2; medians over %d launches; %s" % (launches, os.path.basename(src)),
     "FETCH_SIZE_KB": fetch_kb,

@@ -14,6 +14,8 @@ import subspaceinference_jl_amd as si  # noqa: E402
 if os.environ.get("SI_PROBE_DEV"):   # the development build (python subspaceinference.jl_amd/build.py --dev): SI_GEMM_NO_NARROW=1 A/B
     si._capi.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bin",
                                      "libsubspace_hip_dev.so")
+if os.environ.get("SI_PROBE_LIB"):   # any other build of the library (A/B against an older tree)
+    si._capi.LIB_PATH = os.path.abspath(os.environ["SI_PROBE_LIB"])
 sizes = [int(v) for v in sys.argv[1:]] or [98304, 100000, 100352, 104448, 131072, 65536, 66816]
 
 dims, acts, m = [128, 960, 960, 1], [1, 1, 0], 20
