@@ -83,6 +83,8 @@ def parse_args(argv=None):
     ap.add_argument("--config", choices=sorted(CFG), default="cfg5", help="construct-sharded: which N / K / M")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-chains", action="store_true",
+                    help="also time two independent chains per GPU (second context / host thread); reported beside the headline")
     ap.add_argument("--dry-run-launcher", action="store_true",
                     help="ranks join a gloo group, count themselves and print a line with value null: exercises the "
                          "launch / relay / failure logic on a machine without GPUs (tests/test_bench_launcher.py)")
@@ -559,23 +561,25 @@ def run_chains(args, rk, real_stdout):
     # two independent chains per GPU (a second ctx = second stream, driven from a second host thread): the fill / drain
     # phases and the store drain of one chain's launches run under the other's MFMAs.  Reported BESIDE
     # `value`, which stays BASELINE's one chain per GPU.
-    import threading
-    w2, p2, _ = ctx.construct_get_result()
-    with si.Context(rk.local_rank) as ctx2:
-        ctx2.infer_setup(table, n_par, M, w2, p2, x, y, SIGMA_M)
-        del w2, p2
-        ctx2.sample_rwmh(max(1, args.warmup), SIGMA_Z, seed=100, chain_id0=world + rank, want_z=False)
-        pair = [(ctx, rank), (ctx2, world + rank)]
-        barrier()
-        t0 = time.perf_counter()
-        th = [threading.Thread(target=lambda c=c, cid=cid: c.sample_rwmh(args.steps, SIGMA_Z, seed=100, chain_id0=cid, want_z=False))
-              for c, cid in pair]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        barrier()
-        dt_two = rk.max_over_ranks(time.perf_counter() - t0)
+    dt_two = None
+    if args.two_chains:
+      import threading
+      w2, p2, _ = ctx.construct_get_result()
+      with si.Context(rk.local_rank) as ctx2:
+          ctx2.infer_setup(table, n_par, M, w2, p2, x, y, SIGMA_M)
+          del w2, p2
+          ctx2.sample_rwmh(max(1, args.warmup), SIGMA_Z, seed=100, chain_id0=world + rank, want_z=False)
+          pair = [(ctx, rank), (ctx2, world + rank)]
+          barrier()
+          t0 = time.perf_counter()
+          th = [threading.Thread(target=lambda c=c, cid=cid: c.sample_rwmh(args.steps, SIGMA_Z, seed=100, chain_id0=cid, want_z=False))
+                for c, cid in pair]
+          for t in th:
+              t.start()
+          for t in th:
+              t.join()
+          barrier()
+          dt_two = rk.max_over_ranks(time.perf_counter() - t0)
     bsteps = 20
     ctx.set_profiling(True)
     ctx.reset_stats()
@@ -640,9 +644,10 @@ def run_chains(args, rk, real_stdout):
                                "sample (8.4 MB) streamed to a fresh pageable host array under the following transitions; "
                                "bit-identical to si_reconstruct: %s" % (args.steps, map_ok),
             "chain_1000_steps_samples_per_s": n_seen * 1000 / dt_1000,
-            "two_chains_per_gpu_samples_per_s": 2 * n_seen * args.steps / dt_two,
+            "two_chains_per_gpu_samples_per_s": (2 * n_seen * args.steps / dt_two) if dt_two else None,
             "two_chains_per_gpu_note": "two independent cfg2 chains per GPU from two contexts / host threads, %d transitions each "
-                                       "(chain ids rank and world + rank); NOT the headline: BASELINE's cfg2 / cfg3 are one chain per GPU" % args.steps,
+                                       "(chain ids rank and world + rank); NOT the headline: BASELINE's cfg2 / cfg3 are one chain per GPU; "
+                                       "measured with --two-chains only (its concurrent launches would blur a kernel trace of the default run)" % args.steps,
             "comm": ("in-library RCCL (si_comm_*), world %d" % n_seen) if rk.ctx is not None else
                     ("none (one rank)" if rk.dist is None else "gloo control plane only"),
             "comm_error": getattr(rk, "comm_error", None),
