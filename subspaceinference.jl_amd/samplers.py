@@ -164,7 +164,7 @@ class StanAdaptor:
         log_eps = self.mu - math.sqrt(self.t) / gamma * self.hbar
         eta = self.t ** (-kappa)
         self.log_eps_bar = eta * log_eps + (1.0 - eta) * self.log_eps_bar
-        self.eps = math.exp(log_eps)
+        self.eps = math.exp(min(log_eps, 700.0))   # (a diverging dual average must not raise)
         changed = False
         if self.window_start <= self.i <= self.window_end:
             self._wn += 1
@@ -181,7 +181,7 @@ class StanAdaptor:
                 self._restart_da(self.eps)
         if self.i == self.n_adapts:
             if self.t > 0:
-                self.eps = math.exp(self.log_eps_bar)
+                self.eps = math.exp(min(self.log_eps_bar, 700.0))
         return changed
 
 
@@ -198,7 +198,8 @@ def hmc(logdensity_grad, m, itr, sigma_z, rng, delta=0.8):
         h0 = lp - _kinetic(r, minv)
         zp, rp, lpp, gp = _leapfrog(logdensity_grad, z, r, g, eps, minv)
         h1 = lpp - _kinetic(rp, minv)
-        a = min(1.0, math.exp(h1 - h0)) if np.isfinite(h1) else 0.0
+        # (min(1, exp(dH)) without forming exp of a large positive dH: math.exp raises OverflowError above ~709)
+        a = (1.0 if h1 - h0 >= 0.0 else math.exp(h1 - h0)) if np.isfinite(h1) else 0.0
         if rng.random() < a:
             z, lp, g = zp, lpp, gp
         zs[:, t], lps[t], acc[t] = z, lp, a

@@ -282,3 +282,15 @@ def test_find_good_stepsize_reproduces_upstreams_lagged_crossing():
     # a NaN energy: direction -1 at the start, the crossing loop breaks at once, the bisection accepts its first midpoint
     nan_lg = lambda zz: (float("nan"), np.zeros_like(zz))
     assert samplers.find_good_stepsize(nan_lg, np.zeros(3), 0.0, np.zeros(3), np.random.default_rng(0)) == 0.5 * (0.05 + 0.1)
+
+
+def test_hmc_acceptance_ratio_does_not_overflow():
+    """min(1, exp(dH)) for a transition that LOWERS the energy by more than ~709 (a start far out in a sharp posterior): forming
+    exp(dH) first raised OverflowError (found by tools/guard_fuzz_api.py); the ratio is 1."""
+    from subspaceinference_jl_amd import samplers
+
+    def sharp(z):
+        return float(-0.5e6 * z @ z), -1e6 * z
+    for fn in (samplers.hmc, samplers.nuts, samplers.mala):
+        zs, lps = fn(sharp, 2, 6, 0.05, np.random.default_rng(0))[:2]
+        assert np.all(np.isfinite(np.asarray(lps, dtype=np.float64)))
