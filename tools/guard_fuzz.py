@@ -1,7 +1,7 @@
 """Random Dense chains through forward / log-density (chain-batched) / gradient / training gradient / construction, meant to
 run over the DEVELOPMENT library with the guard-page allocator (csrc/guard_alloc.hip), where an out-of-bounds access of
 any kernel faults at once.  The widths favour the tile edges of the kernels (96 / 128 / 64-row tiles, 16-deep k tiles).
-usage: SI_PROBE_DEV=1 SI_GUARD_ALLOC=end|begin python3 tools/guard_fuzz.py [cases] [seed]
+usage: SI_PROBE_DEV=1 SI_GUARD_ALLOC=end|begin [SI_FUZZ_BIG=1] python3 tools/guard_fuzz.py [cases] [seed]
 Every case is printed BEFORE it runs (a fault names its shape); values are checked against the oracle as well."""
 import os
 import sys
@@ -20,6 +20,9 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 WIDTHS = [1, 2, 3, 5, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 95, 96, 97, 100, 127, 128, 129, 160, 191, 192, 193, 200, 256, 288]
 BATCH = [1, 2, 7, 63, 64, 65, 127, 128, 129, 255, 300, 511, 513, 1000, 2049]
+if os.environ.get("SI_FUZZ_BIG"):   # wider layers and longer batches (more row tiles, the XCD-grouped maps, other split-K plans)
+    WIDTHS += [384, 480, 512, 960, 1000]
+    BATCH += [4096, 10000]
 ctx = si.Context(0)
 for case in range(cases):
     nl = int(rng.integers(1, 5))
