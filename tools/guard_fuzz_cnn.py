@@ -19,8 +19,14 @@ rng = np.random.default_rng(seed)
 osz = si._capi.conv_out_size
 
 
+BIG = bool(os.environ.get("SI_FUZZ_BIG"))   # larger images and channel counts (cfg4-like layers at a reduced batch)
+
+
 def random_spec():
-    w, h, c = int(rng.integers(3, 15)), int(rng.integers(3, 15)), int(rng.choice([1, 2, 3, 4, 16]))
+    if BIG:
+        w, h, c = int(rng.integers(12, 25)), int(rng.integers(12, 25)), int(rng.choice([3, 16]))
+    else:
+        w, h, c = int(rng.integers(3, 15)), int(rng.integers(3, 15)), int(rng.choice([1, 2, 3, 4, 16]))
     whc = (w, h, c)
     spec = []
     for _ in range(int(rng.integers(1, 4))):
@@ -34,7 +40,7 @@ def random_spec():
                 break
         else:
             break
-        cout = int(rng.choice([1, 2, 5, 16, 18, 32, 64, 70]))
+        cout = int(rng.choice([32, 64, 96, 128])) if BIG else int(rng.choice([1, 2, 5, 16, 18, 32, 64, 70]))
         spec.append(("conv", k, cout, int(rng.integers(0, 8)), s, pd, d))
         w, h = wo, ho
         if rng.random() < 0.5:
@@ -52,7 +58,7 @@ def random_spec():
 ctx = si.Context(0)
 for case in range(cases):
     whc, spec = random_spec()
-    b = int(rng.choice([1, 5, 37, 130]))
+    b = int(rng.choice([16, 48])) if BIG else int(rng.choice([1, 5, 37, 130]))
     m = int(rng.integers(1, 6))
     print("case %d input %s B %d M %d spec %s" % (case, whc, b, m, spec), flush=True)
     table, n = so.conv_table(spec, whc)
