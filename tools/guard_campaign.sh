@@ -1,12 +1,12 @@
 #!/bin/bash
-# All random-shape sweeps over the development library with the guard-page allocator, both modes, one seed base.
+# All random-shape sweeps (Dense, CNN, construction, API, end to end, communicator flows at world 1) over the development library with the guard-page allocator, both modes, one seed base.
 # usage (on the GPU box, after `python subspaceinference.jl_amd/build.py --dev`): tools/guard_campaign.sh <seed base> [scale]
 # Stops at the first failure and shows the tail of its log (gpurun_out/campaign_<tool>_<mode>_<seed>.log).
 base=${1:-100}; scale=${2:-1}
 mkdir -p gpurun_out
 export SI_PROBE_DEV=1 PYTHONUNBUFFERED=1
 i=0
-for spec in "guard_fuzz.py $((200*scale))" "guard_fuzz_cnn.py $((120*scale))" "guard_fuzz_gram.py $((120*scale))" "guard_fuzz_api.py $((80*scale))" "guard_fuzz_e2e.py $((25*scale))"; do
+for spec in "guard_fuzz.py $((200*scale))" "guard_fuzz_cnn.py $((120*scale))" "guard_fuzz_gram.py $((120*scale))" "guard_fuzz_api.py $((80*scale))" "guard_fuzz_e2e.py $((25*scale))" "guard_fuzz_comm.py $((40*scale))"; do
   set -- $spec
   for mode in end begin; do
     seed=$((base + i)); i=$((i + 1))
