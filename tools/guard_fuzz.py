@@ -1,7 +1,7 @@
 """Random Dense chains through forward / log-density (chain-batched) / gradient / training gradient / construction, meant to
 run over the DEVELOPMENT library with the guard-page allocator (csrc/guard_alloc.hip), where an out-of-bounds access of
 any kernel faults at once.  The widths favour the tile edges of the kernels (96 / 128 / 64-row tiles, 16-deep k tiles).
-usage: SI_PROBE_DEV=1 SI_GUARD_ALLOC=end|begin [SI_FUZZ_BIG=1] python3 tools/guard_fuzz.py [cases] [seed]
+usage: SI_PROBE_DEV=1 SI_GUARD_ALLOC=end|begin [SI_FUZZ_BIG=1] [SI_FUZZ_REPEAT=1] python3 tools/guard_fuzz.py [cases] [seed]
 Every case is printed BEFORE it runs (a fault names its shape); values are checked against the oracle as well."""
 import os
 import sys
@@ -46,6 +46,11 @@ for case in range(cases):
     lp, g = ctx.logdensity_grad(zs[:, 1])
     lpr, gr, _ = so.logdensity_grad(table, w_swa, p, x, y, 0.8, zs[:, 1])
     assert np.isclose(lp, lpr, rtol=1e-9) and np.allclose(g, gr, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(gr).max()))
+    if os.environ.get("SI_FUZZ_REPEAT"):   # same inputs, same bits: a race inside a kernel would show as a rare difference
+        assert np.array_equal(ctx.forward(zs[:, 0]), ctx.forward(zs[:, 0]))
+        assert np.array_equal(ctx.logdensity(zs), ctx.logdensity(zs))
+        lp_b, g_b = ctx.logdensity_grad(zs[:, 1])
+        assert lp_b == lp and np.array_equal(g_b, g)
     # chains stacked in one launch == one chain at a time, bit for bit; the streamed output map == si_reconstruct
     nch = int(rng.integers(1, 4))
     zc, lpc, _ = ctx.sample_rwmh(4, 0.1, seed=case, nchains=nch)
@@ -63,6 +68,9 @@ for case in range(cases):
     loss, gref = so.mse_value_and_grad(table, w32.astype(np.float64), x[:, ids], y[:, ids])
     assert np.isclose(sse / (dims[-1] * nb), loss, rtol=1e-9)
     assert np.allclose(ctx.train_grad_get(), gref, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(gref).max()))
+    if os.environ.get("SI_FUZZ_REPEAT"):
+        g_a = ctx.train_grad_get()
+        assert ctx.train_grad(ids, nb) == sse and np.array_equal(ctx.train_grad_get(), g_a)
     ctx.train_apply()
     ctx.train_step(ids)
     assert np.all(np.isfinite(ctx.train_get_weights()))

@@ -76,6 +76,10 @@ for case in range(cases):
     lp, g = ctx.logdensity_grad(zs[:, 1])
     lpr, gr, _ = so.logdensity_grad(table, w_swa, p, x, y, 0.8, zs[:, 1])
     assert np.isclose(lp, lp_ref[1], rtol=1e-9) and np.allclose(g, gr, rtol=1e-6, atol=2e-7 * max(1.0, np.abs(gr).max()))
+    if os.environ.get("SI_FUZZ_REPEAT"):   # same inputs, same bits
+        assert np.array_equal(ctx.forward(zs[:, 0]), ctx.forward(zs[:, 0])) and np.array_equal(ctx.logdensity(zs), ctx.logdensity(zs))
+        lp_b, g_b = ctx.logdensity_grad(zs[:, 1])
+        assert lp_b == lp and np.array_equal(g_b, g)
     ctx.sample_rwmh(3, 0.05, seed=case)
     nb = int(rng.integers(1, b + 1))
     w32 = w_swa.astype(np.float32)
@@ -87,6 +91,9 @@ for case in range(cases):
     # (atol: the fused conv + pool route evaluates act' at the window maximum where NNlib's rule picks an EARLIER input within
     # sqrt(eps) of it -- saturated tanh / sigmoid windows -- up to ~1e-8 of the pooled gradient per entry: kernels_conv.hip)
     assert np.allclose(ctx.train_grad_get(), gref, rtol=1e-7, atol=2e-7 * max(1.0, np.abs(gref).max()))
+    if os.environ.get("SI_FUZZ_REPEAT"):
+        g_a = ctx.train_grad_get()
+        assert ctx.train_grad(ids, nb) == sse and np.array_equal(ctx.train_grad_get(), g_a)
     ctx.train_apply()
     ctx.train_step(ids)
     assert np.all(np.isfinite(ctx.train_get_weights()))
