@@ -486,8 +486,10 @@ class Context:
         return m, v, (float(bp[0]), float(bp[1]))
 
     # -- density + sampling
-    def infer_setup(self, table, n, m, w_swa, p, x, y, sigma_m):
-        """table: list of (in, out, act, w_off, b_off); w_swa/p None => reuse the finished construction."""
+    def infer_setup(self, table, n, m, w_swa, p, x, y, sigma_m, compute_dtype=SI_F64):
+        """table: list of (in, out, act, w_off, b_off); w_swa/p None => reuse the finished construction.
+        compute_dtype: SI_F64 (the reference's arithmetic) or SI_F32 (Dense chains: fp32 X / weights / activations on the
+        fp32 matrix instruction, head + SSE in fp64; the measured option of SURVEY section 0 Q6)."""
         arr = _layer_array(table)
         x = _f64(x)
         y = _f64(y)
@@ -500,16 +502,17 @@ class Context:
                 raise SubspaceError("DimensionMismatch: W_swa %s, P %s, expected (%d,), (%d, %d)"
                                     % (w_swa.shape, p.shape, n, n, m))
         self._check(self.lib.si_infer_setup(self.h, arr, len(table), int(n), int(m), _ptr(w_swa), _ptr(p), _ptr(x),
-                                            _ptr(y), x.shape[0], y.shape[0], x.shape[1], float(sigma_m), SI_F64))
+                                            _ptr(y), x.shape[0], y.shape[0], x.shape[1], float(sigma_m), int(compute_dtype)))
         self._m, self._in, self._out, self._b, self._ni = int(m), x.shape[0], y.shape[0], x.shape[1], int(n)
 
-    def infer_setup_dev(self, table, n, m, w_swa_ptr, p_ptr, ld_p, x_ptr, y_ptr, in_dim, out_dim, b, sigma_m, borrow=False):
+    def infer_setup_dev(self, table, n, m, w_swa_ptr, p_ptr, ld_p, x_ptr, y_ptr, in_dim, out_dim, b, sigma_m, borrow=False,
+                        compute_dtype=SI_F64):
         """si_infer_setup with device addresses (ints); w_swa_ptr / p_ptr 0 or None => the finished construction."""
         arr = _layer_array(table)
         self._check(self.lib.si_infer_setup_dev(
             self.h, arr, len(table), int(n), int(m), c_void_p(int(w_swa_ptr)) if w_swa_ptr else None,
             c_void_p(int(p_ptr)) if p_ptr else None, int(ld_p), 1 if borrow else 0, c_void_p(int(x_ptr)), c_void_p(int(y_ptr)),
-            int(in_dim), int(out_dim), int(b), float(sigma_m), SI_F64))
+            int(in_dim), int(out_dim), int(b), float(sigma_m), int(compute_dtype)))
         self._m, self._in, self._out, self._b, self._ni = int(m), int(in_dim), int(out_dim), int(b), int(n)
 
     def set_prior(self, sigma_p):

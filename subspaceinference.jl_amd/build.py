@@ -21,6 +21,7 @@ SOURCES = [
     ("host_copy.cpp", []),
     ("kernels_stream.hip", ["-ffp-contract=off"]),
     ("kernels_gemm.hip", []),
+    ("kernels_gemm_f32.hip", []),
     ("kernels_gram.hip", []),
     ("kernels_gram_wave.hip", ["-DSI_GW_PART=0"], "kernels_gram_wave0"),   # same source, three slices of the tile counts
     ("kernels_gram_wave.hip", ["-DSI_GW_PART=1"], "kernels_gram_wave1"),

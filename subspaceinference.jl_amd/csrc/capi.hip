@@ -118,6 +118,12 @@ static void free_infer(Ctx* c) {
   dev_free(c->d_ssepart);
   dev_free(c->d_part);
   dev_free(c->d_yhat);
+  dev_free(c->d_X32);
+  dev_free(c->d_w32);
+  dev_free(c->d_act32[0]);
+  dev_free(c->d_act32[1]);
+  c->f32 = false;
+  c->fuse_slots32 = 0;
   for (auto& h : c->d_hs) dev_free(h);
   c->d_hs.clear();
   for (auto& h : c->d_pidx) dev_free(h);
@@ -875,15 +881,21 @@ int32_t si_construct_get_A(si_ctx* ctx, int64_t k0, int64_t nk, double* A_out) {
 // forward workspace for `slots` chains evaluated in one launch (grid.y = chain slot)
 static bool alloc_forward(si_ctx* ctx, int slots) {
   dev_free(ctx->d_w); dev_free(ctx->d_act[0]); dev_free(ctx->d_act[1]); dev_free(ctx->d_ssepart); dev_free(ctx->d_part);
-  dev_free(ctx->d_yhat);
+  dev_free(ctx->d_yhat); dev_free(ctx->d_w32); dev_free(ctx->d_act32[0]); dev_free(ctx->d_act32[1]);
   ctx->fw_slots = 0;
   const size_t S = (size_t)slots, dB = (size_t)ctx->out_dim * (size_t)ctx->B;
+  // SI_F32: fp32 weights + fp32 ping-pong activations INSTEAD of the fp64 activations (the fp64 weights stay: K4 writes
+  // both, the output map / prior / gradient read them); the head partials serve both paths (the larger slot count)
+  const size_t pslots = (size_t)std::max(ctx->fuse_slots, ctx->fuse_slots32);
   if (dev_alloc(&ctx->d_w, S * (size_t)pad_ld(ctx->iN)) != hipSuccess ||
-      dev_alloc(&ctx->d_act[0], S * (size_t)ctx->act_elems) != hipSuccess ||
-      dev_alloc(&ctx->d_act[1], S * (size_t)ctx->act_elems) != hipSuccess ||
+      (!ctx->f32 && (dev_alloc(&ctx->d_act[0], S * (size_t)ctx->act_elems) != hipSuccess ||
+                     dev_alloc(&ctx->d_act[1], S * (size_t)ctx->act_elems) != hipSuccess)) ||
+      (ctx->f32 && (dev_alloc(&ctx->d_w32, S * (size_t)pad_ld(ctx->iN)) != hipSuccess ||
+                    dev_alloc(&ctx->d_act32[0], S * (size_t)ctx->act_elems) != hipSuccess ||
+                    dev_alloc(&ctx->d_act32[1], S * (size_t)ctx->act_elems) != hipSuccess)) ||
       dev_alloc(&ctx->d_ssepart, S * (size_t)ctx->sse_blocks) != hipSuccess ||
-      (ctx->fuse_tail && (dev_alloc(&ctx->d_part, S * (size_t)ctx->fuse_slots * dB) != hipSuccess ||
-                          dev_alloc(&ctx->d_yhat, S * dB) != hipSuccess)))
+      (ctx->fuse_tail && dev_alloc(&ctx->d_part, S * pslots * dB) != hipSuccess) ||
+      ((ctx->fuse_tail || ctx->f32) && dev_alloc(&ctx->d_yhat, S * dB) != hipSuccess))
     return false;
   dev_free(ctx->d_wsqpart);
   ctx->wsq_blocks = sse_num_blocks(ctx->iN, ctx->num_cu);
@@ -903,8 +915,8 @@ static int32_t infer_setup_common(si_ctx* ctx, const si_layer* layers, int32_t L
   if (!layers || L <= 0 || N <= 0 || M <= 0 || !X || !Y || in_dim <= 0 || out_dim <= 0 || B <= 0)
     return fail(ctx, SI_ERR_INVALID, "si_infer_setup: bad argument");
   if (!(sigma_m > 0.0)) return fail(ctx, SI_ERR_INVALID, "si_infer_setup: sigma_m must be positive");
-  if (compute_dtype != SI_F64)
-    return fail(ctx, SI_ERR_INVALID, "si_infer_setup: only compute_dtype = SI_F64 (the reference's arithmetic) is implemented");
+  if (compute_dtype != SI_F64 && compute_dtype != SI_F32)
+    return fail(ctx, SI_ERR_INVALID, "si_infer_setup: compute_dtype must be SI_F64 (the reference's arithmetic) or SI_F32");
   if ((W_swa == nullptr) != (P == nullptr))
     return fail(ctx, SI_ERR_INVALID, "si_infer_setup: W_swa and P must both be given or both be NULL");
   // the Chain: Dense / Conv / MaxPool / flatten layers (anything else: the reference's "model_re function is not
@@ -914,6 +926,8 @@ static int32_t infer_setup_common(si_ctx* ctx, const si_layer* layers, int32_t L
     const int32_t prc = net_plan(ctx, "si_infer_setup", layers, L, N, in_dim, out_dim, plan);
     if (prc != SI_OK) return prc;
   }
+  if (compute_dtype == SI_F32 && plan.has_conv)
+    return fail(ctx, SI_ERR_INVALID, "si_infer_setup: compute_dtype = SI_F32 is implemented for Dense chains; Conv / MaxPool / flatten chains compute in SI_F64");
   int main_layer = 0;
   double main_flops = -1.0;
   for (int l = 0; l < L; ++l) {
@@ -971,12 +985,16 @@ static int32_t infer_setup_common(si_ctx* ctx, const si_layer* layers, int32_t L
   ctx->fuse_tail = !plan.has_conv && (L >= 2) && layers[L - 1].out <= SI_FUSE_MAX_OUT &&
                    layers[L - 1].act < SI_ACT_LEAKYRELU && layers[L - 2].act < SI_ACT_LEAKYRELU;   // (kernels_gemm.h)
   ctx->fuse_slots = ctx->fuse_tail ? dense_fused_slots(layers[L - 2].out) : 0;
+  ctx->f32 = compute_dtype == SI_F32;
+  // (the fp32 weight vector is 256-byte aligned and its slots are pad_ld(N) apart: a layer's W is 16-byte aligned iff w_off % 4 == 0)
+  ctx->fuse_slots32 = (ctx->f32 && ctx->fuse_tail) ? dense_f32_fused_slots(layers[L - 2].out, layers[L - 2].in, layers[L - 2].w_off % 4 == 0) : 0;
   int64_t maxstored = 1;
   for (int l = 0; l < (ctx->fuse_tail ? L - 2 : L); ++l) maxstored = std::max<int64_t>(maxstored, plan.L[(size_t)l].out_elems);
   ctx->max_stored = maxstored;
   ctx->act_elems = pad_ld(maxstored * B);
   ctx->sse_blocks = sse_num_blocks((int64_t)out_dim * B, ctx->num_cu);
   if (dev_alloc(&ctx->d_X, (size_t)in_dim * B) != hipSuccess || dev_alloc(&ctx->d_Y, (size_t)out_dim * B) != hipSuccess ||
+      (ctx->f32 && dev_alloc(&ctx->d_X32, (size_t)pad_ld((int64_t)in_dim * B)) != hipSuccess) ||
       !alloc_forward(ctx, 1) ||
       (plan.has_conv && dev_alloc(&ctx->d_wpack, plan.wpack_elems) != hipSuccess) ||
       (plan.input_spatial && dev_alloc(&ctx->d_Xc, (size_t)plan.in_elems * B) != hipSuccess)) {
@@ -989,6 +1007,7 @@ static int32_t infer_setup_common(si_ctx* ctx, const si_layer* layers, int32_t L
     SI_HIP(ctx, hipMemcpyAsync(ctx->d_Y, Y, (size_t)out_dim * B * sizeof(double), kind, ctx->stream));
   }
   if (plan.input_spatial) net_input(ctx, plan, ctx->d_X, ctx->d_Xc, B);  // (W, H, C, N) -> channel-fastest, once
+  if (ctx->f32) launch_narrow_f32(ctx->stream, ctx->d_X, ctx->d_X32, (int64_t)in_dim * B);   // X rounded to fp32 once
   SI_HIP(ctx, hipGetLastError());
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->i_ready = true;
@@ -1037,8 +1056,10 @@ int32_t si_construct_result_ptr(si_ctx* ctx, double** W_swa_dev_out, double** P_
 static constexpr double SI_BATCH_BYTES = 2.0 * 1024.0 * 1024.0 * 1024.0;
 static int batch_width(const si_ctx* ctx, int C) {
   if (ctx->plan.has_conv) return 1;  // chains with Conv layers fill the chip one chain at a time
-  const double per = 8.0 * (2.0 * (double)ctx->act_elems + ((double)ctx->fuse_slots + 1.0) * (double)ctx->out_dim * (double)ctx->B +
-                            (double)pad_ld(ctx->iN) + (double)ctx->sse_blocks);
+  const double pslots = (double)std::max(ctx->fuse_slots, ctx->fuse_slots32);
+  const double per = (ctx->f32 ? 4.0 : 8.0) * 2.0 * (double)ctx->act_elems +
+                     8.0 * ((pslots + 1.0) * (double)ctx->out_dim * (double)ctx->B + (ctx->f32 ? 1.5 : 1.0) * (double)pad_ld(ctx->iN) +
+                            (double)ctx->sse_blocks);
   const double fit = std::floor(SI_BATCH_BYTES / per);
   return (int)std::max(1.0, std::min({(double)C, fit, 1024.0}));
 }
@@ -1072,6 +1093,66 @@ static int32_t ensure_chains(si_ctx* ctx, int32_t C) {
   return SI_OK;
 }
 
+// compute_dtype = SI_F32: the Dense chain of eval_density on the fp32 matrix instruction (kernels_gemm_f32.hip).  K4 has
+// left W_swa + P z in d_w (fp64) AND rounded once in d_w32; X32 / activations are fp32; the narrow head's partial sums, the
+// last bias + activation (tail_sse_kernel, unchanged) and the sum of squared errors are fp64.  Replaces the same reference
+// lines as the fp64 path, src/space_inference.jl:92-94, with the precision option of SURVEY section 0 Q6.
+static int32_t eval_density_f32(si_ctx* ctx, int c0, int nc, const double** yhat_out) {
+  const int64_t N = ctx->iN, B = ctx->B, ldw = pad_ld(N);
+  const double dn = (double)nc;
+  ChainBatch cb;
+  cb.n = nc;
+  cb.w = ldw;
+  cb.hin = 0;  // X is shared by all chains
+  cb.hout = ctx->act_elems;
+  cb.part = (int64_t)ctx->fuse_slots32 * ctx->out_dim * B;
+  const float* h = ctx->d_X32;
+  const float* w = ctx->d_w32;
+  const size_t nl = ctx->layers.size();
+  const size_t nstored = ctx->fuse_tail ? nl - 2 : nl;
+  for (size_t l = 0; l < nstored; ++l) {
+    const si_layer& ly = ctx->layers[l];
+    float* o = ctx->d_act32[l & 1];
+    const double fl = 2.0 * (double)ly.in * (double)ly.out * (double)B * dn;
+    const double by = ((double)ly.in * ly.out + ly.out + (double)(ly.in + ly.out) * (double)B) * 4.0 * dn;
+    {
+      ProfScope ps(ctx, SI_K_DENSE, fl, by);
+      ProfScope pm((int)l == ctx->main_layer ? ctx : nullptr, SI_K_DENSE_MAIN, fl, by);
+      launch_dense_f32(ctx->stream, w + ly.w_off, w + ly.b_off, h, o, ly.out, ly.in, B, ly.act, cb);
+    }
+    h = o;
+    cb.hin = ctx->act_elems;
+  }
+  const int64_t d = (int64_t)ctx->out_dim * B;
+  if (ctx->fuse_tail) {
+    const si_layer& ly = ctx->layers[nl - 2];
+    const si_layer& ll = ctx->layers[nl - 1];
+    const double fl = (2.0 * (double)ly.in * (double)ly.out * (double)B + 2.0 * (double)ll.in * (double)ll.out * (double)B) * dn;
+    const double by = (((double)ly.in * ly.out + ly.out + (double)ly.in * (double)B + (double)ll.in * ll.out) * 4.0 +
+                       (double)ctx->fuse_slots32 * ll.out * (double)B * 8.0) * dn;
+    {
+      ProfScope ps(ctx, SI_K_DENSE, fl, by);
+      ProfScope pm(((int)nl - 2 == ctx->main_layer || (int)nl - 1 == ctx->main_layer) ? ctx : nullptr, SI_K_DENSE_MAIN, fl, by);
+      launch_dense_f32_fused(ctx->stream, w + ly.w_off, w + ly.b_off, h, ly.out, ly.in, B, ly.act, w + ll.w_off, ll.out,
+                             ctx->d_part, cb);
+    }
+    {
+      ProfScope ps(ctx, SI_K_SSE, (3.0 + ctx->fuse_slots32) * (double)d * dn, (16.0 + 8.0 * ctx->fuse_slots32) * (double)d * dn);
+      // the head's bias is added in fp64 from the fp64 weight vector (same number the fp32 copy was rounded from)
+      launch_tail_sse(ctx->stream, ctx->d_part, ctx->fuse_slots32, ll.out, B, ctx->d_w + ll.b_off, ll.act, ctx->d_Y,
+                      yhat_out ? ctx->d_yhat : nullptr, ctx->d_ssepart, ctx->sse_blocks, cb);
+      launch_sse_final(ctx->stream, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, nc);
+    }
+  } else {
+    ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d * dn, 12.0 * (double)d * dn);
+    launch_sse_f32(ctx->stream, h, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, nc, ctx->act_elems,
+                   yhat_out ? ctx->d_yhat : nullptr, d);
+  }
+  SI_HIP(ctx, hipGetLastError());
+  if (yhat_out) *yhat_out = ctx->d_yhat;   // slot j at + j * out_dim*B
+  return SI_OK;
+}
+
 // density evaluations for chain slots [c0, c0 + nc), nc <= fw_slots, in ONE pass of launches:
 // d_zprop[:, c] -> d_sse[c]; optionally leaves the model outputs at *yhat_out (slot j at + j * out_dim*B after the fused
 // tail, at + j * act_elems otherwise)
@@ -1082,7 +1163,7 @@ static int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out
   {
     ProfScope ps(ctx, SI_K_RECON, 2.0 * (double)N * M * dn, (double)N * (M + 1 + dn) * 8.0);
     launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, ctx->d_zprop + (size_t)c0 * M, nc, ctx->d_w, ldw,
-                       ctx->num_cu);
+                       ctx->num_cu, ctx->f32 ? ctx->d_w32 : nullptr, ldw);
   }
   if (ctx->sigma_p > 0.0)  // ||new_W||^2 per chain for the optional prior term (same fixed-order reduction as the SSE)
     launch_sse(ctx->stream, ctx->d_w, nullptr, N, ctx->d_wsqpart, ctx->wsq_blocks, ctx->d_wsq + c0, nc, ldw);
@@ -1154,6 +1235,7 @@ static int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out
     return SI_OK;
   }
 #endif  // SI_DEV_KNOBS
+  if (ctx->f32) return eval_density_f32(ctx, c0, nc, yhat_out);
   ChainBatch cb;
   cb.n = nc;
   cb.w = ldw;
@@ -1462,6 +1544,10 @@ int32_t si_predict(si_ctx* ctx, const double* Z, int32_t C, const double* Xnew, 
     int sse_blocks;
   } sv{ctx->d_X, ctx->d_Y, ctx->d_act[0], ctx->d_act[1], ctx->d_ssepart, ctx->d_part, ctx->d_yhat, ctx->d_Xc,
        ctx->B, ctx->act_elems, ctx->sse_blocks};
+  // (with compute_dtype = SI_F32 the predictive forward still runs in fp64: it owns its fp64 workspace below, and the fp64
+  //  weights are what K4 writes in either mode -- the fp32 option covers the density / the RWMH samplers)
+  const bool f32_saved = ctx->f32;
+  ctx->f32 = false;
   const int64_t act_elems = pad_ld(ctx->max_stored * Bn);
   const int sse_blocks = sse_num_blocks((int64_t)ctx->out_dim * Bn, ctx->num_cu);
   const size_t dB = (size_t)ctx->out_dim * (size_t)Bn;
@@ -1499,6 +1585,7 @@ int32_t si_predict(si_ctx* ctx, const double* Z, int32_t C, const double* Xnew, 
     ctx->d_part = sv.part; ctx->d_yhat = sv.yhat; ctx->B = sv.B; ctx->act_elems = sv.act_elems; ctx->sse_blocks = sv.sse_blocks;
     ctx->d_Xc = sv.Xc;
   }
+  ctx->f32 = f32_saved;
   (void)hipStreamSynchronize(ctx->stream);
   dev_free(tX); dev_free(tY); dev_free(tA0); dev_free(tA1); dev_free(tS); dev_free(tP); dev_free(tYh); dev_free(tXc);
   if (!ok) return fail(ctx, SI_ERR_NOMEM, "si_predict: device allocation failed");

@@ -184,7 +184,10 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(const double* __restri
                                                           const double* __restrict__ P, int64_t ldP,
                                                           int64_t N, int32_t M,
                                                           const double* __restrict__ Z,
-                                                          double* __restrict__ w, int64_t ldw) {
+                                                          double* __restrict__ w, int64_t ldw,
+                                                          float* __restrict__ w32, int64_t ldw32) {
+  // w32 != nullptr (compute_dtype = SI_F32): the same fp64 sum is ALSO stored rounded once to fp32 -- the weights the
+  // fp32 forward multiplies with; the fp64 copy keeps feeding the output map, the prior term and the gradient path
   const int64_t npair = (N + 1) >> 1;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npair; p += stride) {
@@ -215,26 +218,34 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(const double* __restri
       } else {
         dst[0] = sv.x + acc[c].x;
       }
+      if (w32 != nullptr) {   // ldw32 is even (pad_ld) and the rows come in pairs: 8-byte stores
+        float* d32 = w32 + (int64_t)c * ldw32 + r;
+        if (r + 1 < N)
+          *reinterpret_cast<float2*>(d32) = make_float2((float)(sv.x + acc[c].x), (float)(sv.y + acc[c].y));
+        else
+          d32[0] = (float)(sv.x + acc[c].x);
+      }
     }
   }
 }
 
 void launch_reconstruct(hipStream_t st, const double* swa, const double* P, int64_t ldP, int64_t N,
-                        int32_t M, const double* Z, int32_t C, double* w, int64_t ldw, int num_cu) {
+                        int32_t M, const double* Z, int32_t C, double* w, int64_t ldw, int num_cu, float* w32, int64_t ldw32) {
   const int grid = stream_grid((N + 1) >> 1, num_cu);
   int c0 = 0;
   while (c0 < C) {
     const int rem = C - c0;
     const double* Zc = Z + (int64_t)c0 * M;
     double* wc = w + (int64_t)c0 * ldw;
+    float* wc32 = w32 ? w32 + (int64_t)c0 * ldw32 : nullptr;
     if (rem >= 4) {
-      hipLaunchKernelGGL((reconstruct_kernel<4>), dim3(grid), dim3(256), 0, st, swa, P, ldP, N, M, Zc, wc, ldw);
+      hipLaunchKernelGGL((reconstruct_kernel<4>), dim3(grid), dim3(256), 0, st, swa, P, ldP, N, M, Zc, wc, ldw, wc32, ldw32);
       c0 += 4;
     } else if (rem >= 2) {
-      hipLaunchKernelGGL((reconstruct_kernel<2>), dim3(grid), dim3(256), 0, st, swa, P, ldP, N, M, Zc, wc, ldw);
+      hipLaunchKernelGGL((reconstruct_kernel<2>), dim3(grid), dim3(256), 0, st, swa, P, ldP, N, M, Zc, wc, ldw, wc32, ldw32);
       c0 += 2;
     } else {
-      hipLaunchKernelGGL((reconstruct_kernel<1>), dim3(grid), dim3(256), 0, st, swa, P, ldP, N, M, Zc, wc, ldw);
+      hipLaunchKernelGGL((reconstruct_kernel<1>), dim3(grid), dim3(256), 0, st, swa, P, ldP, N, M, Zc, wc, ldw, wc32, ldw32);
       c0 += 1;
     }
   }

@@ -184,6 +184,12 @@ struct Ctx {
   int fuse_slots = 0;
   double* d_part = nullptr;     // fw_slots x [slots][out_last][B] partial last-layer products
   double* d_yhat = nullptr;     // fw_slots x out_dim x B, only filled on request (si_forward)
+  // compute_dtype = SI_F32 (Dense chains): X rounded once, weights rounded once per evaluation (K4 writes both), fp32 activations
+  bool f32 = false;
+  int fuse_slots32 = 0;                      // feature slots of the fp32 fused head (fuse_slots stays the fp64 path's count)
+  float* d_X32 = nullptr;
+  float* d_w32 = nullptr;                    // fw_slots x pad_ld(N)
+  float* d_act32[2] = {nullptr, nullptr};    // fw_slots x act_elems
   int sse_blocks = 0;
   int main_layer = 0;
   // gradient workspace (allocated on the first si_logdensity_grad)
@@ -281,7 +287,8 @@ bool launch_project_stream(hipStream_t st, const double* A, int64_t ldA, int64_t
                            int32_t Mpad, double* P, int64_t ldP, int num_cu);
 // K4: w[c*ldw + r] = swa[r] + sum_m P[r + m*ldP] * Z[m + c*M]
 void launch_reconstruct(hipStream_t st, const double* swa, const double* P, int64_t ldP, int64_t N,
-                        int32_t M, const double* Z, int32_t C, double* w, int64_t ldw, int num_cu);
+                        int32_t M, const double* Z, int32_t C, double* w, int64_t ldw, int num_cu,
+                        float* w32 = nullptr /* SI_F32: the same sums rounded once to fp32 */, int64_t ldw32 = 0);
 // Chain batching of the forward pass: `n` chain slots run in ONE launch (grid.y = slot).  Strides, in elements, from
 // one slot to the next: `w` of the reconstructed weight vectors (W, bias, Wlast all live in it), `hin` / `hout` of
 // the layer's input / output activations (hin = 0 for the first layer: X is shared), `part` of the fused-tail partials.
@@ -301,6 +308,17 @@ int dense_fused_slots(int32_t out);
 void launch_dense_f64_fused(hipStream_t st, const double* W, const double* bias, const double* Hin, int32_t out,
                             int32_t in, int64_t B, int32_t act, const double* Wlast, int32_t out_last, double* part,
                             const ChainBatch& cb = ChainBatch(), double* Hkeep = nullptr /* also store the layer's output */);
+// K5 in fp32 (kernels_gemm_f32.hip; compute_dtype = SI_F32): same operation and chain batching, fp32 operands / outputs on
+// v_mfma_f32_32x32x2_f32; the fused head writes fp64 partials that launch_tail_sse sums as in the fp64 path
+void launch_dense_f32(hipStream_t st, const float* W, const float* bias, const float* Hin, float* Hout, int32_t out, int32_t in,
+                      int64_t B, int32_t act, const ChainBatch& cb = ChainBatch());
+int dense_f32_fused_slots(int32_t out, int32_t in, bool aligned);
+void launch_dense_f32_fused(hipStream_t st, const float* W, const float* bias, const float* Hin, int32_t out, int32_t in, int64_t B,
+                            int32_t act, const float* Wlast, int32_t out_last, double* part, const ChainBatch& cb = ChainBatch(),
+                            float* Hkeep = nullptr);
+void launch_narrow_f32(hipStream_t st, const double* src, float* dst, int64_t n);
+void launch_sse_f32(hipStream_t st, const float* yhat, const double* y, int64_t d, double* part, int nblocks, double* sse_out,
+                    int nch = 1, int64_t yhat_stride = 0, double* yhat64 = nullptr, int64_t yhat64_stride = 0);
 void launch_tail_sse(hipStream_t st, const double* part, int slots, int out_last, int64_t B, const double* bias_last,
                      int act_last, const double* Y, double* yhat, double* blockpart, int nblocks,
                      const ChainBatch& cb = ChainBatch());
