@@ -84,7 +84,9 @@ __device__ __forceinline__ void f32_fused_head(const f16v (&acc)[TM][TN], const 
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NB, bool FUSE>
+// (MINW only keeps the body's instantiation 1:1 with its kernel's: two __global__ instantiations sharing one body with device
+//  builtins inside lambdas do not survive the host-side pass)
+template <int BM, int BN, int WM, int WN, int NB, int MINW, bool FUSE>
 __device__ __forceinline__ void dense_f32_dma_body(const float* __restrict__ W, const float* __restrict__ bias,
                                                    const float* __restrict__ Hin, float* __restrict__ Hout, int out, int in,
                                                    int64_t B, int act, int nMt, int64_t nNt, const float* __restrict__ Wlast,
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f32_dma_kernel(
     }
   }
   extern __shared__ float smem_f32[];
-  dense_f32_dma_body<BM, BN, WM, WN, NB, FUSE>(W, bias, Hin, Hout, out, in, B, act, nMt, nNt, Wlast, out_last, part, cb, smem_f32);
+  dense_f32_dma_body<BM, BN, WM, WN, NB, MINW, FUSE>(W, bias, Hin, Hout, out, in, B, act, nMt, nNt, Wlast, out_last, part, cb, smem_f32);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -12,6 +12,9 @@ sys.path.insert(0, ROOT)
 import subspaceinference_jl_amd as si  # noqa: E402
 from subspaceinference_jl_amd import _capi  # noqa: E402
 
+if os.environ.get("SI_PROBE_LIB"):   # A/B of two builds of the library in one gpurun call (same device)
+    _capi.LIB_PATH = os.path.abspath(os.environ["SI_PROBE_LIB"])
+
 DIMS, ACTS = [128, 960, 960, 1], [1, 1, 0]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 30
