@@ -59,6 +59,8 @@ DIMS, ACTS = [128, 960, 960, 1], [1, 1, 0]  # Chain(Dense(128,960,relu), Dense(9
 B, M, K_SNAP = 100000, 20, 100
 SIGMA_Z, SIGMA_M = 0.1, 1.0
 PEAK_F64_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet; the guide's table has no f64 row -- DESIGN.md section 4)
+PEAK_F32_TFLOPS = 157.3  # MI355X fp32 matrix peak (guide: v_mfma_f32_32x32x2_f32, 155 measured)
+PMC_PROFILE_F32 = "r04_pmc_dense_f32_main.json"   # the same passes on the fp32 kernel (sha-keyed to kernels_gemm_f32.hip)
 PEAK_HBM_GBS = 8000.0
 PMC_PROFILE = "r03_pmc_dense_main.json"   # rocprofv3 --pmc passes of the dominant kernel (sha-keyed to kernels_gemm.hip)
 CFG = {  # construct-only configurations
@@ -555,7 +557,7 @@ def run_chains(args, rk, real_stdout):
     # one long chain, reported beside `value`: itr = 1000 is what BASELINE's cfg2 names; a short --steps run is corroborated
     barrier()
     t0 = time.perf_counter()
-    ctx.sample_rwmh(1000, SIGMA_Z, seed=100, chain_id0=rank, want_z=False)
+    z1k, lp1k, _ = ctx.sample_rwmh(1000, SIGMA_Z, seed=100, chain_id0=rank)
     barrier()
     dt_1000 = rk.max_over_ranks(time.perf_counter() - t0)
     # two independent chains per GPU (a second ctx = second stream, driven from a second host thread): the fill / drain
@@ -587,6 +589,27 @@ def run_chains(args, rk, real_stdout):
     ctx.synchronize()
     bst = ctx.stats()
     ctx.set_profiling(False)
+
+    # ---- compute_dtype = SI_F32 (SURVEY section 0 Q6 / 8(b),(d)): the same chain with X, the per-step weights and the activations
+    # in fp32 on v_mfma_f32_32x32x2_f32 (head + SSE in fp64), reported BESIDE the fp64 headline, never instead of it
+    from subspaceinference_jl_amd import _capi
+    ctx.infer_setup(table, n_par, M, None, None, x, y, SIGMA_M, compute_dtype=_capi.SI_F32)
+    ctx.set_profiling(True, classes=["dense_main"])
+    ctx.sample_rwmh(max(1, args.warmup), SIGMA_Z, seed=100, chain_id0=rank, want_z=False)
+    barrier()
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    z32, lp32, acc32 = ctx.sample_rwmh(args.steps, SIGMA_Z, seed=100, chain_id0=rank)
+    barrier()
+    dt32 = rk.max_over_ranks(time.perf_counter() - t0)
+    st32 = ctx.stats()
+    ctx.set_profiling(False)
+    z32k, lp32k, acc32k = ctx.sample_rwmh(1000, SIGMA_Z, seed=100, chain_id0=rank)   # divergence from the fp64 chain, same Philox stream
+    same = np.all(z32k[:, :, 0] == z1k[:, :, 0], axis=0)
+    f32_first_diff = -1 if bool(same.all()) else int(np.argmin(same))
+    nsame = int(same.sum()) if f32_first_diff < 0 else f32_first_diff
+    f32_lp_rel = float(np.max(np.abs(lp32k[:nsame, 0] - lp1k[:nsame, 0]) / np.abs(lp1k[:nsame, 0]))) if nsame else None
+    ctx.infer_setup(table, n_par, M, None, None, x, y, SIGMA_M)   # back to the reference's arithmetic for what follows
 
     extras = {}
     if rank == 0:
@@ -630,6 +653,12 @@ def run_chains(args, rk, real_stdout):
                 return {"bound": "hbm", "achieved_GBs": round(a, 1), "frac": round(a / PEAK_HBM_GBS, 4), "ms": round(v["ms"], 4)}
             a = v["flops"] / (v["ms"] * 1e-3) / 1e12
             return {"bound": "mfma", "achieved_TFLOPs": round(a, 2), "frac": round(a / PEAK_F64_TFLOPS, 4), "ms": round(v["ms"], 4)}
+        dm32 = st32["dense_main"]
+        avg32 = dm32["ms"] / max(1, dm32["launches"])
+        fl32 = dm32["flops"] / max(1, dm32["launches"])
+        ach32 = fl32 / (avg32 * 1e-3) / 1e12 if avg32 > 0 else 0.0
+        traffic32, traffic32_src = pmc_traffic(PMC_PROFILE_F32, ["kernels_gemm_f32.hip"])
+        ms_step32 = dt32 / args.steps * 1e3
         out = {
             "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": n_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -676,6 +705,19 @@ def run_chains(args, rk, real_stdout):
             "step_roofline": {"bound": "mfma", "flops_per_step": step_flops, "achieved": step_tflops, "peak": PEAK_F64_TFLOPS,
                               "unit": "TFLOP/s", "frac": step_tflops / PEAK_F64_TFLOPS,
                               "note": "ALL of a transition (propose, reconstruct, 3 layers, SSE, accept) against the fp64 matrix peak"},
+            "value_f32": n_seen * args.steps / dt32, "ms_per_step_f32": ms_step32,
+            "roofline_f32": {"kernel": "dense_f32_dma_kernel<192,128> layer 960x960 + fused 960->1 head (v_mfma_f32_32x32x2_f32)",
+                             "bound": "mfma", "achieved": ach32, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": ach32 / PEAK_F32_TFLOPS,
+                             "traffic": traffic32, "traffic_source": traffic32_src, "avg_launch_ms": avg32, "flops_per_launch": fl32,
+                             "launches": dm32["launches"]},
+            "f32": {"note": "compute_dtype = SI_F32 (si_infer_setup): X rounded once, W_swa + P z formed in fp64 and rounded once per "
+                            "transition, activations fp32, narrow head + SSE in fp64; the SAME %d transitions on the same Philox "
+                            "stream as `value`; `value` / `dtype` stay the fp64 chain" % args.steps,
+                    "step_frac_of_fp32_peak": step_flops / (ms_step32 * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                    "accept_rate": float(acc32[0]), "accept_rate_1000": float(acc32k[0]),
+                    "first_transition_of_1000_where_the_chain_leaves_the_f64_chain": f32_first_diff,
+                    "max_lp_rel_diff_vs_f64_chain_while_identical": f32_lp_rel,
+                    "tolerance_stated": "lp rtol 1e-5 vs the fp64 oracle in tests/test_gpu_f32.py (north_star: 1e-4)"},
             "device": ctx.device_name(),
             "next_rows": extras,
         }

@@ -231,7 +231,36 @@ __device__ __forceinline__ void dense_f32_dma_body(const float* __restrict__ W, 
         const float v = acc[a][b][r] + bv[a];
         acc[a][b][r] = act == SI_ACT_RELU ? (v > 0.0f ? v : 0.0f) : act == SI_ACT_IDENTITY ? v : apply_act_f32(v, act);
       }
-  if (!FUSE || Hout != nullptr) {
+  if constexpr (!FUSE) {
+    // Store.  A lane holds D[b = (r&3) + 8*(r>>2) + 4h][i = c]: stored directly that is one 4-byte store per element in 128-byte
+    // runs -- 16*TM*TN store instructions per wave, and on a shallow layer (cfg2's first: 8 k tiles) the store ISSUE is a
+    // large part of the kernel.  Instead every wave transposes 8 batch rows at a time (the four registers 4g .. 4g+3 of both
+    // halves) through its own slice of the now idle staging LDS and writes 16 bytes per lane, consecutive lanes on
+    // consecutive features: a store instruction covers whole 384-byte rows of the wave's sub-tile (4x fewer instructions).
+    constexpr int WI = BM / WM;                     // features per wave
+    constexpr int NCH = 8 * WI / 4 / 64;            // 16-byte chunks per lane per 8-row block  (= TM)
+    static_assert(NWAVES * 8 * WI <= NB * STAGE, "transposition scratch");
+    __syncthreads();                                // every wave is done with the last k tile's fragments
+    float* reg = smem + wave * (8 * WI);            // wave-private: no further workgroup barrier (LDS is in-order per wave)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) reg[(r + 4 * h) * WI + 32 * a + c] = acc[a][b][4 * g + r];
+#pragma unroll
+        for (int p = 0; p < NCH; ++p) {
+          const int chunk = p * 64 + lane;
+          const int row = chunk / (WI / 4), col4 = chunk % (WI / 4);
+          const f4v v = *reinterpret_cast<const f4v*>(reg + row * WI + 4 * col4);
+          const int gf = iw0 + 4 * col4;
+          const int64_t gb = bw0 + 32 * b + 8 * g + row;
+          if (gf < out && gb < B) *reinterpret_cast<f4v*>(Hout + gf + (int64_t)out * gb) = v;   // out % 4 == 0: all four or none
+        }
+      }
+  } else if (Hout != nullptr) {   // (the gradient / training forward keeps this layer's output: plain stores)
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -367,9 +396,9 @@ static void launch_f32_generic(hipStream_t st, const float* W, const float* bias
 #ifndef SI_GEMM_F32_NO_DISPATCH
 // the LDS-DMA kernel needs whole 16-deep k tiles and 16-byte pieces: in % 16 == 0, out % 4 == 0, aligned bases and slot strides
 static bool f32_fast_shape(int32_t out, int32_t in) { return in >= 16 && in % 16 == 0 && out >= 4 && out % 4 == 0; }
-static bool f32_fast_ok(const float* W, const float* Hin, int32_t out, int32_t in, const ChainBatch& cb) {
+static bool f32_fast_ok(const float* W, const float* Hin, const float* Hout, int32_t out, int32_t in, const ChainBatch& cb) {
   return f32_fast_shape(out, in) && (reinterpret_cast<uintptr_t>(W) & 15u) == 0 && (reinterpret_cast<uintptr_t>(Hin) & 15u) == 0 &&
-         ((cb.w | cb.hin) & 3) == 0;
+         (reinterpret_cast<uintptr_t>(Hout) & 15u) == 0 && ((cb.w | cb.hin | cb.hout) & 3) == 0;
 }
 // feature tile of the fast kernel: the one that pads `out` least (960 = 5 x 192; 6656 = 52 x 128)
 static int f32_pick_bm(int32_t out) {
@@ -380,7 +409,7 @@ static int f32_pick_bm(int32_t out) {
 template <bool FUSE>
 static void launch_f32_any(hipStream_t st, const float* W, const float* bias, const float* Hin, float* Hout, int32_t out, int32_t in,
                            int64_t B, int32_t act, const FuseArgsF32& fa) {
-  if (!f32_fast_ok(W, Hin, out, in, fa.cb)) {
+  if (!f32_fast_ok(W, Hin, Hout, out, in, fa.cb)) {
     launch_f32_generic<FUSE>(st, W, bias, Hin, Hout, out, in, B, act, fa);
     return;
   }

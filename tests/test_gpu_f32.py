@@ -94,3 +94,56 @@ def test_f32_rwmh_chain_follows_the_f64_chain_on_a_small_model(si, gpu_ctx):
     # the streamed output map delivers the fp64 W_swa + P z in either mode
     zs, lps, accs, ws = gpu_ctx.sample_rwmh_weights(12, 0.05, seed=3)
     assert np.allclose(ws[:, :, 0], w[:, None] + p @ zs[:, :, 0], rtol=1e-13, atol=1e-15)
+
+
+def test_f32_accept_decisions_at_cfg2(si, capsys):
+    """BASELINE cfg2 at full size (N = 1 047 361, B = 100 000, M = 20, lp ~ -1.5e5): how many accept decisions of a
+    1000-transition chain change when the density is evaluated in fp32?  The fp32 context is made to FOLLOW the fp64 chain
+    (both are driven step-wise, both accept with the fp64 sum of squared errors) while its own evaluations are recorded;
+    the decision each precision would take at every transition is then recomputed on the host from the library's Philox
+    stream (oracle/philox.py, test infrastructure).  The rounding errors of ~1e5 squared residuals average out: the
+    measured |lp32 - lp64| is a few 1e-5 ABSOLUTE on lp ~ -1.5e5 (rtol ~ 3e-10), so a flip needs |lp' - lp + Exp(1)|
+    below that -- none in 1000 transitions here; the assertion allows a handful."""
+    from oracle import philox
+    from subspaceinference_jl_amd import _capi
+    dims, acts, b, m, itr, sigma_z, seed = [128, 960, 960, 1], [1, 1, 0], 100000, 20, 1000, 0.1, 100
+    table, n = so.layer_table(dims, acts)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((dims[0], b))
+    y = rng.standard_normal((1, b))
+    w = np.concatenate([np.concatenate([(rng.uniform(-1, 1, (fo, fi)) * np.sqrt(6.0 / (fi + fo))).reshape(-1, order="F"), np.zeros(fo)])
+                        for fi, fo in zip(dims[:-1], dims[1:])])
+    p = 0.01 * rng.standard_normal((n, m))
+    d = float(b)
+    with si.Context(0) as c64, si.Context(0) as c32:
+        c64.infer_setup(table, n, m, w, p, x, y, 1.0, compute_dtype=_capi.SI_F64)
+        c32.infer_setup(table, n, m, w, p, x, y, 1.0, compute_dtype=_capi.SI_F32)
+        c64.rwmh_begin(itr, sigma_z, seed)
+        c32.rwmh_begin(itr, sigma_z, seed)
+        cur64 = cur32 = -np.inf
+        flips, max_abs, acc = 0, 0.0, 0
+        for t in range(itr):
+            s64 = c64.rwmh_step_eval()
+            s32 = c32.rwmh_step_eval()
+            c64.rwmh_step_accept(s64)
+            c32.rwmh_step_accept(s64)            # the fp32 context follows the fp64 chain's states
+            lp64, lp32 = so.lp_from_sse(float(s64[0]), d, 1.0), so.lp_from_sse(float(s32[0]), d, 1.0)
+            max_abs = max(max_abs, abs(lp64 - lp32))
+            if t == 0:
+                a64 = a32 = True
+            else:
+                e = philox.randexp(seed, 0, t)
+                a64, a32 = (-e < lp64 - cur64), (-e < lp32 - cur32)
+            flips += int(a64 != a32)
+            if a64:
+                cur64, cur32 = lp64, lp32
+                acc += int(t > 0)
+        z64, lps64, acc64 = c64.rwmh_end()
+        z32, lps32, acc32 = c32.rwmh_end()
+    assert np.array_equal(z64, z32)                                    # it did follow
+    assert abs(acc64[0] - acc / (itr - 1)) < 1e-12                       # the host recomputation of the decisions is the library's
+    with capsys.disabled():
+        print("\n[f32 accept decisions, cfg2, %d transitions] accepted %d; decisions that differ fp32 vs fp64: %d; "
+              "max |lp32 - lp64| = %.3e on lp ~ %.4e (rtol %.2e)" % (itr, acc, flips, max_abs, cur64, max_abs / abs(cur64)))
+    assert max_abs <= 1e-5 * abs(cur64)
+    assert flips <= 5

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box (run through gpurun from the repository root):
 #   kernel-trace statistics of bench.py and of the cfg4 CNN bench, PMC passes for the dominant kernels (separate passes,
-#   --kernel-trace only, as gpurun requires), the bench lines of every mode.  Everything lands in gpurun_out/${ROUND:-r3}prof/;
+#   --kernel-trace only, as gpurun requires), the bench lines of every mode.  Everything lands in gpurun_out/${ROUND:-r4}prof/;
 #   the summaries worth judging are copied into profiles/ by hand.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/${ROUND:-r3}prof
+O=$R/gpurun_out/${ROUND:-r4}prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 echo "[1] bench.py under rocprofv3 --kernel-trace --stats"
@@ -18,6 +18,8 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$tag -o p -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pmc_$tag.err
   echo "== --pmc $c" >> $O/pmc_dense_summary.txt
   python3 $R/tools/pmc_summary.py $O/pmc_$tag dense_f64 >> $O/pmc_dense_summary.txt
+  echo "== --pmc $c" >> $O/pmc_dense_f32_summary.txt
+  python3 $R/tools/pmc_summary.py $O/pmc_$tag dense_f32 >> $O/pmc_dense_f32_summary.txt
   echo "== --pmc $c" >> $O/pmc_gram_summary.txt
   python3 $R/tools/pmc_summary.py $O/pmc_$tag gram_ >> $O/pmc_gram_summary.txt
   rm -rf $O/pmc_$tag
