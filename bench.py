@@ -111,6 +111,9 @@ def launch_ranks(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
+    # N processes of the library share this box's CPU quota: each rank's host copy pool gets its share (the library also
+    # shrinks the pool by itself once a rank joins a communicator; the export covers the copies made before that)
+    env.setdefault("SI_HOST_COPY_THREADS", str(max(1, _cpu_budget() // (2 * args.gpus))))
     log("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and ln.rstrip().endswith("}")]
@@ -392,7 +395,8 @@ def run_dry(args, rk, real_stdout):
         rk.dist.barrier()
     if rk.rank == 0:
         emit(real_stdout, {"metric": METRIC, "value": None, "unit": "samples/s", "n_gpus": n, "steps": args.steps,
-                           "warmup": args.warmup, "dry_run": True, "mode": args.mode})
+                           "warmup": args.warmup, "dry_run": True, "mode": args.mode,
+                           "host_copy_threads_env": os.environ.get("SI_HOST_COPY_THREADS"), "cpu_budget": _cpu_budget()})
     rk.finish()
 
 

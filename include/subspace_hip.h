@@ -42,7 +42,7 @@ enum {
   SI_ERR_COMM = -7      /* RCCL error / RCCL not loadable, message has the detail */
 };
 
-enum { SI_F32 = 0, SI_F64 = 1 };                                  /* dtype of a weight snapshot */
+enum { SI_F32 = 0, SI_F64 = 1 };                 /* dtype of a weight snapshot; compute_dtype of si_infer_setup */
 /* Flux 0.11.2 / NNlib 0.7.23 definitions [upstream]: leakyrelu(x) = max(0.01 x, x); elu(x) = x >= 0 ? x : exp(x) - 1;
  * softplus(x) = log(1 + exp(x)); selu(x) = 1.0507009873554805 * (x > 0 ? x : 1.6732632423543772 * (exp(x) - 1)).
  * (gelu / swish are not monotone: their derivative cannot be rebuilt from the stored output, so they are not offered.) */
@@ -101,7 +101,7 @@ typedef struct {
   double bytes[SI_K_COUNT];     /* accumulated ALGORITHMIC HBM bytes per class                 */
 } si_stats;
 
-int32_t si_version(void); /* 300: + the RCCL communicator (si_comm_*), streamed output map, pipelined host push */
+int32_t si_version(void); /* 400: + compute_dtype = SI_F32 (300: RCCL communicator, streamed output map, pipelined host push) */
 
 /* ---- context ------------------------------------------------------------------------------- */
 int32_t si_create(si_ctx** out, int32_t device_id);
@@ -188,7 +188,17 @@ int32_t si_construct_get_A(si_ctx* ctx, int64_t k0, int64_t nk, double* A_out);
 /* ---- density + sampling: replaces src/space_inference.jl:88-95,111-116,125 ------------------- */
 /* :88 split_data (full X, Y), :90-95 density closure.  W_swa / P may both be NULL: the result of the
  * ctx's finished construction is used in place (no host round trip).  X is in_dim x B, Y is out_dim x B,
- * column-major fp64.  compute_dtype: SI_F64 (the reference's arithmetic; the only one implemented).   */
+ * column-major fp64.
+ * compute_dtype: SI_F64 = the reference's arithmetic (src/subspace_construction.jl:31,33 and README.md:56-57 make W_swa, P,
+ *   the data and therefore the whole density Float64 -- SURVEY section 0, Q6).
+ * SI_F32 (Dense chains; Conv chains are refused) = the measured fp32 option of SURVEY section 0 Q6 / 8(b),(d): X is rounded to
+ *   fp32 once, W_swa + P*z is formed in fp64 and rounded to fp32 once per evaluation, every Dense layer multiplies and
+ *   accumulates in fp32 (v_mfma_f32_32x32x2_f32) with fp32 activations; a narrow last layer (out <= 4), its bias /
+ *   activation and the sum of squared errors are fp64.  It applies to si_logdensity, si_forward and the RWMH samplers
+ *   (si_sample_rwmh*, si_rwmh_*); si_logdensity_grad and si_predict keep computing in fp64, and the output map
+ *   (si_sample_rwmh_weights, si_reconstruct) delivers the fp64 W_swa + P*z.  Stated tolerance (tests/test_gpu_f32.py,
+ *   against the fp64 oracle): model outputs 2e-5 of their scale, lp rtol 1e-5 (north_star: 1e-4); at BASELINE cfg2 the
+ *   measured lp difference is rtol 2e-9 and none of 1000 accept decisions changes.                                       */
 int32_t si_infer_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, int32_t M,
                        const double* W_swa, const double* P, const double* X, const double* Y,
                        int32_t in_dim, int32_t out_dim, int64_t B, double sigma_m,
@@ -351,6 +361,14 @@ int si_host_sym_eig_top(int n, const double* g, int m, double* w_top, double* V)
  * |a_pq| <= eps*sqrt(a_pp*a_qq) for a symmetric positive semi-definite matrix (eigenvalues accurate relative to
  * themselves for graded matrices).  a: n x n column-major, destroyed; w: eigenvalues DESCENDING; v: eigenvectors.   */
 int si_host_jacobi_eig_psd(int n, double* a, double* w, double* v);
+/* The host copy pool (si_construct_push, si_reconstruct, si_sample_rwmh_weights) sizes itself from the CPUs the process may
+ * really use: the affinity mask capped by the cgroup CPU quota (si_host_cpu_budget; a container that shows 256 CPUs and
+ * grants 16 gets 16).  Threads per process = SI_HOST_COPY_THREADS if set, else min(8, budget / (2 * nproc)) with nproc = the
+ * world of the ctx's communicator (si_comm_init_rank shrinks the pool: 8 ranks on a 16-CPU quota copy with one thread each).
+ * si_host_parse_cpu_max: "<quota> <period>" of a cgroup-v2 cpu.max file -> CPUs granted (0 = unlimited / unparsable).    */
+int si_host_cpu_budget(void);
+double si_host_parse_cpu_max(const char* text);
+int si_host_copy_plan(int budget, int nproc, const char* env /* value of SI_HOST_COPY_THREADS or NULL */);
 
 #ifdef __cplusplus
 }

@@ -129,6 +129,9 @@ SIGNATURES = {
     "si_host_sym_eig": (c_int, [c_int, c_void_p, c_void_p]),
     "si_host_sym_eig_top": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "si_host_jacobi_eig_psd": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
+    "si_host_cpu_budget": (c_int, []),
+    "si_host_parse_cpu_max": (c_double, [c_char_p]),
+    "si_host_copy_plan": (c_int, [c_int, c_int, c_char_p]),
 }
 
 _lib = None

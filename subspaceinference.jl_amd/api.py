@@ -13,7 +13,7 @@ Python identifiers may be Greek, so `σ_z=` works as in Julia; `sigma_z=` is acc
 """
 import numpy as np
 
-from . import dist, flux, samplers
+from . import _capi, dist, flux, samplers
 from ._capi import Context, SubspaceError
 
 _RWMH_ALGS = ("rwmh", "mh")
@@ -117,7 +117,7 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
 
 def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=100, M=3, alg="rwmh",
                   backend="forwarddiff", *, sigma_z=None, sigma_m=None, sigma_p=None, device=0, ctx=None,
-                  seed=0, chain_id=0, return_z=False, nchains=1, include_prior=False):
+                  seed=0, chain_id=0, return_z=False, nchains=1, include_prior=False, compute_dtype="f64"):
     """src/space_inference.jl:82-164 for a Chain model and alg = :rwmh.
 
     `density(z)` (:90-95: W_swa + P*z -> model_re -> forward over the FULL data -> Gaussian log-likelihood,
@@ -129,6 +129,11 @@ def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=10
     `nchains > 1` (RWMH only; not in the reference, which runs one chain per call) runs the independent chains
     chain_id .. chain_id+nchains-1 stacked in every launch of the forward pass: chn becomes a list over chains
     (or the M x itr x nchains array with return_z) and lp is itr x nchains.
+
+    `compute_dtype="f32"` (non-default; SURVEY section 0 Q6: "forward fp64 with fp32 as a measured option") evaluates the
+    density of a Dense chain on the fp32 matrix instruction: X rounded once, W_swa + P*z formed in fp64 and rounded once per
+    transition, fp32 activations, head + sum of squared errors in fp64 (lp within 1e-5 of the fp64 value, tests/test_gpu_f32.py).
+    The gradient samplers (:mala / :hmc / :nuts) keep the fp64 reverse sweep either way.
     """
     σ_z = σ_z if sigma_z is None else sigma_z
     σ_m = σ_m if sigma_m is None else sigma_m
@@ -142,17 +147,20 @@ def sub_inference(in_model, data, W_swa, P, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=10
         raise SubspaceError("Error: density function is not avaliable for this model")  # [sic] reference :103
     x, y, in_size = flux.data_matrices(data)  # split_data, src/libs.jl:75-77 (full data, not the batches)
     table, n_par = flux.layer_table(in_model, in_size)
+    if compute_dtype not in ("f64", "f32"):
+        raise SubspaceError("compute_dtype must be \"f64\" (the reference's arithmetic) or \"f32\"")
+    cdt = _capi.SI_F32 if compute_dtype == "f32" else _capi.SI_F64
     ctx, own = _get_ctx(ctx, device)
     try:
         if W_swa is None:
-            ctx.infer_setup(table, n_par, M, None, None, x, y, σ_m)
+            ctx.infer_setup(table, n_par, M, None, None, x, y, σ_m, compute_dtype=cdt)
         else:
             W_swa = np.asarray(W_swa, dtype=np.float64)
             P = np.asarray(P, dtype=np.float64)
             if P.shape[1] != M:
                 # reference: MvNormal(zeros(M), σ_z) proposal against an N x size(P,2) matrix -> DimensionMismatch in P*z
                 raise SubspaceError("DimensionMismatch: P has %d columns but M = %d" % (P.shape[1], M))
-            ctx.infer_setup(table, n_par, M, W_swa, P, x, y, σ_m)
+            ctx.infer_setup(table, n_par, M, W_swa, P, x, y, σ_m, compute_dtype=cdt)
         # include_prior=True adds the term the reference leaves dead after its `return` (quirk Q4); default: as the reference
         ctx.set_prior(σ_p if include_prior else 0.0)
         if nchains != 1 and a not in _RWMH_ALGS:
@@ -189,7 +197,8 @@ def inference(*args, **kwargs):
 
 def subspace_inference(model, cost, data, opt, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr=1000, T=25, c=1, M=20,
                        print_freq=1, alg="rwmh", backend="forwarddiff", method="subspace", *, sigma_z=None,
-                       sigma_m=None, sigma_p=None, device=0, ctx=None, seed=0, verbose=True, return_z=False):
+                       sigma_m=None, sigma_p=None, device=0, ctx=None, seed=0, verbose=True, return_z=False,
+                       compute_dtype="f64"):
     """src/space_inference.jl:33-54: construction, then sampling; returns (chn, lp, W_swa).
     W_swa and P stay on the device between the two stages (no host round trip)."""
     m = _alg_name(method)
@@ -206,7 +215,7 @@ def subspace_inference(model, cost, data, opt, σ_z=1.0, σ_m=1.0, σ_p=1.0, itr
                                          verbose=verbose, keep_on_device=True)
         chn, lp = sub_inference(model, data, None, None, σ_z=σ_z, σ_m=σ_m, σ_p=σ_p, itr=itr, M=M, alg=alg,
                                 backend=backend, sigma_z=sigma_z, sigma_m=sigma_m, ctx=ctx, seed=seed,
-                                return_z=return_z)
+                                return_z=return_z, compute_dtype=compute_dtype)
         return chn, lp, w_swa
     finally:
         if own:

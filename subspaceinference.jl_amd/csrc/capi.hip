@@ -235,7 +235,7 @@ static void free_wstream(si_ctx* ctx);
 
 extern "C" {
 
-int32_t si_version(void) { return 300; }
+int32_t si_version(void) { return 400; }
 
 const char* si_last_error(si_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 

@@ -102,6 +102,9 @@ void comm_release(Ctx* c) {
   c->comm_rank = 0;
   if (c->d_commtmp) (void)hipFree(c->d_commtmp);
   c->d_commtmp = nullptr;
+  if (c->d_gathertmp) (void)hipFree(c->d_gathertmp);
+  c->d_gathertmp = nullptr;
+  c->gathertmp_cap = 0;
 }
 
 static int32_t need_comm(Ctx* c, const char* who) {
@@ -143,6 +146,9 @@ int32_t si_comm_init_rank(si_ctx* ctx, int32_t world, int32_t rank, const uint8_
   ctx->comm = comm;
   ctx->comm_world = world;
   ctx->comm_rank = rank;
+  // `world` processes of the library now share this host's CPUs (one node, one process per GPU): the host copy pool of
+  // this process keeps to its share of the CPU quota (8 ranks on a 16-CPU quota: one copy thread each, not eight)
+  host_copy_set_share(world);
   if (hipMalloc(reinterpret_cast<void**>(&ctx->d_commtmp), COMM_TMP_ELEMS * sizeof(double)) != hipSuccess) {
     comm_release(ctx);
     return fail(ctx, SI_ERR_NOMEM, "si_comm_init_rank: scratch allocation failed");
@@ -209,16 +215,23 @@ int32_t si_comm_allgather_host(si_ctx* ctx, const double* send, int64_t n, doubl
   if (!send || !recv || n <= 0) return fail(ctx, SI_ERR_INVALID, "si_comm_allgather_host: bad argument");
   SI_HIP(ctx, hipSetDevice(ctx->device));
   const size_t W = (size_t)ctx->comm_world;
-  double* tmp = nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&tmp), (W + 1) * (size_t)n * sizeof(double)) != hipSuccess)
-    return fail(ctx, SI_ERR_NOMEM, "si_comm_allgather_host: allocation failed");
+  const size_t need = (W + 1) * (size_t)n;
+  if (ctx->gathertmp_cap < need) {   // scratch kept between calls (the chains' (Z, lp) gathers repeat with the same size)
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_gathertmp) (void)hipFree(ctx->d_gathertmp);
+    ctx->d_gathertmp = nullptr;
+    ctx->gathertmp_cap = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->d_gathertmp), need * sizeof(double)) != hipSuccess)
+      return fail(ctx, SI_ERR_NOMEM, "si_comm_allgather_host: allocation failed");
+    ctx->gathertmp_cap = need;
+  }
+  double* tmp = ctx->d_gathertmp;
   hipError_t e = hipMemcpyAsync(tmp + W * (size_t)n, send, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   ncclResult_t nr = ncclSuccess;
   if (e == hipSuccess) nr = rccl().AllGather(tmp + W * (size_t)n, tmp, (size_t)n, ncclFloat64, comm_of(ctx), ctx->stream);
   if (e == hipSuccess && nr == ncclSuccess)
     e = hipMemcpyAsync(recv, tmp, W * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
   const hipError_t e2 = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(tmp);
   if (nr != ncclSuccess) return fail(ctx, SI_ERR_COMM, std::string("si_comm_allgather_host: ncclAllGather: ") + rccl().GetErrorString(nr));
   if (e != hipSuccess || e2 != hipSuccess)
     return fail(ctx, SI_ERR_HIP, std::string("si_comm_allgather_host: ") + hipGetErrorString(e != hipSuccess ? e : e2));

@@ -103,6 +103,10 @@ int jacobi_eig_psd(int n, double* a, double* w, double* v) {
 
 extern "C" int si_host_jacobi_eig_psd(int n, double* a, double* w, double* v) { return si::jacobi_eig_psd(n, a, w, v); }
 extern "C" int si_host_sym_eig(int n, double* a, double* w) { return si::sym_eig(n, a, w); }
+// host copy pool sizing (host_copy.cpp), exported for the CPU tests
+extern "C" int si_host_cpu_budget(void) { return si::host_cpu_budget(); }
+extern "C" double si_host_parse_cpu_max(const char* text) { return si::parse_cpu_max(text); }
+extern "C" int si_host_copy_plan(int budget, int nproc, const char* env) { return si::host_copy_plan(budget, nproc, env); }
 extern "C" int si_host_sym_eig_top(int n, const double* g, int m, double* w_top, double* V) {
   return si::sym_eig_top(n, g, m, w_top, V);
 }

@@ -97,6 +97,8 @@ struct Ctx {
   void* comm = nullptr;
   int comm_world = 0, comm_rank = 0;
   double* d_commtmp = nullptr;  // device scratch of the host-value collectives
+  double* d_gathertmp = nullptr;  // device scratch of si_comm_allgather_host, kept between calls
+  size_t gathertmp_cap = 0;
 
   // development build only (-DSI_DEV_KNOBS, SI_OVERLAP_HALVES=1): the two halves of the batch of ONE chain on two streams
   bool overlap_halves = false;
@@ -439,6 +441,10 @@ void launch_widen_f32(hipStream_t st, const float* src, double* dst, int64_t n, 
 // host copy pool (host_copy.cpp): parallel memcpy between pageable caller arrays and pinned staging
 void host_copy(void* dst, const void* src, size_t bytes);
 int host_copy_threads();
+void host_copy_set_share(int nproc);   // `nproc` processes of the library share this host (one per GPU): shrink the pool's share
+int host_cpu_budget();                 // affinity mask capped by the cgroup CPU quota
+double parse_cpu_max(const char* text);
+int host_copy_plan(int budget, int nproc, const char* env);
 
 // host symmetric eigensolver (eig.cpp): a is n x n symmetric col-major, overwritten by eigenvectors
 // (columns), w gets eigenvalues ascending.  Returns 0 on success.

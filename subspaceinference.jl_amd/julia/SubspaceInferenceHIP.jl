@@ -298,11 +298,15 @@ function reconstruct(ctx::Ctx, Z::Matrix{Float64}, N)
 end
 
 # include_prior = true adds the term the reference writes after its `return` (dead code, :95); default: as the reference
+# compute_dtype = :f32 (non-default; SURVEY section 0 Q6): the density of a Dense chain on the fp32 matrix instruction -- X rounded
+# once, W_swa + P*z formed in Float64 and rounded once per transition, Float32 activations, head + sum of squared errors in Float64
 function sub_inference(in_model, data, W_swa, P; σ_z = 1.0, σ_m = 1.0, σ_p = 1.0, itr = 100, M = 3, alg = :rwmh,
-                       backend = :forwarddiff, device = 0, ctx = Ctx(device), seed = 0, chain_id = 0, include_prior = false)
+                       backend = :forwarddiff, device = 0, ctx = Ctx(device), seed = 0, chain_id = 0, include_prior = false,
+                       compute_dtype = :f64)
     alg == :mh && (alg = :rwmh)                                     # README.md:153-154
     alg in (:rwmh, :mala, :hmc, :nuts) || throw("$alg is not available")       # :162 (:advi is outside this build)
     in_model isa Chain || throw("Error: density function is not avaliable for this model")
+    compute_dtype in (:f64, :f32) || throw("compute_dtype must be :f64 (the reference's arithmetic) or :f32")
     X, Y, insize = data_matrices(data)                              # split_data (src/libs.jl:75-77)
     tbl, N = layer_table(in_model, insize)
     Wp = W_swa === nothing ? C_NULL : pointer(W_swa)
@@ -310,7 +314,7 @@ function sub_inference(in_model, data, W_swa, P; σ_z = 1.0, σ_m = 1.0, σ_p = 
     GC.@preserve tbl W_swa P X Y check(ctx, ccall((:si_infer_setup, LIB), Int32,
         (Ptr{Cvoid}, Ptr{SiLayer}, Int32, Int64, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
          Int32, Int32, Int64, Float64, Int32),
-        ctx.h, tbl, length(tbl), N, M, Wp, Pp, X, Y, size(X, 1), size(Y, 1), size(X, 2), σ_m, SI_F64))
+        ctx.h, tbl, length(tbl), N, M, Wp, Pp, X, Y, size(X, 1), size(Y, 1), size(X, 2), σ_m, compute_dtype == :f32 ? SI_F32 : SI_F64))
     check(ctx, ccall((:si_infer_set_prior, LIB), Int32, (Ptr{Cvoid}, Float64), ctx.h, include_prior ? Float64(σ_p) : 0.0))
     if alg == :rwmh
         # :111-116 on the device: chain state, proposals (Philox) and accept decisions never leave the GPU
@@ -425,8 +429,12 @@ One GPU per Distributed worker: worker `ws[r]` creates its `Ctx(r - 1)` and join
 function init_gpus(ws::Vector{Int} = workers())
     id = comm_unique_id()                                   # needs no GPU; travels to the workers by remotecall
     world = length(ws)
+    # `world` processes share this host's CPU quota: each worker's host copy pool gets its share before its first copy
+    # (the library also shrinks the pool by itself in si_comm_init_rank; SI_HOST_COPY_THREADS set by the user wins)
+    share = max(1, ccall((:si_host_cpu_budget, LIB), Cint, ()) ÷ (2 * world))
     @sync for (r, w) in enumerate(ws)
         @async remotecall_wait(w, id, world, r - 1) do id, world, rank
+            haskey(ENV, "SI_HOST_COPY_THREADS") || (ENV["SI_HOST_COPY_THREADS"] = string(share))
             ctx = Ctx(rank)
             comm_init!(ctx, world, rank, id)
             RANK_CTX[] = ctx

@@ -26,6 +26,8 @@ def test_launcher_starts_n_ranks_and_relays_one_line():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["dry_run"] is True
+    # every rank's host copy pool is told its share of the CPU quota: budget // (2 * ranks), at least one thread
+    assert out["host_copy_threads_env"] == str(max(1, out["cpu_budget"] // 4))
 
 
 @pytest.mark.timeout(300)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(si):
         assert hasattr(lib, s), "libsubspace_hip.so does not export %s" % s
     # and the ctypes table binds exactly the declared ABI
     assert sorted(si._capi.SIGNATURES) == syms
-    assert lib.si_version() == 300
+    assert lib.si_version() == 400
 
 
 def test_no_cpu_fallback(si):
@@ -294,3 +294,27 @@ def test_hmc_acceptance_ratio_does_not_overflow():
     for fn in (samplers.hmc, samplers.nuts, samplers.mala):
         zs, lps = fn(sharp, 2, 6, 0.05, np.random.default_rng(0))[:2]
         assert np.all(np.isfinite(np.asarray(lps, dtype=np.float64)))
+
+
+def test_host_copy_pool_respects_the_cpu_quota():
+    """the pool was sized from the affinity mask alone (8 threads per process on a box that shows 256 CPUs and
+    grants 16: 64 spinning threads at --gpus 8).  Now: affinity capped by the cgroup quota, divided by the ranks sharing the host."""
+    import ctypes
+    import subspaceinference_jl_amd as si
+    lib = si.load()
+    parse = lib.si_host_parse_cpu_max
+    assert parse(b"1600000 100000\n") == 16.0 and parse(b"max 100000") == 0.0 and parse(b"250000 100000") == 2.5
+    assert parse(b"garbage") == 0.0 and parse(None) == 0.0
+    plan = lib.si_host_copy_plan
+    assert plan(16, 1, None) == 8 and plan(16, 8, None) == 1 and plan(16, 2, None) == 4 and plan(256, 1, None) == 8
+    assert plan(2, 1, None) == 1 and plan(16, 8, b"3") == 3 and plan(16, 1, b"0") == 1
+    # this process: the same number bench.py / conftest compute in Python
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    assert lib.si_host_cpu_budget() == n
+    assert isinstance(ctypes.c_int(lib.si_host_cpu_budget()).value, int)

@@ -147,3 +147,20 @@ def test_f32_accept_decisions_at_cfg2(si, capsys):
               "max |lp32 - lp64| = %.3e on lp ~ %.4e (rtol %.2e)" % (itr, acc, flips, max_abs, cur64, max_abs / abs(cur64)))
     assert max_abs <= 1e-5 * abs(cur64)
     assert flips <= 5
+
+
+def test_f32_through_the_api_mirror(si):
+    """sub_inference(...; compute_dtype = "f32") -- the reference's call with the non-default precision option"""
+    from subspaceinference_jl_amd import flux
+    rng = np.random.default_rng(5)
+    x, y = rng.random((16, 200)), rng.random((1, 200))
+    mdl = flux.Chain(flux.Dense(16, 64, flux.relu, rng=rng), flux.Dense(64, 32, flux.relu, rng=rng), flux.Dense(32, 1, rng=rng))
+    data = flux.DataLoader(x, y, batchsize=50)
+    table, n = flux.layer_table(mdl, None)
+    w = rng.standard_normal(n) * 0.3
+    p = 0.05 * rng.standard_normal((n, 4))
+    z64, lp64 = si.sub_inference(mdl, data, w, p, σ_z=0.1, itr=50, M=4, seed=9, return_z=True)
+    z32, lp32 = si.sub_inference(mdl, data, w, p, σ_z=0.1, itr=50, M=4, seed=9, return_z=True, compute_dtype="f32")
+    assert np.array_equal(z64, z32) and np.allclose(lp32, lp64, rtol=1e-5)
+    with pytest.raises(si.SubspaceError):
+        si.sub_inference(mdl, data, w, p, itr=5, M=4, compute_dtype="bf16")

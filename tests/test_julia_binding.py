@@ -31,7 +31,7 @@ COMPAT = {
     "char*": {"Ptr{UInt8}", "Cstring"},
     "uint8_t*": {"Ptr{UInt8}"},
 }
-RET = {"int32_t": {"Int32", "Cint"}, "int": {"Cint", "Int32"}, "const char*": {"Cstring", "Ptr{UInt8}"}}
+RET = {"int32_t": {"Int32", "Cint"}, "int": {"Cint", "Int32"}, "const char*": {"Cstring", "Ptr{UInt8}"}, "double": {"Float64", "Cdouble"}}
 
 
 def _strip_comments(text):
@@ -41,7 +41,7 @@ def _strip_comments(text):
 def header_prototypes():
     text = _strip_comments(open(HEADER).read())
     protos = {}
-    for m in re.finditer(r"\b(int32_t|int|const char\s*\*)\s+(si_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(int32_t|int|double|const char\s*\*)\s+(si_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         ret = re.sub(r"\s+", " ", m.group(1)).replace(" *", "*")
         args = []
         raw = m.group(3).strip()
@@ -106,7 +106,7 @@ def test_the_wrapper_binds_the_whole_single_process_path():
     unbound = set(header_prototypes()) - bound
     for name in unbound:
         assert re.search(r"_dev$|_ptr$|gram_get|gram_set|rwmh_|train_grad|train_apply|allreduce_grad|profiling|stats|stream|synchronize|"
-                         r"version|device_name|get_A|host_sym_eig|host_jacobi|si_forward|push_batch|si_sample_rwmh$", name), "unbound without a reason: " + name
+                         r"version|device_name|get_A|host_sym_eig|host_jacobi|host_copy_plan|host_parse_cpu_max|si_forward|push_batch|si_sample_rwmh$", name), "unbound without a reason: " + name
     jl = open(JL).read()
     assert "function init_gpus" in jl and "ngpu = 1, nchains = ngpu" in jl and "remotecall" in jl
 
