@@ -259,6 +259,11 @@ int32_t si_rwmh_end(si_ctx* ctx, double* Z_out, double* lp_out, double* accept_r
 /* drop an open session.  While a session is open, si_logdensity / _grad / si_forward / si_predict / si_sample_rwmh
  * return SI_ERR_STATE (they share the session's proposal and SSE buffers); si_rwmh_begin restarts it.              */
 int32_t si_rwmh_abort(si_ctx* ctx);
+/* K6 as a DEVICE-RESIDENT loop: for small Dense chains (weights, data and activations of a chain fit one
+ * workgroup's LDS, 2*N*B <= 3 MFLOP -- the reference's own README / docs sizes) si_sample_rwmh runs all `itr` transitions of
+ * all chains in ONE launch, one workgroup per chain, instead of ~8 launches per transition; results are bit-identical to the
+ * launch-per-step loop.  on = 0 forces the launch-per-step loop (the parity tests compare the two); default on.           */
+int32_t si_set_chain_loop(si_ctx* ctx, int32_t on);
 /* :91 / :125  W_out[:, c] = W_swa + P * Z[:, c]   (N x C col-major).  Pipelined: K4 -> pinned staging (second stream) ->
  * host threads (SI_HOST_COPY_THREADS, default min(8, cpus / 2)) copy into W_out, which may be pageable and untouched.  */
 int32_t si_reconstruct(si_ctx* ctx, const double* Z /* M x C */, int64_t C, double* W_out);

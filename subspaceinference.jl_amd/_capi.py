@@ -129,6 +129,7 @@ SIGNATURES = {
     "si_host_sym_eig": (c_int, [c_int, c_void_p, c_void_p]),
     "si_host_sym_eig_top": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "si_host_jacobi_eig_psd": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
+    "si_set_chain_loop": (c_int32, [c_void_p, c_int32]),
     "si_host_cpu_budget": (c_int, []),
     "si_host_parse_cpu_max": (c_double, [c_char_p]),
     "si_host_copy_plan": (c_int, [c_int, c_int, c_char_p]),
@@ -581,6 +582,10 @@ class Context:
         self._check(self.lib.si_sample_rwmh_weights(self.h, int(itr), float(sigma_z), int(seed), int(chain_id0), int(nchains),
                                                     _ptr(z), _ptr(lp), _ptr(acc), _ptr(w)))
         return z, lp, acc, w
+
+    def set_chain_loop(self, on):
+        """False: si_sample_rwmh always takes the launch-per-step loop (default: small Dense chains run device-resident)."""
+        self._check(self.lib.si_set_chain_loop(self.h, 1 if on else 0))
 
     def rwmh_begin(self, itr, sigma_z, seed, chain_id0=0, nchains=1, d_total=0):
         self._check(self.lib.si_rwmh_begin(self.h, int(itr), float(sigma_z), int(seed), int(chain_id0), int(nchains),

@@ -20,6 +20,7 @@ SOURCES = [
     ("comm.hip", []),
     ("host_copy.cpp", []),
     ("kernels_stream.hip", ["-ffp-contract=off"]),
+    ("kernels_chain.hip", ["-ffp-contract=off"]),
     ("kernels_gemm.hip", []),
     ("kernels_gemm_f32.hip", []),
     ("kernels_gram.hip", []),

@@ -1636,6 +1636,18 @@ static int32_t ensure_wstream(si_ctx* ctx, int32_t C) {
   return SI_OK;
 }
 
+// the device-resident loop covers: Dense chains in fp64 with the head folded into the layer before it (fuse_tail), the
+// four activations the MFMA epilogues carry, no prior term, and little enough arithmetic that ONE CU per chain beats ~8
+// launches per transition spread over the chip (2 N B <= 3 MFLOP: the README toy is 0.14)
+static constexpr size_t SI_CHAIN_LDS_LIMIT = 160 * 1024 - 256;
+static bool chain_loop_applies(const si_ctx* ctx) {
+  if (ctx->f32 || ctx->plan.has_conv || !ctx->fuse_tail || ctx->sigma_p > 0.0) return false;
+  if (ctx->layers.size() > (size_t)SI_CHAIN_MAX_LAYERS || ctx->iN > (1 << 20) || ctx->B > (1 << 20)) return false;
+  for (const auto& ly : ctx->layers)
+    if (ly.kind != SI_LAYER_DENSE || ly.act >= SI_ACT_LEAKYRELU) return false;
+  return 2.0 * (double)ctx->iN * (double)ctx->B <= 3.0e6;
+}
+
 static int32_t sample_rwmh_impl(si_ctx* ctx, const char* who, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0,
                                 int32_t nchains, double* Z_out, double* lp_out, double* accept_rate_out, double* W_out) {
   CHECK_CTX(ctx);
@@ -1657,6 +1669,41 @@ static int32_t sample_rwmh_impl(si_ctx* ctx, const char* who, int64_t itr, doubl
   }
   const double d = (double)ctx->out_dim * (double)ctx->B;
   const double c0 = mvnormal_c0(d, ctx->sigma_m), s2 = ctx->sigma_m * ctx->sigma_m;
+  // ---- K6 as a device-resident loop (kernels_chain.hip): small Dense chains whose weights, data and activations fit one
+  // workgroup's LDS run ALL transitions in one launch, one workgroup per chain -- the launch-per-step loop below costs ~8
+  // dependent launches (25 us) per transition whatever the size.  Same bits (tests/test_gpu_chain.py).
+  if (!W_out && chain_loop_applies(ctx) && ctx->chain_loop_enabled) {
+    ChainLoopArgs a{};
+    const int L = (int)ctx->layers.size();
+    for (int l = 0; l < L; ++l) a.lay[l] = ctx->layers[(size_t)l];
+    a.swa = ctx->i_swa; a.P = ctx->i_P; a.X = ctx->d_X; a.Y = ctx->d_Y;
+    a.Z_out = dZ; a.lp_out = dlp; a.nacc_out = ctx->d_nacc;
+    a.ldP = ctx->ldP; a.itr = itr; a.seed = seed; a.sigma_z = sigma_z; a.c0 = c0; a.sigma2 = s2;
+    a.N = (int)N; a.M = M; a.B = (int)ctx->B; a.L = L; a.chain_id0 = chain_id0;
+    a.slot_feats = dense_fused_slot_feats(ctx->layers[(size_t)L - 2].out);
+    a.fuse_slots = ctx->fuse_slots;
+    const size_t lds = chain_loop_plan(a, SI_CHAIN_LDS_LIMIT);
+    if (lds != 0) {
+      {
+        const double fl = 2.0 * (double)N * (double)ctx->B * (double)itr * C;
+        ProfScope ps(ctx, SI_K_RWMH, fl, 0.0);
+        launch_chain_loop(ctx->stream, a, C, lds);
+      }
+      hipError_t e = hipGetLastError();
+      std::vector<int64_t> nacc((size_t)C);
+      if (e == hipSuccess && Z_out) e = hipMemcpyAsync(Z_out, dZ, (size_t)M * itr * C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess && lp_out) e = hipMemcpyAsync(lp_out, dlp, (size_t)itr * C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(nacc.data(), ctx->d_nacc, (size_t)C * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+      const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+      dev_free(dZ);
+      dev_free(dlp);
+      if (e != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
+      if (e2 != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e2));
+      if (accept_rate_out)
+        for (int c = 0; c < C; ++c) accept_rate_out[c] = itr > 1 ? (double)nacc[(size_t)c] / (double)(itr - 1) : 0.0;
+      return SI_OK;
+    }
+  }
   {
     ProfScope ps(ctx, SI_K_RWMH, 0, 0);
     launch_rwmh_init(ctx->stream, ctx->d_zcur, ctx->d_lpcur, ctx->d_nacc, ctx->d_steps, M, C);
@@ -1753,6 +1800,12 @@ int32_t si_sample_rwmh_weights(si_ctx* ctx, int64_t itr, double sigma_z, uint64_
 // between evaluation and acceptance, so that a DATA-SHARDED density (each rank holds B/world observations of X, Y and
 // the same W_swa, P) can all-reduce the per-rank partial sums.  Every rank draws the same Philox
 // stream (same seed / chain ids), so all ranks take identical accept decisions and keep identical chains.
+int32_t si_set_chain_loop(si_ctx* ctx, int32_t on) {
+  CHECK_CTX(ctx);
+  ctx->chain_loop_enabled = on != 0;
+  return SI_OK;
+}
+
 int32_t si_rwmh_begin(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0, int32_t nchains,
                       int64_t d_total) {
   CHECK_CTX(ctx);

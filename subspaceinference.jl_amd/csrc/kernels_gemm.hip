@@ -500,6 +500,12 @@ int dense_fused_slots(int32_t out) {
   return (out + bm - 1) / bm * wm;
 }
 
+// features per slot (= per wave of a feature tile): the unit the fused head sums in one fma chain
+int dense_fused_slot_feats(int32_t out) {
+  const int bm = pick_bm(out);
+  return bm == 32 ? 32 : bm / 2;
+}
+
 void launch_dense_f64_fused(hipStream_t st, const double* W, const double* bias, const double* Hin, int32_t out,
                             int32_t in, int64_t B, int32_t act, const double* Wlast, int32_t out_last, double* part,
                             const ChainBatch& cb, double* Hkeep) {

@@ -225,6 +225,7 @@ struct Ctx {
   uint64_t sw_seed = 0;
   int32_t sw_chain0 = 0, sw_C = 0;
   bool sw_evaluated = false;
+  bool chain_loop_enabled = true;   // si_set_chain_loop: 0 forces the launch-per-step loop (the parity tests compare the two)
 };
 
 void free_train(Ctx* c);
@@ -423,6 +424,27 @@ void net_scratch_sizes(const NetPlan& p, int64_t B, int num_cu, size_t* bwpart, 
 // g0 holds d / d(output of the last layer) (out_feat x B) on entry; g0 / g1: max_elems * B doubles each; hs[l]: kept outputs
 int32_t net_backward(Ctx* c, const NetPlan& p, const double* w, const double* xin, int64_t B, double* const* hs, double* g0,
                      double* g1, double* gw, const NetScratch& s);
+// K6, device-resident loop (kernels_chain.hip): all `itr` transitions of `nchains` small Dense chains in ONE launch, one
+// workgroup per chain, weights / data / activations in LDS; bit-identical to the launch-per-step loop of si_sample_rwmh
+constexpr int SI_CHAIN_MAX_LAYERS = 8;
+struct ChainLoopArgs {
+  si_layer lay[SI_CHAIN_MAX_LAYERS];
+  const double *swa, *P, *X, *Y;
+  double *Z_out, *lp_out;
+  int64_t* nacc_out;
+  int64_t ldP, itr;
+  uint64_t seed;
+  double sigma_z, c0, sigma2;
+  int N, M, B, L, chain_id0;
+  int slot_feats, fuse_slots, nblocks;   // head slots of layer L-2 (BM / WM of dense_f64_kernel's choice), SSE virtual blocks
+  int p_in_lds;
+  int o_X, o_Y, o_act0, o_act1, o_part, o_blk, o_z, o_red, o_P, o_swa, o_map;
+  int wp[SI_CHAIN_MAX_LAYERS], bp[SI_CHAIN_MAX_LAYERS];   // padded W / bias image of every layer (chain_loop_plan)
+  long long* dbg_stamps;   // tools/chain_bench.hip (-DSI_CHAIN_STAMPS) only; nullptr in the library   // LDS offsets (doubles), set by chain_loop_plan
+};
+size_t chain_loop_plan(ChainLoopArgs& a, size_t lds_limit);   // LDS bytes, 0 = the model does not fit / does not apply
+void launch_chain_loop(hipStream_t st, const ChainLoopArgs& a, int nchains, size_t lds);
+int dense_fused_slot_feats(int32_t out);   // features per head slot of the fused fp64 layer (kernels_gemm.hip: BM / WM)
 // K6
 void launch_rwmh_init(hipStream_t st, double* zcur, double* lpcur, int64_t* nacc, uint64_t* steps, int32_t M, int32_t C);
 void launch_rwmh_propose(hipStream_t st, const double* zcur, double* zprop, int32_t M, int32_t C,
