@@ -1672,7 +1672,10 @@ static int32_t sample_rwmh_impl(si_ctx* ctx, const char* who, int64_t itr, doubl
   // ---- K6 as a device-resident loop (kernels_chain.hip): small Dense chains whose weights, data and activations fit one
   // workgroup's LDS run ALL transitions in one launch, one workgroup per chain -- the launch-per-step loop below costs ~8
   // dependent launches (25 us) per transition whatever the size.  Same bits (tests/test_gpu_chain.py).
-  if (!W_out && chain_loop_applies(ctx) && ctx->chain_loop_enabled) {
+  // (with the output map requested -- what the drop-in sub_inference call does -- the weight samples of the finished chains
+  //  come from ONE K4 pass over all itr * C samples, the kernel si_reconstruct runs: same bits, no streaming needed at this size)
+  const size_t wall_elems = (size_t)ldw * (size_t)itr * (size_t)C;
+  if ((!W_out || wall_elems <= ((size_t)512 << 20) / sizeof(double)) && chain_loop_applies(ctx) && ctx->chain_loop_enabled) {
     ChainLoopArgs a{};
     const int L = (int)ctx->layers.size();
     for (int l = 0; l < L; ++l) a.lay[l] = ctx->layers[(size_t)l];
@@ -1694,7 +1697,20 @@ static int32_t sample_rwmh_impl(si_ctx* ctx, const char* who, int64_t itr, doubl
       if (e == hipSuccess && Z_out) e = hipMemcpyAsync(Z_out, dZ, (size_t)M * itr * C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess && lp_out) e = hipMemcpyAsync(lp_out, dlp, (size_t)itr * C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess) e = hipMemcpyAsync(nacc.data(), ctx->d_nacc, (size_t)C * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+      double* dW = nullptr;
+      if (e == hipSuccess && W_out) {   // src/space_inference.jl:125 for every sample of every chain
+        if (dev_alloc(&dW, wall_elems) != hipSuccess) e = hipErrorOutOfMemory;
+        if (e == hipSuccess) {
+          ProfScope ps(ctx, SI_K_RECON, 2.0 * (double)N * M * (double)itr * C, (double)N * (M + 1 + (double)itr * C) * 8.0);
+          launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, dZ, (int32_t)(itr * C), dW, ldw, ctx->num_cu);
+          e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+          e = hipMemcpy2DAsync(W_out, (size_t)N * sizeof(double), dW, (size_t)ldw * sizeof(double), (size_t)N * sizeof(double),
+                               (size_t)itr * C, hipMemcpyDeviceToHost, ctx->stream);
+      }
       const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+      dev_free(dW);
       dev_free(dZ);
       dev_free(dlp);
       if (e != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));

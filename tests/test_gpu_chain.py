@@ -46,8 +46,13 @@ def test_chain_loop_falls_back_where_it_does_not_apply(si, gpu_ctx):
     w, p = 0.3 * rng.standard_normal(n), 0.05 * rng.standard_normal((n, 3))
     gpu_ctx.infer_setup(table, n, 3, w, p, x, y, 1.0)
     z0, lp0, a0 = gpu_ctx.sample_rwmh(50, 0.1, seed=1)
-    zw, lpw, aw, ww = gpu_ctx.sample_rwmh_weights(50, 0.1, seed=1)
-    assert np.array_equal(z0, zw) and np.array_equal(lp0, lpw)
+    zw, lpw, aw, ww = gpu_ctx.sample_rwmh_weights(50, 0.1, seed=1, nchains=3)   # the loop + one K4 pass over all samples
+    assert np.array_equal(z0[:, :, 0], zw[:, :, 0]) and np.array_equal(lp0[:, 0], lpw[:, 0])
+    gpu_ctx.set_chain_loop(False)
+    zs, lps, _, ws = gpu_ctx.sample_rwmh_weights(50, 0.1, seed=1, nchains=3)   # streamed output map of the launch path
+    gpu_ctx.set_chain_loop(True)
+    assert np.array_equal(zs, zw) and np.array_equal(lps, lpw) and np.array_equal(ws, ww)
+    assert np.array_equal(ww[:, :, 1], gpu_ctx.reconstruct(zw[:, :, 1]))
     gpu_ctx.set_prior(2.0)
     zp, lpp, _ = gpu_ctx.sample_rwmh(50, 0.1, seed=1)
     assert np.all(np.isfinite(lpp)) and not np.array_equal(lpp, lp0)
