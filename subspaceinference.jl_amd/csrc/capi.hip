@@ -98,6 +98,8 @@ static void free_construct(Ctx* c) {
   dev_free(c->d_V);
   dev_free(c->d_P);
   dev_free(c->d_B);
+  dev_free(c->d_At);
+  c->at_cap = 0;
   c->refine_stage = 0;
   c->gpart_bytes = 0;
   c->c_active = c->c_finished = c->gram_valid = false;
@@ -740,6 +742,101 @@ int32_t si_construct_refine(si_ctx* ctx) {
   return SI_OK;
 }
 
+static int32_t alloc_P(si_ctx* ctx, int32_t M) {
+  if (ctx->d_P != nullptr && ctx->M_built == M) return SI_OK;
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // P is re-allocated: an inference bound to the old P of this construction must not outlive it
+  if (ctx->i_ready && ctx->i_P == ctx->d_P && ctx->d_P != nullptr) free_infer(ctx);
+  dev_free(ctx->d_P);
+  ctx->M_built = 0;
+  if (dev_alloc(&ctx->d_P, (size_t)ctx->ldA * M) != hipSuccess)
+    return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: allocation of P failed");
+  // zeroed once, for the padding rows [N, ldA): every row < N of every column is written on each finish
+  SI_HIP(ctx, hipMemsetAsync(ctx->d_P, 0, (size_t)ctx->ldA * M * sizeof(double), ctx->stream));
+  return SI_OK;
+}
+
+// K > N: A' on the device (transpose), G = A A' with the Gram kernel, top-M eigenpairs of the N x N matrix on the host,
+// the right singular vectors A'U only to read the deterministic column signs from, P = U * Diagonal(s) uploaded.
+// *done = false: lambda_M is too close to the rounding floor of a squared-condition Gram matrix (the caller takes the K x K route)
+static int32_t finish_wide(si_ctx* ctx, int32_t M, bool* done) {
+  *done = false;
+  const int64_t K = ctx->K, N = ctx->N, ldt = pad_ld(K);
+  int32_t rc;
+  if (ctx->at_cap < ldt * N) {
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_At);
+    ctx->at_cap = 0;
+    if (dev_alloc(&ctx->d_At, (size_t)ldt * N) != hipSuccess) return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: allocation of A' failed");
+    ctx->at_cap = ldt * N;
+  }
+  // the Gram kernel reads whole 64-row slabs: rows [K, ldt) of every column must be zero (K differs between constructions)
+  SI_HIP(ctx, hipMemsetAsync(ctx->d_At, 0, (size_t)ldt * N * sizeof(double), ctx->stream));
+  const size_t need = launch_gram(ctx->stream, ctx->d_At, ldt, K, N, nullptr, nullptr, ctx->num_cu, nullptr);
+  if (ctx->gpart_bytes < need) {
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_Gpart);
+    ctx->gpart_bytes = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->d_Gpart), need) != hipSuccess)
+      return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: partial-slab allocation failed");
+    ctx->gpart_bytes = need;
+  }
+  if (ctx->g_cap < N * N) {
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_G);
+    ctx->g_cap = 0;
+    if (dev_alloc(&ctx->d_G, (size_t)N * N) != hipSuccess) return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: G allocation failed");
+    ctx->g_cap = N * N;
+  }
+  {
+    ProfScope ps(ctx, SI_K_PUSH, 0.0, 16.0 * (double)N * (double)K);
+    launch_transpose(ctx->stream, ctx->d_A, ctx->ldA, N, K, ctx->d_At, ldt);
+  }
+  launch_gram(ctx->stream, ctx->d_At, ldt, K, N, ctx->d_Gpart, ctx->d_G, ctx->num_cu, ctx);   // N x N: A A'
+  SI_HIP(ctx, hipGetLastError());
+  if ((rc = fetch_G(ctx, N)) != SI_OK) return rc;
+  std::vector<double> wtop, U;
+  if ((rc = top_eigen(ctx, N, M, wtop, U)) != SI_OK) return rc;
+  if (!(wtop[0] > 0.0)) return fail(ctx, SI_ERR_BOUNDS, "BoundsError: the deviation matrix is zero (rank 0 < M)");
+  if (!(wtop[(size_t)M - 1] > SI_GRAM_ROUTE_MIN * wtop[0])) return SI_OK;   // ill-conditioned: the K x K route with its second stage
+  ctx->svals.assign((size_t)M, 0.0);
+  for (int m = 0; m < M; ++m) ctx->svals[(size_t)m] = std::sqrt(wtop[(size_t)m]);
+  // signs: the right singular vector s_m v_m = A' u_m, largest-magnitude entry positive (the convention of the K x K route)
+  const int Mpad = project_mpad(M);
+  if ((rc = ensure_pin(ctx, (size_t)N * N * 2 + (size_t)N * Mpad + (size_t)ldt * M + (size_t)N * M)) != SI_OK) return rc;
+  double* const Uh = ctx->h_pin + (size_t)N * N * 2;          // N x Mpad, row n contiguous
+  double* const Rh = Uh + (size_t)N * Mpad;                    // ldt x M
+  double* const Ph = Rh + (size_t)ldt * M;                     // N x M
+  std::fill(Uh, Uh + (size_t)N * Mpad, 0.0);
+  for (int m = 0; m < M; ++m)
+    for (int64_t n = 0; n < N; ++n) Uh[(size_t)n * Mpad + m] = U[(size_t)m * N + n];
+  if ((rc = ensure_V(ctx, (size_t)N * Mpad + (size_t)ldt * M)) != SI_OK) return rc;
+  double* const dU = ctx->d_V;
+  double* const dR = ctx->d_V + (size_t)N * Mpad;
+  SI_HIP(ctx, hipMemcpyAsync(dU, Uh, (size_t)N * Mpad * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  {
+    ProfScope ps(ctx, SI_K_PROJECT, 2.0 * (double)N * (double)K * (double)M, (double)K * (double)(N + M) * 8.0);
+    launch_project(ctx->stream, ctx->d_At, ldt, K, N, dU, M, Mpad, dR, ldt, ctx->num_cu);   // R = A' U_M  (K x M)
+  }
+  SI_HIP(ctx, hipGetLastError());
+  SI_HIP(ctx, hipMemcpyAsync(Rh, dR, (size_t)ldt * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int m = 0; m < M; ++m) {
+    const double* v = Rh + (size_t)m * ldt;
+    int64_t imax = 0;
+    for (int64_t k = 1; k < K; ++k)
+      if (std::fabs(v[k]) > std::fabs(v[imax])) imax = k;
+    const double f = (v[imax] < 0.0 ? -1.0 : 1.0) * ctx->svals[(size_t)m];
+    for (int64_t n = 0; n < N; ++n) Ph[(size_t)m * N + n] = f * U[(size_t)m * N + n];
+  }
+  if ((rc = alloc_P(ctx, M)) != SI_OK) return rc;
+  SI_HIP(ctx, hipMemcpy2DAsync(ctx->d_P, (size_t)ctx->ldA * sizeof(double), Ph, (size_t)N * sizeof(double), (size_t)N * sizeof(double),
+                               (size_t)M, hipMemcpyHostToDevice, ctx->stream));
+  SI_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the pinned buffers may be rewritten
+  *done = true;
+  return SI_OK;
+}
+
 int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P_out, double* s_out,
                             int64_t* K_out) {
   CHECK_CTX(ctx);
@@ -752,6 +849,26 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
   if (M > std::min<int64_t>(N, K))
     return fail(ctx, SI_ERR_BOUNDS, "BoundsError: M exceeds min(N, K), the largest possible rank of the deviation matrix");
   int32_t rc;
+  // ---- K > N (the README toy: batchsize 1 x 100 observations x 10 epochs = 1000 deviation columns of 682 weights): the Gram
+  // matrix on the SMALLER side, A A' (N x N) instead of A'A (K x K).  Its top eigenpairs are (s^2, U) directly:
+  // P = U[:, 1:M] * Diagonal(s[1:M]) (src/subspace_construction.jl:65).  Only when the caller has not asked for the K x K
+  // Gram matrix itself (si_construct_gram + all-reduce: a row-sharded construction sums A'A over the ranks, A A' does not add).
+  if (!ctx->gram_valid && ctx->refine_stage == 0 && K > N) {
+    bool done = false;
+    if ((rc = finish_wide(ctx, M, &done)) != SI_OK) return rc;
+    if (done) {
+      ctx->M_built = M;
+      ctx->c_finished = true;
+      if (s_out) std::copy(ctx->svals.begin(), ctx->svals.end(), s_out);
+      if (W_swa_out)
+        SI_HIP(ctx, hipMemcpyAsync(W_swa_out, ctx->d_swa, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      if (P_out)
+        SI_HIP(ctx, hipMemcpy2DAsync(P_out, (size_t)N * sizeof(double), ctx->d_P, (size_t)ctx->ldA * sizeof(double),
+                                     (size_t)N * sizeof(double), (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
+      SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      return SI_OK;
+    }   // (an ill-conditioned A A' falls through to the K x K route, which has the two-stage refinement)
+  }
   if (!ctx->gram_valid && (rc = si_construct_gram(ctx)) != SI_OK) return rc;
   const int Mpad = project_mpad(M);
   const size_t v_elems = (size_t)K * Mpad;
@@ -814,17 +931,7 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
     const double* v = vcols.data() + (size_t)m * K;
     for (int64_t k = 0; k < K; ++k) V[(size_t)k * Mpad + m] = sgn * v[k];
   }
-  if (ctx->d_P == nullptr || ctx->M_built != M) {
-    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // P is re-allocated: an inference bound to the old P of this construction must not outlive it
-    if (ctx->i_ready && ctx->i_P == ctx->d_P && ctx->d_P != nullptr) free_infer(ctx);
-    dev_free(ctx->d_P);
-    ctx->M_built = 0;
-    if (dev_alloc(&ctx->d_P, (size_t)ctx->ldA * M) != hipSuccess)
-      return fail(ctx, SI_ERR_NOMEM, "si_construct_finish: allocation of P failed");
-    // zeroed once, for the padding rows [N, ldA): the projection writes every row < N of every column on each finish
-    SI_HIP(ctx, hipMemsetAsync(ctx->d_P, 0, (size_t)ctx->ldA * M * sizeof(double), ctx->stream));
-  }
+  if ((rc = alloc_P(ctx, M)) != SI_OK) return rc;
   if ((rc = ensure_V(ctx, std::max(v_elems, (size_t)K * project_mpad((int)K) * (ctx->refine_stage ? 1 : 0)))) != SI_OK) return rc;
   SI_HIP(ctx, hipMemcpyAsync(ctx->d_V, V, v_elems * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   {

@@ -423,6 +423,27 @@ __global__ __launch_bounds__(256) void prior_grad_kernel(double* __restrict__ g,
 void launch_prior_grad(hipStream_t st, double* g, const double* w, int64_t n, double inv_s2, int num_cu) {
   hipLaunchKernelGGL(prior_grad_kernel, dim3(stream_grid(n, num_cu)), dim3(256), 0, st, g, w, n, inv_s2);
 }
+// At[k + ldt*r] = A[r + lda*k]: the deviation matrix transposed, for the K > N route of si_construct_finish (the Gram kernel
+// reads columns: the Gram matrix of A' is A A').  32 x 32 tiles through LDS, both sides coalesced.
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ A, int64_t lda, int64_t N, int64_t K,
+                                                        double* __restrict__ At, int64_t ldt) {
+  __shared__ double tile[32][33];
+  const int64_t r0 = (int64_t)blockIdx.x * 32, k0 = (int64_t)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int64_t r = r0 + tx, k = k0 + j;
+    tile[j][tx] = (r < N && k < K) ? A[r + lda * k] : 0.0;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int64_t k = k0 + tx, r = r0 + j;
+    if (k < K && r < N) At[k + ldt * r] = tile[tx][j];
+  }
+}
+void launch_transpose(hipStream_t st, const double* A, int64_t lda, int64_t N, int64_t K, double* At, int64_t ldt) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((N + 31) / 32), (unsigned)((K + 31) / 32)), dim3(256), 0, st, A, lda, N, K, At, ldt);
+}
+
 // dst[i] = (double)src[i]  (initial W_swa from Float32 weights: the non-default init = :pretrained option)
 __global__ __launch_bounds__(256) void widen_f32_kernel(const float* __restrict__ src, double* __restrict__ dst, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;

@@ -154,6 +154,8 @@ struct Ctx {
   std::vector<double> svals;
   // ill-conditioned route (second-stage Gram): B = A * V_full, d_G then holds G2 = B'B
   int refine_stage = 0;           // 0: d_G = A'A;  1: d_B valid and d_G = B'B (possibly all-reduced by the caller)
+  double* d_At = nullptr;         // K > N route: A' (pad_ld(K) x N), kept between finishes of one shape
+  int64_t at_cap = 0;
   double* d_B = nullptr;          // ldA x K
   std::vector<double> vfull;      // K x K eigenvectors of A'A, columns DESCENDING by eigenvalue (host)
 
@@ -459,6 +461,7 @@ void launch_weights_select(hipStream_t st, const int32_t* flag, const double* wp
                            int64_t ldd, int64_t N, int32_t C, int num_cu);
 void launch_prior_grad(hipStream_t st, double* g, const double* w, int64_t n, double inv_s2, int num_cu);
 void launch_widen_f32(hipStream_t st, const float* src, double* dst, int64_t n, int num_cu);
+void launch_transpose(hipStream_t st, const double* A, int64_t lda, int64_t N, int64_t K, double* At, int64_t ldt);
 
 // host copy pool (host_copy.cpp): parallel memcpy between pageable caller arrays and pinned staging
 void host_copy(void* dst, const void* src, size_t bytes);

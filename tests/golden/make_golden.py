@@ -47,6 +47,14 @@ def main():
     p, s = so.projection_from_A(a, 3)
     np.savez_compressed(os.path.join(HERE, "toy_construct_k12.npz"), snapshots=np.stack(snaps), ns=np.array(ns),
                         W_swa=w_swa, A=a, P=p, s=s[:3])
+    # ---- construction at the README toy's REAL shape (README.md:52-79): DataLoader batchsize 1 over 100
+    # observations, T = 10 epochs, c = 1  =>  K = 1000 deviation columns of N = 682 weights (K > N), n = epoch per batch, M = 3
+    snaps = snapshot_stream(n, 1000, seed=5)
+    ns = [float(i) for i in range(1, 11) for _ in range(100)]
+    w_swa_k, a_k = so.construct_stream(snaps, ns)
+    p_k, s_k = so.projection_from_A(a_k, 3)
+    np.savez_compressed(os.path.join(HERE, "toy_construct_k1000.npz"), snapshots=np.stack(snaps), ns=np.array(ns),
+                        W_swa=w_swa_k, P=p_k, s=s_k[:20])
     # ---- density + RWMH at README toy size: X = rand(10,100), Y = rand(2,100), M=3, itr=10, sigma = 1
     rng = np.random.default_rng(0)
     x = rng.random((10, 100))

@@ -39,6 +39,20 @@ M = 3
 P = U[:, 1:M] * Diagonal(s[1:M])                        # :65
 npzwrite(joinpath(here, "toy_construct_k12_reference.npz"), Dict("W_swa" => W_swa, "A" => A, "P" => P, "s" => s[1:M]))
 
+# ---- the same at the README toy's REAL shape (README.md:52-79: K = 1000 deviation columns of N = 682 weights, K > N) -------
+big = npzread(joinpath(here, "toy_construct_k1000.npz"))
+let snaps = big["snapshots"], ns = big["ns"], N = size(big["snapshots"], 2)
+    W = zeros(N); Ab = Float64[]
+    for k in 1:size(snaps, 1)
+        w = snaps[k, :]; n = ns[k]
+        W = (n .* W + w) ./ (n + 1)                     # :47
+        append!(Ab, w - W)                              # :51-52
+    end
+    Ab = reshape(Ab, N, :)                              # :61
+    Ub, sb, Vb = psvd(Ab)                               # :63
+    npzwrite(joinpath(here, "toy_construct_k1000_reference.npz"), Dict("W_swa" => W, "P" => Ub[:, 1:3] * Diagonal(sb[1:3]), "s" => sb[1:3]))
+end
+
 # ---- density: src/space_inference.jl:90-95 through the package's own model_re ---------------------------------------
 model = Chain(Dense(10, 20), Dense(20, 20), Dense(20, 2))           # README.md:62
 X, Y = den["X"], den["Y"]

@@ -162,6 +162,34 @@ def test_golden_construct(gpu_ctx):
     assert np.allclose(_align_signs(p, g["P"]), g["P"], rtol=1e-7, atol=1e-10)
 
 
+def test_golden_construct_toy_real_shape_k1000(gpu_ctx):
+    """BASELINE cfg1 at the shape the README really produces (README.md:52-79: K = 1000 > N = 682, M = 3), against the
+    committed oracle fixture: W_swa bit for bit, s rtol 1e-8, P up to sign rtol 1e-6.  si_construct_finish takes
+    the K > N route here (Gram matrix on the N side); forcing the K x K route (explicit si_construct_gram) must agree."""
+    g = np.load(os.path.join(GOLD, "toy_construct_k1000.npz"))
+    res = {}
+    for route in ("wide", "kxk"):
+        gpu_ctx.construct_begin(682, 1000)
+        for w, nn in zip(g["snapshots"], g["ns"]):
+            gpu_ctx.construct_push(w, float(nn))
+        if route == "kxk":
+            gpu_ctx.construct_gram()
+        w_swa, p, s, k = gpu_ctx.construct_finish(3)
+        assert k == 1000 and np.array_equal(w_swa, g["W_swa"])
+        assert np.allclose(s, g["s"][:3], rtol=1e-8)
+        assert np.allclose(_align_signs(p, g["P"]), g["P"], rtol=1e-6, atol=1e-9 * np.abs(g["P"]).max())
+        res[route] = (p, s)
+    assert np.allclose(res["wide"][0], res["kxk"][0], rtol=1e-9, atol=1e-12 * np.abs(g["P"]).max())   # same signs as well
+    # M up to the rank: the 20 leading singular values, and BoundsError past min(N, K)
+    gpu_ctx.construct_begin(682, 1000)
+    for w, nn in zip(g["snapshots"], g["ns"]):
+        gpu_ctx.construct_push(w, float(nn))
+    _, p20, s20, _ = gpu_ctx.construct_finish(20)
+    assert np.allclose(s20, g["s"], rtol=1e-8) and np.allclose(p20.T @ p20, np.diag(s20 ** 2), rtol=1e-8, atol=1e-9 * s20[0] ** 2)
+    with pytest.raises(Exception):
+        gpu_ctx.construct_finish(683)
+
+
 # ----------------------------------------------------------------------------------------------- K4 / K5
 def _random_problem(dims, acts, b, m, seed):
     rng = np.random.default_rng(seed)

@@ -134,6 +134,21 @@ def test_golden_vectors_match_oracle():
     assert nacc == int(d["nacc"])
 
 
+def test_golden_toy_at_its_real_shape_k1000():
+    """README.md:52-79: batchsize 1 x 100 observations x T = 10 => K = 1000 deviation columns of N = 682 weights.
+    The fixture pins the oracle at K > N; identities that do not depend on the oracle being right: LAPACK's SVD of A."""
+    g = np.load(os.path.join(GOLD, "toy_construct_k1000.npz"))
+    assert g["snapshots"].shape == (1000, 682) and g["snapshots"].dtype == np.float32
+    w_swa, a = so.construct_stream(list(g["snapshots"]), list(g["ns"]))
+    assert np.array_equal(w_swa, g["W_swa"]) and a.shape == (682, 1000)
+    p, s = so.projection_from_A(a, 3)
+    assert np.allclose(s[:20], g["s"], rtol=1e-12)
+    assert np.allclose(p * np.sign(np.sum(p * g["P"], axis=0)), g["P"], rtol=1e-9, atol=1e-12)
+    sv = np.linalg.svd(a, compute_uv=False)
+    assert np.allclose(sv[:20], g["s"], rtol=1e-10)
+    assert np.allclose(g["P"].T @ g["P"], np.diag(g["s"][:3] ** 2), rtol=1e-9, atol=1e-9 * g["s"][0] ** 2)
+
+
 GOLD_CNN_WHC = (6, 6, 2)   # tests/golden/make_golden.py CNN_WHC / CNN_SPEC
 GOLD_CNN_SPEC = [("conv", (3, 3), 4, so.ACT_RELU, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("conv", (2, 2), 3, so.ACT_TANH, (2, 2)),
                  ("flatten",), ("dense", 3, so.ACT_IDENTITY)]
@@ -358,7 +373,8 @@ def test_reference_fixtures_when_present():
     When a maintainer has run it and committed the files, this test holds the oracle against them -- the moment the parity
     of this repository stops being 'unpinned'.  Without the files it is skipped."""
     gold = os.path.join(os.path.dirname(__file__), "golden")
-    names = ["toy_construct_k12_reference.npz", "toy_density_rwmh_reference.npz", "toy_train_steps_reference.npz"]
+    names = ["toy_construct_k12_reference.npz", "toy_density_rwmh_reference.npz", "toy_train_steps_reference.npz",
+             "toy_construct_k1000_reference.npz"]
     present = [n for n in names if os.path.exists(os.path.join(gold, n))]
     if not present:
         pytest.skip("no *_reference.npz committed (the reference cannot be run in this environment)")
@@ -374,6 +390,11 @@ def test_reference_fixtures_when_present():
         table, _ = so.layer_table([10, 20, 20, 2], [0, 0, 0])
         _, g1, _ = so.logdensity_grad(table, mine["W_swa"], mine["P"], mine["X"], mine["Y"], 1.0, mine["Z"][:, 1])
         assert np.allclose(ref["grad1"], g1, rtol=1e-8)
+    if names[3] in present:   # the README toy at its real shape, K = 1000 > N = 682
+        ref, mine = np.load(os.path.join(gold, names[3])), np.load(os.path.join(gold, "toy_construct_k1000.npz"))
+        assert np.array_equal(ref["W_swa"], mine["W_swa"]) and np.allclose(ref["s"], mine["s"][:3], rtol=1e-8)
+        sign = np.sign(np.sum(ref["P"] * mine["P"], axis=0))
+        assert np.allclose(ref["P"] * sign, mine["P"], rtol=1e-4, atol=1e-10)
     if names[2] in present:
         ref, mine = np.load(os.path.join(gold, names[2])), np.load(os.path.join(gold, "toy_train_steps.npz"))
         for name in ("descent", "momentum", "adam"):
