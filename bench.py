@@ -534,6 +534,8 @@ def run_chains(args, rk, real_stdout):
     # ---- sampling.  The timed region carries event pairs around the DOMINANT kernel only (roofline.achieved is its
     # live average launch duration); the per-class breakdown comes from a short untimed pass afterwards.
     ctx.infer_setup(table, n_par, M, None, None, x, y, SIGMA_M)
+    # every rank evaluates the density at the same point: identical (W_swa, P) after the broadcast <=> identical bits
+    lp0_per_rank = rk.gather_floats(float(ctx.logdensity(np.full((M, 1), 0.25))[0]))
     ctx.set_profiling(True, classes=["dense_main"])
     ctx.sample_rwmh(max(1, args.warmup), SIGMA_Z, seed=100, chain_id0=rank, want_z=False)
     barrier()
@@ -686,6 +688,7 @@ def run_chains(args, rk, real_stdout):
             "comm_error": getattr(rk, "comm_error", None),
             "per_rank_ms_per_step": [round(t, 4) for t in per_rank_ms], "lp_last_per_rank": lp_per_rank,
             "chains_are_independent": bool(len(set(lp_per_rank)) == len(lp_per_rank)),
+            "subspace_identical_on_all_ranks": bool(len(set(lp0_per_rank)) == 1),   # lp at a fixed z, bit for bit, after si_bcast_subspace
             "construct_wall_ms": construct_ms, "construct_wall_ms_runs": construct_runs,
             "construct_wall_ms_note": "100 x si_construct_push_dev (one K1 launch per batch, the entry point api.py / the .jl "
                                       "wrapper use) + Gram + host eigensolve + projection",

@@ -309,6 +309,14 @@ int32_t si_train_apply(si_ctx* ctx);
  * src/subspace_construction.jl:39-43 (data-parallel training step), and independent chains (no per-step exchange).
  * Every collective is issued on the ctx's stream, in place on buffers the library owns: no host staging and no
  * synchronisation of its own.  All ranks must make the same calls in the same order (RCCL semantics).
+ * Failure behaviour: the entry points that prepare something LOCALLY before their collective (si_bcast_subspace,
+ * si_construct_allgather, si_sample_rwmh_sharded, si_train_step_dp) first agree on the ranks' local status with one
+ * 8-byte all-reduce (max): when any rank failed its preparation, NO rank issues the data collective -- the failing rank
+ * returns its own error, the others SI_ERR_COMM.  The thin in-place collectives (si_construct_allreduce_gram,
+ * si_rwmh_allreduce_sse, si_train_allreduce_grad, si_comm_*_host) check only local state that is the same on every rank
+ * of an SPMD caller (a communicator exists, si_construct_gram / si_rwmh_step_eval / si_train_grad ran); a rank that
+ * returns SI_ERR_STATE from one of them while the others are inside it leaves those blocked -- keep the call sequences
+ * identical, as with RCCL itself.
  *
  * Start-up: rank 0 calls si_comm_unique_id and ships the 128 bytes to the other ranks by whatever the host has
  * (Julia: Distributed.remotecall / a file; Python: a file or any process group); every rank then calls

@@ -29,7 +29,7 @@ def _alg_name(alg):
 
 def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, *, device=0, ctx=None,
                           max_cols=0, verbose=True, keep_on_device=False, device_training="auto", init="zeros",
-                          data_parallel="auto"):
+                          data_parallel=False):
     """src/subspace_construction.jl:26-67.
 
     Per batch the host does `gradient` + `update!` (:39-43, caller side) and hands the flattened weights
@@ -45,11 +45,12 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
     init ("zeros" | "pretrained"): "zeros" is what the reference's CODE does (W_swa = zeros, :31 -- quirk Q1, the default);
     "pretrained" starts the running mean at the model's weights, as the reference's docs describe (nn_example.md:44).
 
-    With a ctx that carries an RCCL communicator (one process per GPU, dist.comm_init) the device training step is
-    data-parallel: every rank must be called with the same model, data and DataLoader seed; each takes its share
-    of every batch and the gradient is all-reduced once per step inside the library (si_train_step_dp), so all
-    ranks return the same (W_swa, P).  data_parallel=False keeps the step local even then (a rank doing extra work on
-    its own: every rank of a data-parallel step must make the same calls).
+    data_parallel=True (opt-in; needs a ctx with an RCCL communicator -- one process per GPU, dist.comm_init -- or a torch
+    process group) makes the device training step data-parallel: EVERY rank must make this call with the same model, data
+    and DataLoader seed; each takes its share of every batch and the gradient is all-reduced once per step inside the
+    library (si_train_step_dp), so all ranks return the same (W_swa, P).  The default keeps the step local whatever the
+    ctx carries: the documented cfg3 flow (construct on rank 0, then si_bcast_subspace) must not find rank 0 alone inside a
+    gradient all-reduce.
     """
     ps = flux.params(model)
     n_par = int(sum(p.size for p in ps))
@@ -74,7 +75,11 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
         elif _alg_name(init) != "zeros":
             raise SubspaceError("init must be :zeros (the reference's behaviour) or :pretrained")
         training_loss = 0.0
-        use_dp = use_dev and data_parallel is not False
+        if data_parallel not in (True, False):
+            raise SubspaceError("data_parallel must be True or False")
+        if data_parallel and not use_dev:
+            raise SubspaceError("data_parallel=True needs the device training step (cost = flux.mse, Float32 model, a fresh optimiser)")
+        use_dp = use_dev and data_parallel is True
         dp_rank, dp_world = dist.world(ctx) if use_dp else (0, 1)
         if use_dev:
             xm, ym, in_size = flux.data_matrices(data)

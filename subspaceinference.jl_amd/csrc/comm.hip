@@ -149,7 +149,7 @@ int32_t si_comm_init_rank(si_ctx* ctx, int32_t world, int32_t rank, const uint8_
   // `world` processes of the library now share this host's CPUs (one node, one process per GPU): the host copy pool of
   // this process keeps to its share of the CPU quota (8 ranks on a 16-CPU quota: one copy thread each, not eight)
   host_copy_set_share(world);
-  if (hipMalloc(reinterpret_cast<void**>(&ctx->d_commtmp), COMM_TMP_ELEMS * sizeof(double)) != hipSuccess) {
+  if (hipMalloc(reinterpret_cast<void**>(&ctx->d_commtmp), (COMM_TMP_ELEMS + 8) * sizeof(double)) != hipSuccess) {   // (+ the status word of comm_agree)
     comm_release(ctx);
     return fail(ctx, SI_ERR_NOMEM, "si_comm_init_rank: scratch allocation failed");
   }
@@ -200,6 +200,31 @@ int32_t si_comm_allreduce_host(si_ctx* ctx, double* inout, int64_t n, int32_t op
                                 comm_of(ctx), ctx->stream));
   SI_HIP(ctx, hipMemcpyAsync(inout, ctx->d_commtmp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+// Collective error agreement: an entry point that validates PER RANK and returns before its data collective
+// would leave every other rank blocked inside RCCL for good.  Every rank therefore first contributes its local status to
+// ONE small all-reduce (max) and only then issues the data collective -- or none of them does: the failing rank returns its
+// own error, the others SI_ERR_COMM.  Synchronous (one 8-byte all-reduce + a stream sync): used by the one-off collectives
+// and by si_train_step_dp, never inside the per-transition loop of a sharded chain.
+static int32_t comm_agree(si_ctx* ctx, int32_t local_rc, const char* who) {
+  double flag = local_rc == SI_OK ? 0.0 : 1.0;
+  double* slot = ctx->d_commtmp + COMM_TMP_ELEMS;
+  const std::string own = ctx->err;
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e == hipSuccess) e = hipMemcpyAsync(slot, &flag, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  ncclResult_t nr = ncclSuccess;
+  if (e == hipSuccess) nr = rccl().AllReduce(slot, slot, 1, ncclFloat64, ncclMax, comm_of(ctx), ctx->stream);
+  if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(&flag, slot, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  if (local_rc != SI_OK) {   // this rank's own failure is what it reports
+    ctx->err = own;
+    return local_rc;
+  }
+  if (nr != ncclSuccess) return fail(ctx, SI_ERR_COMM, std::string(who) + ": status all-reduce: " + rccl().GetErrorString(nr));
+  if (e != hipSuccess || e2 != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e != hipSuccess ? e : e2));
+  if (flag != 0.0) return fail(ctx, SI_ERR_COMM, std::string(who) + ": another rank failed before the collective (nothing was exchanged)");
   return SI_OK;
 }
 
@@ -289,7 +314,8 @@ int32_t si_train_step_dp(si_ctx* ctx, const int64_t* idx, int64_t nb, int64_t nb
   if (!ctx) return SI_ERR_INVALID;
   int32_t rc = need_comm(ctx, "si_train_step_dp");
   if (rc != SI_OK) return rc;
-  if ((rc = si_train_grad(ctx, idx, nb, nb_total, nullptr)) != SI_OK) return rc;
+  // (a rank whose forward / reverse sweep failed must not leave the others inside the gradient all-reduce)
+  if ((rc = comm_agree(ctx, si_train_grad(ctx, idx, nb, nb_total, nullptr), "si_train_step_dp")) != SI_OK) return rc;
   double sse = 0.0;
   if ((rc = si_train_allreduce_grad(ctx, loss_out ? &sse : nullptr)) != SI_OK) return rc;
   if ((rc = si_train_apply(ctx)) != SI_OK) return rc;
@@ -307,13 +333,18 @@ int32_t si_bcast_subspace(si_ctx* ctx, int32_t root, int64_t N, int32_t M) {
   if (root < 0 || root >= ctx->comm_world || N <= 0 || M <= 0 || M > COMM_TMP_ELEMS) return fail(ctx, SI_ERR_INVALID, "si_bcast_subspace: bad root / N / M");
   SI_HIP(ctx, hipSetDevice(ctx->device));
   const int64_t ld = pad_ld(N);
-  if (ctx->comm_rank == root) {
-    if (!ctx->c_finished || ctx->N != N || ctx->M_built != M)
-      return fail(ctx, SI_ERR_STATE, "si_bcast_subspace: the root has no finished construction of this N / M");
-    SI_HIP(ctx, hipMemcpyAsync(ctx->d_commtmp, ctx->svals.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  } else if (!(ctx->c_finished && !ctx->c_active && ctx->N == N && ctx->M_built == M && ctx->d_swa && ctx->d_P)) {
-    if ((rc = construct_adopt(ctx, N, M)) != SI_OK) return rc;
-  }
+  // local preparation (root: a finished construction of this shape; receivers: buffers to receive into), then agreement
+  auto prepare = [&]() -> int32_t {
+    if (ctx->comm_rank == root) {
+      if (!ctx->c_finished || ctx->N != N || ctx->M_built != M)
+        return fail(ctx, SI_ERR_STATE, "si_bcast_subspace: the root has no finished construction of this N / M");
+      SI_HIP(ctx, hipMemcpyAsync(ctx->d_commtmp, ctx->svals.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    } else if (!(ctx->c_finished && !ctx->c_active && ctx->N == N && ctx->M_built == M && ctx->d_swa && ctx->d_P)) {
+      return construct_adopt(ctx, N, M);
+    }
+    return SI_OK;
+  };
+  if ((rc = comm_agree(ctx, prepare(), "si_bcast_subspace")) != SI_OK) return rc;
   SI_NCCL(ctx, rccl().GroupStart());
   const ncclResult_t r1 = rccl().Broadcast(ctx->d_swa, ctx->d_swa, (size_t)ld, ncclFloat64, root, comm_of(ctx), ctx->stream);
   const ncclResult_t r2 = rccl().Broadcast(ctx->d_P, ctx->d_P, (size_t)ld * (size_t)M, ncclFloat64, root, comm_of(ctx), ctx->stream);
@@ -346,8 +377,6 @@ int32_t si_construct_allgather(si_ctx* ctx, int64_t n_total) {
     mx = std::max(mx, r1[(size_t)r] - r0[(size_t)r]);
   }
   const int64_t n_loc = r1[(size_t)me] - r0[(size_t)me];
-  if (ctx->N != n_loc)
-    return fail(ctx, SI_ERR_INVALID, "si_construct_allgather: this rank's construction does not hold rows si_row_shard(n_total, rank, world)");
   SI_HIP(ctx, hipSetDevice(ctx->device));
   const int32_t M = ctx->M_built;
   const int64_t ld_loc = ctx->ldA, ld = pad_ld(n_total);
@@ -359,14 +388,20 @@ int32_t si_construct_allgather(si_ctx* ctx, int64_t n_total) {
     if (send) (void)hipFree(send);
     if (recv) (void)hipFree(recv);
   };
-  if (hipMalloc(reinterpret_cast<void**>(&send), (size_t)chunk * mx * sizeof(double)) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&recv), (size_t)W * chunk * mx * sizeof(double)) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&w_full), (size_t)ld * sizeof(double)) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&p_full), (size_t)ld * M * sizeof(double)) != hipSuccess) {
+  // validation and allocation are LOCAL and may fail on one rank only: agree before the first ncclAllGather
+  int32_t lrc = SI_OK;
+  if (ctx->N != n_loc)
+    lrc = fail(ctx, SI_ERR_INVALID, "si_construct_allgather: this rank's construction does not hold rows si_row_shard(n_total, rank, world)");
+  else if (hipMalloc(reinterpret_cast<void**>(&send), (size_t)chunk * mx * sizeof(double)) != hipSuccess ||
+           hipMalloc(reinterpret_cast<void**>(&recv), (size_t)W * chunk * mx * sizeof(double)) != hipSuccess ||
+           hipMalloc(reinterpret_cast<void**>(&w_full), (size_t)ld * sizeof(double)) != hipSuccess ||
+           hipMalloc(reinterpret_cast<void**>(&p_full), (size_t)ld * M * sizeof(double)) != hipSuccess)
+    lrc = fail(ctx, SI_ERR_NOMEM, "si_construct_allgather: device allocation failed");
+  if ((rc = comm_agree(ctx, lrc, "si_construct_allgather")) != SI_OK) {
     cleanup();
     if (w_full) (void)hipFree(w_full);
     if (p_full) (void)hipFree(p_full);
-    return fail(ctx, SI_ERR_NOMEM, "si_construct_allgather: device allocation failed");
+    return rc;
   }
   hipStream_t st = ctx->stream;
   hipError_t e = hipMemsetAsync(w_full, 0, (size_t)ld * sizeof(double), st);
@@ -415,7 +450,15 @@ int32_t si_sample_rwmh_sharded(si_ctx* ctx, int64_t itr, double sigma_z, uint64_
   if (!ctx) return SI_ERR_INVALID;
   int32_t rc = need_comm(ctx, "si_sample_rwmh_sharded");
   if (rc != SI_OK) return rc;
-  if ((rc = si_rwmh_begin(ctx, itr, sigma_z, seed, chain_id0, nchains, d_total)) != SI_OK) return rc;
+  // (set-up state, arguments and the output allocation are local: agree before the first per-transition all-reduce)
+  if ((rc = comm_agree(ctx, si_rwmh_begin(ctx, itr, sigma_z, seed, chain_id0, nchains, d_total), "si_sample_rwmh_sharded")) != SI_OK) {
+    if (ctx->sw_Z) {
+      const std::string msg = ctx->err;
+      (void)si_rwmh_abort(ctx);
+      ctx->err = msg;
+    }
+    return rc;
+  }
   for (int64_t t = 0; t < itr; ++t) {
     if ((rc = si_rwmh_step_eval(ctx, nullptr)) != SI_OK || (rc = si_rwmh_allreduce_sse(ctx)) != SI_OK ||
         (rc = si_rwmh_step_accept(ctx, nullptr)) != SI_OK) {

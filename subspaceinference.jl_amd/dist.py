@@ -72,26 +72,63 @@ def comm_init(ctx, rank=None, world=None, id_file=None, timeout_s=120.0):
         if isinstance(uid, tuple):
             raise _capi.SubspaceError("comm_init: rank 0 could not create the RCCL id: %s" % uid[1], _capi.SI_ERR_COMM)
     elif id_file is not None:
+        # File rendezvous.  A file left behind by an EARLIER run must never be taken for this run's id (ncclCommInitRank on
+        # a dead id hangs): every rank is handed the same `nonce` by its launcher (SI_COMM_NONCE, e.g. the launch time or
+        # the launcher's pid), rank 0 writes nonce + id, the others accept only a file that carries their nonce.  Without a
+        # nonce a file older than this process is ignored.  Rank 0 removes the file once it has joined the communicator.
+        nonce = os.environ.get("SI_COMM_NONCE", "").encode()[:64]
+        started = _process_start_time()
         if rank == 0:
+            try:
+                os.unlink(id_file)          # whatever an earlier run left there
+            except OSError:
+                pass
             uid = _capi.comm_unique_id()
             tmp = "%s.tmp.%d" % (id_file, os.getpid())
             with open(tmp, "wb") as f:
-                f.write(uid)
+                f.write(bytes([len(nonce)]) + nonce + uid)
             os.replace(tmp, id_file)
         else:
             t0 = time.time()
-            while not (os.path.exists(id_file) and os.path.getsize(id_file) == _capi.SI_COMM_ID_BYTES):
-                if time.time() - t0 > timeout_s:
-                    raise _capi.SubspaceError("comm_init: no RCCL id appeared at %s within %.0f s" % (id_file, timeout_s))
-                time.sleep(0.01)
-            with open(id_file, "rb") as f:
-                uid = f.read()
+            uid = None
+            while uid is None:
+                try:
+                    st = os.stat(id_file)
+                    with open(id_file, "rb") as f:
+                        blob = f.read()
+                    ok = len(blob) >= 1 and len(blob) == 1 + blob[0] + _capi.SI_COMM_ID_BYTES and blob[1:1 + blob[0]] == nonce
+                    if ok and (nonce or st.st_mtime >= started - 1.0):
+                        uid = blob[1 + blob[0]:]
+                except OSError:
+                    pass
+                if uid is None:
+                    if time.time() - t0 > timeout_s:
+                        raise _capi.SubspaceError("comm_init: no RCCL id of this run appeared at %s within %.0f s" % (id_file, timeout_s),
+                                                  _capi.SI_ERR_COMM)
+                    time.sleep(0.01)
     elif world == 1:
         uid = _capi.comm_unique_id()
     else:
         raise _capi.SubspaceError("comm_init: %d ranks need a way to share the RCCL id (a torch process group or id_file)" % world)
     ctx.comm_init_rank(world, rank, uid)
+    if id_file is not None and rank == 0:   # every rank has read the id once ncclCommInitRank returns anywhere
+        try:
+            os.unlink(id_file)
+        except OSError:
+            pass
     return rank, world
+
+
+def _process_start_time():
+    """wall-clock start of this process (seconds since the epoch): /proc/self/stat field 22 in clock ticks since boot"""
+    try:
+        with open("/proc/self/stat") as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            up = float(f.read().split()[0])
+        return time.time() - up + ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, IndexError):
+        return time.time()
 
 
 def world(ctx=None):

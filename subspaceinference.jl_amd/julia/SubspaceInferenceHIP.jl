@@ -165,7 +165,10 @@ function index_batches(d)
     return out
 end
 
-function train_on_device!(ctx::Ctx, model, data, opt, T, c, print_freq)
+# data_parallel = true (opt-in): every rank of the ctx's communicator makes this call with the same model / data / DataLoader
+# seed and takes its share of every batch.  The default keeps the step local whatever the ctx carries: a construction on one
+# rank followed by bcast_subspace! (the cfg3 flow) must not wait alone inside a gradient all-reduce.
+function train_on_device!(ctx::Ctx, model, data, opt, T, c, print_freq; data_parallel = false)
     X, Y, insize = data_matrices(data)
     tbl, N = layer_table(model, insize)
     kind, η, p1, p2 = device_optimiser(opt)
@@ -180,7 +183,7 @@ function train_on_device!(ctx::Ctx, model, data, opt, T, c, print_freq)
     world, rank = comm_info(ctx)
     for i in 1:T
         for ids in index_batches(data)
-            if world > 0
+            if data_parallel && world > 0
                 # data-parallel step (SURVEY 8e): this rank's share of the batch; the N-double gradient and the SSE are
                 # all-reduced inside the library (RCCL, in place, one grouped launch) -- every rank must iterate the
                 # same batches (same DataLoader seed)
@@ -222,7 +225,7 @@ end
 # init = :zeros is what the reference's code does (W_swa = zeros, :31); :pretrained is what its docs describe (nn_example.md:44)
 function subspace_construction(model, cost, data, opt; T = 10, c = 1, M = 3, print_freq = 1, device = 0,
                                ctx = Ctx(device), max_cols = 0, keep_on_device = false, device_training = false,
-                               init = :zeros)
+                               init = :zeros, data_parallel = false)
     training_loss = 0.0
     ps = Flux.params(model)
     N = sum(length, ps)
@@ -234,7 +237,7 @@ function subspace_construction(model, cost, data, opt; T = 10, c = 1, M = 3, pri
                                          ctx.h, pointer(W0), eltype(W0) == Float32 ? SI_F32 : SI_F64))
     end
     if device_training
-        train_on_device!(ctx, model, data, opt, T, c, print_freq)
+        train_on_device!(ctx, model, data, opt, T, c, print_freq; data_parallel = data_parallel)
     else
         for i in 1:T
             for d in data

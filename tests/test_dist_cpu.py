@@ -4,6 +4,7 @@ rank-local pieces with the ORACLE (tests may use it as the checker); the collect
 product's own (subspaceinference.jl_amd/dist.py)."""
 import os
 import socket
+import time
 import sys
 
 import numpy as np
@@ -248,15 +249,32 @@ def test_rccl_is_bound_at_run_time_and_ids_are_unique(tmp_path):
     a, b = si._capi.comm_unique_id(), si._capi.comm_unique_id()
     assert len(a) == len(b) == si._capi.SI_COMM_ID_BYTES == 128 and a != b
 
+    import threading
+    joined = threading.Barrier(2)   # ncclCommInitRank returns only once every rank has joined: the stand-in does the same
+
     class Rec:
         def comm_init_rank(self, world, rank, uid):
             self.got = (world, rank, uid)
+            joined.wait(timeout=20)
     from subspaceinference_jl_amd import dist as sd
     path = str(tmp_path / "id")
+    # a file an EARLIER run left behind (right size, old): must not be taken for this run's id
+    with open(path, "wb") as f:
+        f.write(bytes([0]) + b"\x07" * 128)
+    os.utime(path, (1.0, 1.0))
     r0, r1 = Rec(), Rec()
-    assert sd.comm_init(r0, rank=0, world=2, id_file=path) == (0, 2)
-    assert sd.comm_init(r1, rank=1, world=2, id_file=path) == (1, 2)
-    assert r0.got[2] == r1.got[2] and len(r1.got[2]) == 128 and (r0.got[:2], r1.got[:2]) == ((2, 0), (2, 1))
+    out = {}
+    t1 = threading.Thread(target=lambda: out.setdefault(1, sd.comm_init(r1, rank=1, world=2, id_file=path, timeout_s=20)))
+    t1.start()
+    time.sleep(0.3)                 # rank 1 is polling and has NOT accepted the stale file
+    assert not hasattr(r1, "got")
+    out[0] = sd.comm_init(r0, rank=0, world=2, id_file=path)
+    t1.join(20)
+    assert out == {0: (0, 2), 1: (1, 2)}
+    assert r0.got[2] == r1.got[2] and len(r1.got[2]) == 128 and r1.got[2] != b"\x07" * 128
+    assert (r0.got[:2], r1.got[:2]) == ((2, 0), (2, 1))
+    assert not os.path.exists(path)   # rank 0 removed it after the join
+    joined = threading.Barrier(1)
     with pytest.raises(si.SubspaceError):
         sd.comm_init(Rec(), rank=1, world=2, id_file=str(tmp_path / "never"), timeout_s=0.2)
     with pytest.raises(si.SubspaceError):

@@ -160,7 +160,7 @@ def test_api_construction_uses_the_communicator(si):
         m = flux.Chain(flux.Dense(10, 20, flux.tanh, rng=wr), flux.Dense(20, 20, flux.relu, rng=wr), flux.Dense(20, 2, rng=wr))
         data = flux.DataLoader(x, y, batchsize=25, shuffle=True, rng=np.random.default_rng(7))
         return si.subspace_construction(m, flux.mse, data, flux.ADAM(0.01), T=4, c=2, M=3, ctx=ctx, verbose=False,
-                                        device_training=True)
+                                        device_training=True, data_parallel=si.dist._has_comm(ctx))
     a, b = si.Context(0), _with_comm(si)
     try:
         (w0, p0), (w1, p1) = run(a), run(b)

@@ -613,7 +613,8 @@ x, y = rng.random((10, 100)), rng.random((2, 100))
 wr = np.random.default_rng(2)
 m = flux.Chain(flux.Dense(10, 20, flux.tanh, rng=wr), flux.Dense(20, 20, flux.relu, rng=wr), flux.Dense(20, 2, rng=wr))
 data = flux.DataLoader(x, y, batchsize=25, shuffle=True, rng=np.random.default_rng(7))   # same seed on every rank
-w_swa, p = si.subspace_construction(m, flux.mse, data, flux.ADAM(0.01), T=4, c=2, M=3, verbose=False, device_training=True)
+w_swa, p = si.subspace_construction(m, flux.mse, data, flux.ADAM(0.01), T=4, c=2, M=3, verbose=False, device_training=True,
+                                    data_parallel=True)
 np.savez(os.environ["SI_OUT"] + "_%d.npz" % rank, w_swa=w_swa, p=p, w=flux.extract_params(flux.params(m)))
 import torch.distributed as td
 td.destroy_process_group()
