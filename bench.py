@@ -441,8 +441,10 @@ def run_chains(args, rk, real_stdout):
     #             Flux step in Julia, extract_params, ccall), pipelined through pinned staging
     base = snaps.data_ptr()
 
-    def construct(kind):
+    def construct(kind, a32=False):
         ctx.construct_begin(n_par, K_SNAP)
+        if a32:
+            ctx.construct_set_storage(0)   # SI_F32: the opt-in fp32 storage of the deviation matrix
         if kind == "batched":
             ctx.construct_push_batch_dev(base, 0, ldw, ns)
         elif kind == "per_push":
@@ -453,12 +455,12 @@ def run_chains(args, rk, real_stdout):
                 ctx.construct_push(snaps_host[j], ns[j])
         return ctx.construct_finish(M, want_swa=False, want_p=False)
 
-    def wall3(kind):
+    def wall3(kind, a32=False):
         runs = []
         for _ in range(3):   # median of three back-to-back constructions, no event pairs
             barrier()
             t0 = time.perf_counter()
-            construct(kind)
+            construct(kind, a32)
             ctx.synchronize()
             runs.append((time.perf_counter() - t0) * 1e3)
         return sorted(runs)[1], [round(t, 4) for t in runs]
@@ -475,6 +477,16 @@ def run_chains(args, rk, real_stdout):
     ctx.set_profiling(False)
     construct_ms, construct_runs = wall3("per_push")
     construct_b_ms, construct_b_runs = wall3("batched")
+    # the same with the deviation matrix stored in fp32 (opt-in; W_swa, G, the eigen-decomposition and P stay fp64)
+    ctx.set_profiling(True)
+    construct("per_push", True)
+    ctx.reset_stats()
+    construct("per_push", True)
+    ctx.synchronize()
+    cst32 = ctx.stats()
+    ctx.set_profiling(False)
+    construct32_ms, construct32_runs = wall3("per_push", True)
+    construct32_b_ms, _ = wall3("batched", True)
     host_push = None
     if rank == 0:
         snaps_host = snaps[:, :n_par].cpu().numpy()   # 100 pageable Float32 vectors (419 MB)
@@ -693,6 +705,12 @@ def run_chains(args, rk, real_stdout):
             "construct_wall_ms_note": "100 x si_construct_push_dev (one K1 launch per batch, the entry point api.py / the .jl "
                                       "wrapper use) + Gram + host eigensolve + projection",
             "construct_wall_ms_batched": construct_b_ms, "construct_wall_ms_batched_runs": construct_b_runs,
+            "construct_a_fp32": {"note": "si_construct_set_storage(SI_F32): the deviation columns formed in fp64 and stored rounded once to fp32 "
+                                         "(opt-in, SURVEY section 0 Q6); W_swa bit-exact, s rtol 1e-6, P 1e-5 of its scale vs the fp64 oracle "
+                                         "(tests/test_gpu_a32.py).  The register-staged Gram kernels read it (no LDS-DMA variant): the Gram "
+                                         "itself does not get faster, the push and the projection do",
+                                 "construct_wall_ms": construct32_ms, "runs": construct32_runs, "construct_wall_ms_batched": construct32_b_ms,
+                                 "device_ms": {k: round(cst32[k]["ms"], 4) for k in ("push", "gram", "gram_reduce", "project")}},
             "construct_host_push": host_push,
             "construct_end_to_end_ms": e2e,
             "construct_end_to_end_note": "subspace_construction(model, mse, DataLoader(batchsize = B), ADAM; T = 100, M = 20) through "

@@ -128,6 +128,13 @@ int32_t si_construct_begin(si_ctx* ctx, int64_t N, int64_t K_capacity, int32_t m
  * reference's docs describe ("Initialize ... W_swa = W_0", docs/src/nn_example.md:44) but its code does not do (:31).
  * Call right after si_construct_begin.                                                                             */
 int32_t si_construct_set_mean(si_ctx* ctx, const void* w_host, int32_t w_dtype);
+/* NON-DEFAULT option: store the deviation matrix in fp32.  The reference keeps A in Float64
+ * (src/subspace_construction.jl:33,51-52); with a_dtype = SI_F32 every column w - W_swa is still FORMED in fp64 and rounded
+ * once on the way to memory, while W_swa, the Gram matrix, its eigen-decomposition and P stay fp64.  Halves the memory of A
+ * (BASELINE cfg5: 52 -> 26 GB) and the bytes the Gram / projection kernels stream.  Measured against the fp64 oracle
+ * (tests/test_gpu_a32.py): W_swa bit-exact, singular values rtol 1e-6, P up to sign 1e-5 of its scale (north_star: 1e-4).
+ * Call right after si_construct_begin, before the first push; si_construct_get_A returns the stored (rounded) columns.   */
+int32_t si_construct_set_storage(si_ctx* ctx, int32_t a_dtype);
 /* :45-52  W = extract_params(ps); n = i/c; W_swa = (n.*W_swa + W)./(n+1); W_dev = W - W_swa;
  * append!(A, W_dev).  `n` is supplied by the caller (it is the EPOCH counter i/c, repeated for every
  * batch of the epoch).  w has N elements of w_dtype.

@@ -130,6 +130,7 @@ SIGNATURES = {
     "si_host_sym_eig_top": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "si_host_jacobi_eig_psd": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
     "si_set_chain_loop": (c_int32, [c_void_p, c_int32]),
+    "si_construct_set_storage": (c_int32, [c_void_p, c_int32]),
     "si_host_cpu_budget": (c_int, []),
     "si_host_parse_cpu_max": (c_double, [c_char_p]),
     "si_host_copy_plan": (c_int, [c_int, c_int, c_char_p]),
@@ -347,6 +348,10 @@ class Context:
     def construct_begin(self, n, k_capacity, max_cols=0):
         self._check(self.lib.si_construct_begin(self.h, int(n), int(k_capacity), int(max_cols)))
         self._n = int(n)
+
+    def construct_set_storage(self, a_dtype):
+        """SI_F32: keep the deviation matrix in fp32 (opt-in); right after construct_begin."""
+        self._check(self.lib.si_construct_set_storage(self.h, int(a_dtype)))
 
     def construct_set_mean(self, w):
         """non-default init = :pretrained (Q1): W_swa starts at w instead of zeros"""

@@ -29,7 +29,7 @@ def _alg_name(alg):
 
 def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, *, device=0, ctx=None,
                           max_cols=0, verbose=True, keep_on_device=False, device_training="auto", init="zeros",
-                          data_parallel=False):
+                          data_parallel=False, a_storage="f64"):
     """src/subspace_construction.jl:26-67.
 
     Per batch the host does `gradient` + `update!` (:39-43, caller side) and hands the flattened weights
@@ -44,6 +44,10 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
 
     init ("zeros" | "pretrained"): "zeros" is what the reference's CODE does (W_swa = zeros, :31 -- quirk Q1, the default);
     "pretrained" starts the running mean at the model's weights, as the reference's docs describe (nn_example.md:44).
+
+    a_storage ("f64" | "f32"): "f64" keeps the deviation matrix in Float64 like the reference (:33,51-52); "f32" (opt-in,
+    SURVEY section 0 Q6) stores every column rounded once to Float32 -- half the memory and half the bytes of the Gram /
+    projection kernels, P within 1e-5 of the Float64 result (tests/test_gpu_a32.py).
 
     data_parallel=True (opt-in; needs a ctx with an RCCL communicator -- one process per GPU, dist.comm_init -- or a torch
     process group) makes the device training step data-parallel: EVERY rank must make this call with the same model, data
@@ -70,6 +74,10 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
     ctx, own = _get_ctx(ctx, device)
     try:
         ctx.construct_begin(n_par, n_push, max_cols)
+        if a_storage not in ("f64", "f32"):
+            raise SubspaceError("a_storage must be \"f64\" (the reference) or \"f32\"")
+        if a_storage == "f32":
+            ctx.construct_set_storage(_capi.SI_F32)
         if _alg_name(init) == "pretrained":
             ctx.construct_set_mean(flux.extract_params(ps))
         elif _alg_name(init) != "zeros":

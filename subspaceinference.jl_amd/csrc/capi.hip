@@ -105,6 +105,9 @@ static void free_construct(Ctx* c) {
   c->c_active = c->c_finished = c->gram_valid = false;
   c->K = c->Kcap = c->N = c->ldA = 0;
   c->a_cols_alloc = 0;
+  c->a_bytes = 0;
+  c->a_zero_dtype = -1;
+  c->a_dtype = SI_F64;
   c->npush = 0;
   c->M_built = 0;
 }
@@ -365,6 +368,33 @@ int32_t si_device_name(si_ctx* ctx, char* buf, int32_t buflen) {
 // =================================================================================================
 // construction
 // =================================================================================================
+// The deviation matrix: ldA x Kcap elements of a_dtype behind d_A.  (Re)allocated when too small; the padding rows [N, ldA) of
+// every column must be zero (the Gram kernels read whole slabs): zeroed whenever the buffer is new or was last used with
+// another element size -- pushes only ever write rows < N, stale columns beyond K are never read.
+static int32_t ensure_A(si_ctx* ctx) {
+  const size_t esz = ctx->a_dtype == SI_F32 ? 4 : 8;
+  const size_t need = (size_t)ctx->ldA * (size_t)ctx->Kcap * esz;
+  if (ctx->d_A == nullptr || ctx->a_bytes < need) {
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_A);
+    ctx->a_bytes = 0;
+    if (dev_alloc(reinterpret_cast<char**>(&ctx->d_A), need) != hipSuccess) {
+      ctx->d_A = nullptr;
+      return fail(ctx, SI_ERR_NOMEM, "si_construct_begin: device allocation of the deviation matrix failed");
+    }
+    ctx->a_bytes = need;
+    ctx->a_zero_dtype = -1;
+  }
+  if (ctx->a_zero_dtype != ctx->a_dtype) {
+    // only the padding rows [N, ldA) of every column (a strided fill of < 64 elements per column, not the whole matrix)
+    if (ctx->ldA > ctx->N)
+      SI_HIP(ctx, hipMemset2DAsync(reinterpret_cast<char*>(ctx->d_A) + (size_t)ctx->N * esz, (size_t)ctx->ldA * esz, 0,
+                                   (size_t)(ctx->ldA - ctx->N) * esz, (size_t)ctx->Kcap, ctx->stream));
+    ctx->a_zero_dtype = ctx->a_dtype;
+  }
+  return SI_OK;
+}
+
 int32_t si_construct_begin(si_ctx* ctx, int64_t N, int64_t K_capacity, int32_t max_cols) {
   CHECK_CTX(ctx);
   if (N <= 0 || K_capacity <= 0 || max_cols < 0)
@@ -372,9 +402,8 @@ int32_t si_construct_begin(si_ctx* ctx, int64_t N, int64_t K_capacity, int32_t m
   BIND(ctx);
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const int64_t kcap = max_cols > 0 ? std::min<int64_t>(max_cols, K_capacity) : K_capacity;
-  if (ctx->d_A != nullptr && ctx->N == N && ctx->a_cols_alloc >= kcap) {
-    // same problem size as the previous construction: keep the buffers (the padding rows of A are still zero --
-    // pushes only ever write rows < N -- and stale columns beyond K are never read)
+  if (ctx->d_swa != nullptr && ctx->N == N) {
+    // same problem size as the previous construction: keep the buffers (ensure_A re-uses A when it is large enough)
     if (ctx->i_ready && ctx->i_swa == ctx->d_swa) free_infer(ctx);  // an inference bound to the old W_swa / P
     ctx->c_finished = ctx->gram_valid = false;
     ctx->K = 0;
@@ -383,20 +412,35 @@ int32_t si_construct_begin(si_ctx* ctx, int64_t N, int64_t K_capacity, int32_t m
     free_construct(ctx);
     ctx->N = N;
     ctx->ldA = pad_ld(N);
-    if (dev_alloc(&ctx->d_swa, (size_t)ctx->ldA) != hipSuccess ||
-        dev_alloc(&ctx->d_A, (size_t)ctx->ldA * (size_t)kcap) != hipSuccess) {
+    if (dev_alloc(&ctx->d_swa, (size_t)ctx->ldA) != hipSuccess) {
       free_construct(ctx);
-      return fail(ctx, SI_ERR_NOMEM, "si_construct_begin: device allocation of W_swa / A failed");
+      return fail(ctx, SI_ERR_NOMEM, "si_construct_begin: device allocation of W_swa failed");
     }
-    ctx->a_cols_alloc = kcap;
-    SI_HIP(ctx, hipMemsetAsync(ctx->d_A, 0, (size_t)ctx->ldA * (size_t)kcap * sizeof(double), ctx->stream));
   }
   ctx->max_cols = max_cols;
   ctx->Kcap = kcap;
+  ctx->a_dtype = SI_F64;   // the reference's storage (A = Array{Float64}); si_construct_set_storage changes it before the first push
+  {
+    const int32_t arc = ensure_A(ctx);   // allocated here (not at the first push) so that an out-of-memory shows at begin
+    if (arc != SI_OK) return arc;
+  }
   // W_swa = zeros(N)  (reference :31, quirk Q1: NOT the pretrained weights)
   SI_HIP(ctx, hipMemsetAsync(ctx->d_swa, 0, (size_t)ctx->ldA * sizeof(double), ctx->stream));
   ctx->c_active = true;
   return SI_OK;
+}
+
+// NON-DEFAULT option ("fp32 storage is an opt-in bandwidth optimisation that must still meet rtol 1e-4"):
+// the deviation columns w - W_swa are formed in fp64 and stored rounded once to fp32; W_swa, the Gram matrix, the eigen-
+// decomposition and P stay fp64.  Halves the memory of A (cfg5: 52 -> 26 GB) and the bytes K2 / K3 stream.
+int32_t si_construct_set_storage(si_ctx* ctx, int32_t a_dtype) {
+  CHECK_CTX(ctx);
+  if (!ctx->c_active || ctx->npush != 0)
+    return fail(ctx, SI_ERR_STATE, "si_construct_set_storage: call right after si_construct_begin, before the first push");
+  if (a_dtype != SI_F32 && a_dtype != SI_F64) return fail(ctx, SI_ERR_INVALID, "si_construct_set_storage: SI_F64 (the reference) or SI_F32");
+  BIND(ctx);
+  ctx->a_dtype = a_dtype;
+  return ensure_A(ctx);
 }
 
 int32_t si_construct_set_mean(si_ctx* ctx, const void* w_host, int32_t w_dtype) {
@@ -434,11 +478,11 @@ static int32_t push_common(si_ctx* ctx, const void* w_dev, int32_t w_dtype, doub
     if (ctx->K >= ctx->Kcap) return fail(ctx, SI_ERR_STATE, "si_construct_push: more pushes than K_capacity");
     slot = ctx->K;
   }
-  const size_t wsz = w_dtype == SI_F32 ? 4 : 8;
+  const size_t wsz = w_dtype == SI_F32 ? 4 : 8, asz = ctx->a_dtype == SI_F32 ? 4 : 8;
   {
-    ProfScope ps(ctx, SI_K_PUSH, 4.0 * (double)ctx->N, (double)ctx->N * (double)(wsz + 24));
-    launch_swa_dev_push(ctx->stream, w_dev, w_dtype, ctx->d_swa, ctx->d_A + slot * ctx->ldA, ctx->N, n,
-                        ctx->num_cu);
+    ProfScope ps(ctx, SI_K_PUSH, 4.0 * (double)ctx->N, (double)ctx->N * (double)(wsz + 16 + asz));
+    launch_swa_dev_push(ctx->stream, w_dev, w_dtype, ctx->d_swa, reinterpret_cast<char*>(ctx->d_A) + (size_t)slot * ctx->ldA * asz,
+                        ctx->N, n, ctx->num_cu, ctx->a_dtype);
   }
   SI_HIP(ctx, hipGetLastError());
   ctx->npush += 1;
@@ -479,9 +523,9 @@ int32_t si_construct_push_batch_dev(si_ctx* ctx, const void* w_dev, int32_t w_dt
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));  // n_host is caller-owned and only valid during the call
   const size_t wsz = w_dtype == SI_F32 ? 4 : 8;
   {
-    ProfScope ps(ctx, SI_K_PUSH, 4.0 * (double)ctx->N * count, (double)ctx->N * ((double)count * (wsz + 8) + 16.0));
+    ProfScope ps(ctx, SI_K_PUSH, 4.0 * (double)ctx->N * count, (double)ctx->N * ((double)count * (wsz + (ctx->a_dtype == SI_F32 ? 4 : 8)) + 16.0));
     launch_swa_dev_push_batch(ctx->stream, w_dev, w_dtype, ld, ctx->d_swa, ctx->d_A, ctx->ldA, ctx->N, count,
-                              ctx->d_nvals, ctx->max_cols > 0 ? ctx->npush % ctx->Kcap : ctx->K, ctx->Kcap, ctx->num_cu);
+                              ctx->d_nvals, ctx->max_cols > 0 ? ctx->npush % ctx->Kcap : ctx->K, ctx->Kcap, ctx->num_cu, ctx->a_dtype);
   }
   SI_HIP(ctx, hipGetLastError());
   ctx->npush += count;
@@ -555,7 +599,7 @@ int32_t si_construct_gram(si_ctx* ctx) {
   if (!ctx->c_active || ctx->K <= 0) return fail(ctx, SI_ERR_STATE, "si_construct_gram: nothing pushed");
   BIND(ctx);
   const int64_t K = ctx->K;
-  const size_t need = launch_gram(ctx->stream, ctx->d_A, ctx->ldA, ctx->N, K, nullptr, nullptr, ctx->num_cu, nullptr);
+  const size_t need = launch_gram(ctx->stream, ctx->d_A, ctx->ldA, ctx->N, K, nullptr, nullptr, ctx->num_cu, nullptr, ctx->a_dtype);
   if (ctx->gpart_bytes < need) {
     SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     dev_free(ctx->d_Gpart);
@@ -573,7 +617,7 @@ int32_t si_construct_gram(si_ctx* ctx) {
       return fail(ctx, SI_ERR_NOMEM, "si_construct_gram: G allocation failed");
     ctx->g_cap = K * K;
   }
-  launch_gram(ctx->stream, ctx->d_A, ctx->ldA, ctx->N, K, ctx->d_Gpart, ctx->d_G, ctx->num_cu, ctx);
+  launch_gram(ctx->stream, ctx->d_A, ctx->ldA, ctx->N, K, ctx->d_Gpart, ctx->d_G, ctx->num_cu, ctx, ctx->a_dtype);
   SI_HIP(ctx, hipGetLastError());
   ctx->gram_valid = true;
   if (ctx->refine_stage != 0 || ctx->d_B) {  // a fresh first-stage Gram: drop the second stage of an earlier finish
@@ -733,7 +777,7 @@ int32_t si_construct_refine(si_ctx* ctx) {
   SI_HIP(ctx, hipMemcpyAsync(ctx->d_V, V, (size_t)K * Kpad * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   {
     ProfScope ps(ctx, SI_K_PROJECT, 2.0 * (double)N * (double)K * (double)K, (double)N * (double)(2 * K) * 8.0);
-    launch_project(ctx->stream, ctx->d_A, ctx->ldA, N, K, ctx->d_V, (int32_t)K, Kpad, ctx->d_B, ctx->ldA, ctx->num_cu);
+    launch_project(ctx->stream, ctx->d_A, ctx->ldA, N, K, ctx->d_V, (int32_t)K, Kpad, ctx->d_B, ctx->ldA, ctx->num_cu, ctx->a_dtype);
   }
   launch_gram(ctx->stream, ctx->d_B, ctx->ldA, N, K, ctx->d_Gpart, ctx->d_G, ctx->num_cu, ctx);
   SI_HIP(ctx, hipGetLastError());
@@ -790,7 +834,7 @@ static int32_t finish_wide(si_ctx* ctx, int32_t M, bool* done) {
   }
   {
     ProfScope ps(ctx, SI_K_PUSH, 0.0, 16.0 * (double)N * (double)K);
-    launch_transpose(ctx->stream, ctx->d_A, ctx->ldA, N, K, ctx->d_At, ldt);
+    launch_transpose(ctx->stream, ctx->d_A, ctx->a_dtype, ctx->ldA, N, K, ctx->d_At, ldt);
   }
   launch_gram(ctx->stream, ctx->d_At, ldt, K, N, ctx->d_Gpart, ctx->d_G, ctx->num_cu, ctx);   // N x N: A A'
   SI_HIP(ctx, hipGetLastError());
@@ -935,8 +979,10 @@ int32_t si_construct_finish(si_ctx* ctx, int32_t M, double* W_swa_out, double* P
   if ((rc = ensure_V(ctx, std::max(v_elems, (size_t)K * project_mpad((int)K) * (ctx->refine_stage ? 1 : 0)))) != SI_OK) return rc;
   SI_HIP(ctx, hipMemcpyAsync(ctx->d_V, V, v_elems * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   {
-    ProfScope ps(ctx, SI_K_PROJECT, 2.0 * (double)N * (double)K * (double)M, (double)N * (double)(K + M) * 8.0);
-    launch_project(ctx->stream, src, ctx->ldA, N, K, ctx->d_V, M, Mpad, ctx->d_P, ctx->ldA, ctx->num_cu);
+    ProfScope ps(ctx, SI_K_PROJECT, 2.0 * (double)N * (double)K * (double)M,
+                 (double)N * ((double)K * ((src == ctx->d_A && ctx->a_dtype == SI_F32) ? 4.0 : 8.0) + (double)M * 8.0));
+    launch_project(ctx->stream, src, ctx->ldA, N, K, ctx->d_V, M, Mpad, ctx->d_P, ctx->ldA, ctx->num_cu,
+                   src == ctx->d_A ? ctx->a_dtype : SI_F64);
   }
   SI_HIP(ctx, hipGetLastError());
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the pinned V may be rewritten by the next finish
@@ -975,6 +1021,15 @@ int32_t si_construct_get_A(si_ctx* ctx, int64_t k0, int64_t nk, double* A_out) {
   if (k0 < 0 || nk < 0 || k0 + nk > ctx->K || !A_out) return fail(ctx, SI_ERR_INVALID, "si_construct_get_A: bad range");
   BIND(ctx);
   if (nk == 0) return SI_OK;
+  if (ctx->a_dtype == SI_F32) {   // fp32 storage: read the floats back and widen them (exact)
+    std::vector<float> tmp((size_t)ctx->N * (size_t)nk);
+    SI_HIP(ctx, hipMemcpy2DAsync(tmp.data(), (size_t)ctx->N * sizeof(float), reinterpret_cast<const float*>(ctx->d_A) + k0 * ctx->ldA,
+                                 (size_t)ctx->ldA * sizeof(float), (size_t)ctx->N * sizeof(float), (size_t)nk, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < tmp.size(); ++i) A_out[i] = (double)tmp[i];
+    return SI_OK;
+  }
   SI_HIP(ctx, hipMemcpy2DAsync(A_out, (size_t)ctx->N * sizeof(double), ctx->d_A + k0 * ctx->ldA,
                                (size_t)ctx->ldA * sizeof(double), (size_t)ctx->N * sizeof(double), (size_t)nk,
                                hipMemcpyDeviceToHost, ctx->stream));

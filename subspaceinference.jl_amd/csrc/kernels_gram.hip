@@ -13,6 +13,18 @@ namespace si {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// two consecutive rows of one column of A as doubles, whatever A is stored in (fp64: the reference; fp32: the opt-in storage of
+// SURVEY section 0 Q6 -- half the bytes of the kernels whose time follows the bytes of A; the arithmetic stays fp64)
+template <typename AT>
+__device__ __forceinline__ double2 load_a2(const AT* p) {
+  if constexpr (sizeof(AT) == 8) {
+    return *reinterpret_cast<const double2*>(p);
+  } else {
+    const float2 f = *reinterpret_cast<const float2*>(p);
+    return make_double2((double)f.x, (double)f.y);
+  }
+}
+
 constexpr int GR = 32;   // slab rows
 constexpr int GRP = 34;  // padded column stride in LDS (68 dwords): lane l reads column l&15, row 4s + (l>>4), i.e. dword
                          // banks 4*col + 2*row (mod 64) -- distinct inside each 32-lane half for ds_read_b64.  Measured
@@ -108,8 +120,8 @@ struct GramWave {
 
 // whole workgroup loop for wave W: the accumulators of a wave never meet another wave's code path, so there is no
 // register shuffling at the joins.  All eight paths execute the same barriers (s_barrier counts arrivals per workgroup).
-template <int NT, int W>
-__device__ __forceinline__ void gram_small_body(const double* __restrict__ A, int64_t ldA, int64_t N, int K,
+template <int NT, int W, typename AT>
+__device__ __forceinline__ void gram_small_body(const AT* __restrict__ A, int64_t ldA, int64_t N, int K,
                                                 int col0, double* __restrict__ Gpart, double* sA) {
   constexpr int NC = NT * 16;
   constexpr int NLD = (NC + 31) / 32;  // staging passes: 512 threads cover 32 columns x 32 rows with 16 B per lane
@@ -118,14 +130,14 @@ __device__ __forceinline__ void gram_small_body(const double* __restrict__ A, in
   const int q = lane >> 4, c = lane & 15;
   const int srow = (lane & 15) * 2;            // 16 lanes x 2 rows = one 32-row column
   const int scol0 = W * 4 + (lane >> 4);       // 4 columns per wave per pass
-  const double* Arow = A + srow;
+  const AT* Arow = A + srow;
   double2 rg[NLD];
   auto load_slab = [&](int64_t slab) {
-    const double* base = Arow + slab * GR;
+    const AT* base = Arow + slab * GR;
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
       const int g = col0 + scol0 + p * 32;
-      rg[p] = *reinterpret_cast<const double2*>(base + (int64_t)(g < K ? g : K - 1) * ldA);
+      rg[p] = load_a2<AT>(base + (int64_t)(g < K ? g : K - 1) * ldA);
     }
   };
   auto store_slab = [&](double* dst) {
@@ -180,22 +192,22 @@ __device__ __forceinline__ void gram_small_body(const double* __restrict__ A, in
   GramWave<NT, W>::store(Gpart + (int64_t)blockIdx.x * (NT * (NT + 1) / 2) * 256, acc, q, c);
 }
 
-template <int NT>
+template <int NT, typename AT>
 #ifndef GS_MINW
 #define GS_MINW 4
 #endif
-__global__ __launch_bounds__(512, GS_MINW) void gram_small_kernel(const double* __restrict__ A, int64_t ldA, int64_t N,
+__global__ __launch_bounds__(512, GS_MINW) void gram_small_kernel(const AT* __restrict__ A, int64_t ldA, int64_t N,
                                                                   int K, int col0, double* __restrict__ Gpart) {
   extern __shared__ double sA[];  // [2][NT*16][GRP]
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-    case 0: gram_small_body<NT, 0>(A, ldA, N, K, col0, Gpart, sA); break;
-    case 1: gram_small_body<NT, 1>(A, ldA, N, K, col0, Gpart, sA); break;
-    case 2: gram_small_body<NT, 2>(A, ldA, N, K, col0, Gpart, sA); break;
-    case 3: gram_small_body<NT, 3>(A, ldA, N, K, col0, Gpart, sA); break;
-    case 4: gram_small_body<NT, 4>(A, ldA, N, K, col0, Gpart, sA); break;
-    case 5: gram_small_body<NT, 5>(A, ldA, N, K, col0, Gpart, sA); break;
-    case 6: gram_small_body<NT, 6>(A, ldA, N, K, col0, Gpart, sA); break;
-    default: gram_small_body<NT, 7>(A, ldA, N, K, col0, Gpart, sA); break;
+    case 0: gram_small_body<NT, 0, AT>(A, ldA, N, K, col0, Gpart, sA); break;
+    case 1: gram_small_body<NT, 1, AT>(A, ldA, N, K, col0, Gpart, sA); break;
+    case 2: gram_small_body<NT, 2, AT>(A, ldA, N, K, col0, Gpart, sA); break;
+    case 3: gram_small_body<NT, 3, AT>(A, ldA, N, K, col0, Gpart, sA); break;
+    case 4: gram_small_body<NT, 4, AT>(A, ldA, N, K, col0, Gpart, sA); break;
+    case 5: gram_small_body<NT, 5, AT>(A, ldA, N, K, col0, Gpart, sA); break;
+    case 6: gram_small_body<NT, 6, AT>(A, ldA, N, K, col0, Gpart, sA); break;
+    default: gram_small_body<NT, 7, AT>(A, ldA, N, K, col0, Gpart, sA); break;
   }
 }
 
@@ -234,15 +246,15 @@ __global__ __launch_bounds__(1024) void gram_small_reduce_kernel(const double* _
   }
 }
 
-template <int NT>
-static void launch_gram_small(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, int col0, double* Gpart,
+template <int NT, typename AT>
+static void launch_gram_small(hipStream_t st, const AT* A, int64_t ldA, int64_t N, int K, int col0, double* Gpart,
                               double* G, int nblocks, Ctx* prof, double flops, double bytes) {
   constexpr size_t lds = (size_t)2 * NT * 16 * GRP * sizeof(double);
   static LdsOptIn optin;
-  optin.ensure(reinterpret_cast<const void*>(gram_small_kernel<NT>), lds);
+  optin.ensure(reinterpret_cast<const void*>(gram_small_kernel<NT, AT>), lds);
   {
     ProfScope ps(prof, SI_K_GRAM, flops, bytes);
-    hipLaunchKernelGGL(gram_small_kernel<NT>, dim3(nblocks), dim3(512), lds, st, A, ldA, N, K, col0, Gpart);
+    hipLaunchKernelGGL((gram_small_kernel<NT, AT>), dim3(nblocks), dim3(512), lds, st, A, ldA, N, K, col0, Gpart);
   }
   {
     ProfScope ps(prof, SI_K_GRAM_RED, 0.0, (double)nblocks * NT * (NT + 1) / 2 * 256 * 8.0);
@@ -260,8 +272,8 @@ static void launch_gram_small(hipStream_t st, const double* A, int64_t ldA, int6
 constexpr int GR2 = 32;   // slab rows of the off-diagonal kernel
 constexpr int GRP2 = 34;  // 68 dwords per column: operand reads touch banks 4c + 2q (mod 64), conflict-free
 
-template <int NTJ>
-__global__ __launch_bounds__(512, 4) void gram_off_kernel(const double* __restrict__ A, int64_t ldA, int64_t N, int K,
+template <int NTJ, typename AT>
+__global__ __launch_bounds__(512, 4) void gram_off_kernel(const AT* __restrict__ A, int64_t ldA, int64_t N, int K,
                                                           int ci0, int cj0, double* __restrict__ Gpart) {
   extern __shared__ double sA[];  // [(8 + NTJ) * 16][GRP2]: panel I columns first, then panel J
   constexpr int NC = (8 + NTJ) * 16;
@@ -271,16 +283,16 @@ __global__ __launch_bounds__(512, 4) void gram_off_kernel(const double* __restri
   const int q = lane >> 4, c = lane & 15;
   const int srow = (tid & 15) * 2;  // 16 lanes x 2 rows = one 32-row column
   const int scol0 = tid >> 4;       // 0..31
-  const double* Arow = A + srow;
+  const AT* Arow = A + srow;
   double2 rg[NLD];
   auto gcol = [&](int lc) { return lc < 128 ? ci0 + lc : cj0 + (lc - 128); };
   auto load_slab = [&](int64_t slab) {
-    const double* base = Arow + slab * GR2;
+    const AT* base = Arow + slab * GR2;
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
       const int lc = scol0 + p * 32;
       const int g = gcol(lc < NC ? lc : 0);
-      rg[p] = *reinterpret_cast<const double2*>(base + (int64_t)(g < K ? g : K - 1) * ldA);
+      rg[p] = load_a2<AT>(base + (int64_t)(g < K ? g : K - 1) * ldA);
     }
   };
   auto store_slab = [&]() {
@@ -348,15 +360,15 @@ __global__ __launch_bounds__(256) void gram_off_reduce_kernel(const double* __re
   }
 }
 
-template <int NTJ>
-static void launch_gram_off(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, int ci0, int cj0, double* Gpart,
+template <int NTJ, typename AT>
+static void launch_gram_off(hipStream_t st, const AT* A, int64_t ldA, int64_t N, int K, int ci0, int cj0, double* Gpart,
                             double* G, int nblocks, Ctx* prof, double flops, double bytes) {
   constexpr size_t lds = (size_t)(8 + NTJ) * 16 * GRP2 * sizeof(double);
   static LdsOptIn optin;
-  optin.ensure(reinterpret_cast<const void*>(gram_off_kernel<NTJ>), lds);
+  optin.ensure(reinterpret_cast<const void*>(gram_off_kernel<NTJ, AT>), lds);
   {
     ProfScope ps(prof, SI_K_GRAM, flops, bytes);
-    hipLaunchKernelGGL(gram_off_kernel<NTJ>, dim3(nblocks), dim3(512), lds, st, A, ldA, N, K, ci0, cj0, Gpart);
+    hipLaunchKernelGGL((gram_off_kernel<NTJ, AT>), dim3(nblocks), dim3(512), lds, st, A, ldA, N, K, ci0, cj0, Gpart);
   }
   {
     ProfScope ps(prof, SI_K_GRAM_RED, 0.0, (double)nblocks * 8 * NTJ * 256 * 8.0);
@@ -364,31 +376,33 @@ static void launch_gram_off(hipStream_t st, const double* A, int64_t ldA, int64_
   }
 }
 
-static void gram_diag_dispatch(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, int col0, int nt, double* Gpart,
+template <typename AT>
+static void gram_diag_dispatch(hipStream_t st, const AT* A, int64_t ldA, int64_t N, int K, int col0, int nt, double* Gpart,
                                double* G, int nblocks, Ctx* prof, double flops, double bytes) {
   switch (nt) {
-    case 1: launch_gram_small<1>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
-    case 2: launch_gram_small<2>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
-    case 3: launch_gram_small<3>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
-    case 4: launch_gram_small<4>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
-    case 5: launch_gram_small<5>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
-    case 6: launch_gram_small<6>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
-    case 7: launch_gram_small<7>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
-    default: launch_gram_small<8>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
+    case 1: launch_gram_small<1, AT>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
+    case 2: launch_gram_small<2, AT>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
+    case 3: launch_gram_small<3, AT>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
+    case 4: launch_gram_small<4, AT>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
+    case 5: launch_gram_small<5, AT>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
+    case 6: launch_gram_small<6, AT>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
+    case 7: launch_gram_small<7, AT>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
+    default: launch_gram_small<8, AT>(st, A, ldA, N, K, col0, Gpart, G, nblocks, prof, flops, bytes); break;
   }
 }
 
-static void gram_off_dispatch(hipStream_t st, const double* A, int64_t ldA, int64_t N, int K, int ci0, int cj0, int ntj,
+template <typename AT>
+static void gram_off_dispatch(hipStream_t st, const AT* A, int64_t ldA, int64_t N, int K, int ci0, int cj0, int ntj,
                               double* Gpart, double* G, int nblocks, Ctx* prof, double flops, double bytes) {
   switch (ntj) {
-    case 1: launch_gram_off<1>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
-    case 2: launch_gram_off<2>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
-    case 3: launch_gram_off<3>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
-    case 4: launch_gram_off<4>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
-    case 5: launch_gram_off<5>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
-    case 6: launch_gram_off<6>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
-    case 7: launch_gram_off<7>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
-    default: launch_gram_off<8>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
+    case 1: launch_gram_off<1, AT>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
+    case 2: launch_gram_off<2, AT>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
+    case 3: launch_gram_off<3, AT>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
+    case 4: launch_gram_off<4, AT>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
+    case 5: launch_gram_off<5, AT>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
+    case 6: launch_gram_off<6, AT>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
+    case 7: launch_gram_off<7, AT>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
+    default: launch_gram_off<8, AT>(st, A, ldA, N, K, ci0, cj0, Gpart, G, nblocks, prof, flops, bytes); break;
   }
 }
 
@@ -468,35 +482,46 @@ static bool gram_force_panels() {
 static constexpr bool gram_force_panels() { return false; }
 #endif
 
-size_t launch_gram(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, double* Gpart,
-                   double* G, int num_cu, Ctx* prof) {
+template <typename AT>
+static void gram_panels(hipStream_t st, const AT* A, int64_t ldA, int64_t N, int64_t K, double* Gpart, double* G, int64_t nb_diag,
+                        int64_t nb_off, int npan, Ctx* prof, double tot_flops, double tot_bytes) {
+  bool first = true;
+  for (int I = 0; I < npan; ++I) {
+    const int ci0 = I * 128;
+    const int nti = (int)((std::min<int64_t>(K, ci0 + 128) - ci0 + 15) / 16);
+    // the algorithmic flops / bytes of the whole Gram are booked on the first launch, the rest add time only
+    gram_diag_dispatch<AT>(st, A, ldA, N, (int)K, ci0, nti, Gpart, G, (int)nb_diag, prof, first ? tot_flops : 0.0,
+                           first ? tot_bytes : 0.0);
+    first = false;
+    for (int J = I + 1; J < npan; ++J) {
+      const int cj0 = J * 128;
+      const int ntj = (int)((std::min<int64_t>(K, cj0 + 128) - cj0 + 15) / 16);
+      gram_off_dispatch<AT>(st, A, ldA, N, (int)K, ci0, cj0, ntj, Gpart, G, (int)nb_off, prof, 0.0, 0.0);
+    }
+  }
+}
+
+// a_dtype = SI_F32: A holds floats (ldA in elements); the register-staged panel kernels widen them on the way to LDS
+size_t launch_gram(hipStream_t st, const void* Av, int64_t ldA, int64_t N, int64_t K, double* Gpart,
+                   double* G, int num_cu, Ctx* prof, int32_t a_dtype) {
+  const double* A = static_cast<const double*>(Av);
   // workspace: the largest single launch (an off-diagonal pair of full panels: 64 tiles per block)
   const int64_t nslab_d = (N + GR - 1) / GR, nslab_o = (N + GR2 - 1) / GR2;
   int64_t nb_diag = std::min<int64_t>((int64_t)num_cu * 2, nslab_d);
   int64_t nb_off = std::min<int64_t>((int64_t)num_cu * 2, nslab_o);
   const int npan = (int)((K + 127) / 128);
   const int ntw = (int)((K + 15) / 16);
-  const bool wave_path = ntw <= 13 && !gram_force_panels();
+  const bool wave_path = ntw <= 13 && !gram_force_panels() && a_dtype != SI_F32;
   const int64_t nb_wave = std::min<int64_t>((int64_t)num_cu * gram_wave_blocks_per_cu(ntw), nslab_d);
   const size_t need = wave_path ? ((size_t)nb_wave + GR2_Y) * (size_t)(ntw * (ntw + 1) / 2) * 256 * sizeof(double)
                                 : (size_t)std::max<int64_t>(nb_diag * 36, npan > 1 ? nb_off * 64 : 0) * 256 * sizeof(double);
   if (Gpart == nullptr) return need;
-  const double tot_flops = (double)N * (double)K * (double)(K + 1), tot_bytes = (double)N * (double)K * 8.0;
+  const double tot_flops = (double)N * (double)K * (double)(K + 1), tot_bytes = (double)N * (double)K * (a_dtype == SI_F32 ? 4.0 : 8.0);
   if (wave_path && gram_wave_dispatch(st, A, ldA, N, (int)K, Gpart, G, (int)nb_wave, prof, tot_flops, tot_bytes)) return need;
-  bool first = true;
-  for (int I = 0; I < npan; ++I) {
-    const int ci0 = I * 128;
-    const int nti = (int)((std::min<int64_t>(K, ci0 + 128) - ci0 + 15) / 16);
-    // the algorithmic flops / bytes of the whole Gram are booked on the first launch, the rest add time only
-    gram_diag_dispatch(st, A, ldA, N, (int)K, ci0, nti, Gpart, G, (int)nb_diag, prof, first ? tot_flops : 0.0,
-                       first ? tot_bytes : 0.0);
-    first = false;
-    for (int J = I + 1; J < npan; ++J) {
-      const int cj0 = J * 128;
-      const int ntj = (int)((std::min<int64_t>(K, cj0 + 128) - cj0 + 15) / 16);
-      gram_off_dispatch(st, A, ldA, N, (int)K, ci0, cj0, ntj, Gpart, G, (int)nb_off, prof, 0.0, 0.0);
-    }
-  }
+  if (a_dtype == SI_F32)
+    gram_panels<float>(st, static_cast<const float*>(Av), ldA, N, K, Gpart, G, nb_diag, nb_off, npan, prof, tot_flops, tot_bytes);
+  else
+    gram_panels<double>(st, A, ldA, N, K, Gpart, G, nb_diag, nb_off, npan, prof, tot_flops, tot_bytes);
   return need;
 }
 
@@ -506,8 +531,8 @@ size_t launch_gram(hipStream_t st, const double* A, int64_t ldA, int64_t N, int6
 // wave per column of A) and MT accumulators per row; V[k][m] is wave-uniform and comes through scalar loads.
 // Algorithmic bytes: N*(K+M)*8.
 // ------------------------------------------------------------------------------------------------
-template <int MT>
-__global__ __launch_bounds__(256) void project_kernel(const double* __restrict__ A, int64_t ldA, int64_t N,
+template <int MT, typename AT>
+__global__ __launch_bounds__(256) void project_kernel(const AT* __restrict__ A, int64_t ldA, int64_t N,
                                                       int K, const double* __restrict__ V, int Mpad,
                                                       int m0, int M, double* __restrict__ P, int64_t ldP) {
   const int64_t npair = (N + 1) >> 1;
@@ -519,7 +544,7 @@ __global__ __launch_bounds__(256) void project_kernel(const double* __restrict__
     for (int j = 0; j < MT; ++j) acc[j] = make_double2(0.0, 0.0);
 #pragma unroll 2
     for (int k = 0; k < K; ++k) {
-      const double2 av = *reinterpret_cast<const double2*>(A + r + (int64_t)k * ldA);
+      const double2 av = load_a2<AT>(A + r + (int64_t)k * ldA);
       const double* vk = V + (int64_t)k * Mpad + m0;
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
@@ -556,15 +581,9 @@ int project_mpad(int M) {
   return m0;
 }
 
-void launch_project(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, const double* V,
-                    int32_t M, int32_t Mpad, double* P, int64_t ldP, int num_cu) {
-  if (M > 32) {  // wide subspace: one pass over A on the matrix cores instead of ceil(M/32) VALU passes
-    if (!project_force_gemm() && launch_project_stream(st, A, ldA, N, K, V, M, Mpad, P, ldP, num_cu)) return;  // K <= 128: slab stream
-    if (N < 0x7fffffff) {
-      launch_project_mfma(st, A, ldA, N, K, V, M, Mpad, P, ldP);
-      return;
-    }
-  }
+template <typename AT>
+static void project_valu(hipStream_t st, const AT* A, int64_t ldA, int64_t N, int64_t K, const double* V, int32_t M, int32_t Mpad,
+                         double* P, int64_t ldP, int num_cu) {
   int64_t blocks = (((N + 1) >> 1) + 255) / 256;
   if (blocks > (int64_t)num_cu * 8) blocks = (int64_t)num_cu * 8;
   if (blocks < 1) blocks = 1;
@@ -572,19 +591,36 @@ void launch_project(hipStream_t st, const double* A, int64_t ldA, int64_t N, int
   while (m0 < M) {
     const int rem = M - m0;
     if (rem > 24) {
-      hipLaunchKernelGGL((project_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP);
+      hipLaunchKernelGGL((project_kernel<32, AT>), dim3((unsigned)blocks), dim3(256), 0, st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP);
       m0 += 32;
     } else if (rem > 16) {
-      hipLaunchKernelGGL((project_kernel<24>), dim3((unsigned)blocks), dim3(256), 0, st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP);
+      hipLaunchKernelGGL((project_kernel<24, AT>), dim3((unsigned)blocks), dim3(256), 0, st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP);
       m0 += 24;
     } else if (rem > 8) {
-      hipLaunchKernelGGL((project_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP);
+      hipLaunchKernelGGL((project_kernel<16, AT>), dim3((unsigned)blocks), dim3(256), 0, st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP);
       m0 += 16;
     } else {
-      hipLaunchKernelGGL((project_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP);
+      hipLaunchKernelGGL((project_kernel<8, AT>), dim3((unsigned)blocks), dim3(256), 0, st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP);
       m0 += 8;
     }
   }
+}
+
+void launch_project(hipStream_t st, const void* Av, int64_t ldA, int64_t N, int64_t K, const double* V,
+                    int32_t M, int32_t Mpad, double* P, int64_t ldP, int num_cu, int32_t a_dtype) {
+  if (a_dtype == SI_F32) {   // fp32-stored A: the streaming kernel in passes of <= 32 columns (HBM-bound: half the bytes per pass)
+    project_valu<float>(st, static_cast<const float*>(Av), ldA, N, K, V, M, Mpad, P, ldP, num_cu);
+    return;
+  }
+  const double* A = static_cast<const double*>(Av);
+  if (M > 32) {  // wide subspace: one pass over A on the matrix cores instead of ceil(M/32) VALU passes
+    if (!project_force_gemm() && launch_project_stream(st, A, ldA, N, K, V, M, Mpad, P, ldP, num_cu)) return;  // K <= 128: slab stream
+    if (N < 0x7fffffff) {
+      launch_project_mfma(st, A, ldA, N, K, V, M, Mpad, P, ldP);
+      return;
+    }
+  }
+  project_valu<double>(st, A, ldA, N, K, V, M, Mpad, P, ldP, num_cu);
 }
 
 }  // namespace si

@@ -14,22 +14,24 @@ namespace si {
 // Layout: s and the A column are 256-B aligned (padded leading dimension), so 16-B accesses are legal;
 // each thread handles 4 consecutive elements per iteration (16 B of f32 w / 2 x 16 B of f64).
 // ------------------------------------------------------------------------------------------------
-template <typename WT>
+// AT = element type of the deviation matrix: double (the reference: A = Array{Float64}, src/subspace_construction.jl:33,51-52) or
+// float (the opt-in storage of SURVEY section 0 Q6: the column w - W_swa is formed in fp64 and rounded ONCE; W_swa itself stays fp64)
+template <typename WT, typename AT>
 __device__ __forceinline__ void push_one(const WT* __restrict__ w, double* __restrict__ s,
-                                         double* __restrict__ acol, int64_t i, double n, double np1) {
+                                         AT* __restrict__ acol, int64_t i, double n, double np1) {
 #pragma clang fp contract(off)
   const double wv = (double)w[i];
   const double t = n * s[i];
   const double u = t + wv;
   const double sn = u / np1;
   s[i] = sn;
-  acol[i] = wv - sn;
+  acol[i] = (AT)(wv - sn);
 }
 
-template <typename WT, bool W_ALIGNED>
+template <typename WT, bool W_ALIGNED, typename AT>
 __global__ __launch_bounds__(256) void swa_dev_push_kernel(const WT* __restrict__ w,
                                                            double* __restrict__ s,
-                                                           double* __restrict__ acol, int64_t N,
+                                                           AT* __restrict__ acol, int64_t N,
                                                            double n, double np1) {
 #pragma clang fp contract(off)
   const int64_t nquad = N >> 2;
@@ -63,13 +65,17 @@ __global__ __launch_bounds__(256) void swa_dev_push_kernel(const WT* __restrict_
     }
     *reinterpret_cast<double2*>(s + i) = make_double2(sn[0], sn[1]);
     *reinterpret_cast<double2*>(s + i + 2) = make_double2(sn[2], sn[3]);
-    *reinterpret_cast<double2*>(acol + i) = make_double2(dv[0], dv[1]);
-    *reinterpret_cast<double2*>(acol + i + 2) = make_double2(dv[2], dv[3]);
+    if constexpr (sizeof(AT) == 8) {
+      *reinterpret_cast<double2*>(acol + i) = make_double2(dv[0], dv[1]);
+      *reinterpret_cast<double2*>(acol + i + 2) = make_double2(dv[2], dv[3]);
+    } else {
+      *reinterpret_cast<float4*>(acol + i) = make_float4((float)dv[0], (float)dv[1], (float)dv[2], (float)dv[3]);
+    }
   }
   // tail (N mod 4 elements) by the first threads of block 0
   if (blockIdx.x == 0) {
     const int64_t i = (nquad << 2) + threadIdx.x;
-    if (i < N) push_one<WT>(w, s, acol, i, n, np1);
+    if (i < N) push_one<WT, AT>(w, s, acol, i, n, np1);
   }
 }
 
@@ -77,9 +83,9 @@ __global__ __launch_bounds__(256) void swa_dev_push_kernel(const WT* __restrict_
 // stays in registers across the pushes, so the traffic per element drops from count*(s_w+24) to count*(s_w+8)+16 bytes
 // and `count` launches become one.  Same three rounded operations per push, in the same order: bit-identical to
 // `count` calls of swa_dev_push_kernel.  slot_j = (slot0 + j) mod kcap (ring only when max_cols is used).
-template <typename WT, bool VEC>
+template <typename WT, bool VEC, typename AT>
 __global__ __launch_bounds__(256) void swa_dev_push_batch_kernel(const WT* __restrict__ w, int64_t ld,
-                                                                 double* __restrict__ s, double* __restrict__ A,
+                                                                 double* __restrict__ s, AT* __restrict__ A,
                                                                  int64_t ldA, int64_t N, int count,
                                                                  const double* __restrict__ nvals, int64_t slot0,
                                                                  int64_t kcap) {
@@ -110,11 +116,15 @@ __global__ __launch_bounds__(256) void swa_dev_push_batch_kernel(const WT* __res
       const double u0 = t0 + w0, u1 = t1 + w1;
       sv.x = u0 / np1;
       sv.y = u1 / np1;
-      double* col = A + ((slot0 + j) % kcap) * ldA + i;
-      if (two)
-        *reinterpret_cast<double2*>(col) = make_double2(w0 - sv.x, w1 - sv.y);
-      else
-        col[0] = w0 - sv.x;
+      AT* col = A + ((slot0 + j) % kcap) * ldA + i;
+      if (two) {
+        if constexpr (sizeof(AT) == 8)
+          *reinterpret_cast<double2*>(col) = make_double2(w0 - sv.x, w1 - sv.y);
+        else
+          *reinterpret_cast<float2*>(col) = make_float2((float)(w0 - sv.x), (float)(w1 - sv.y));
+      } else {
+        col[0] = (AT)(w0 - sv.x);
+      }
     }
     if (two)
       *reinterpret_cast<double2*>(s + i) = sv;
@@ -131,29 +141,36 @@ static int stream_grid(int64_t work_items, int num_cu) {
   return (int)blocks;
 }
 
-void launch_swa_dev_push(hipStream_t st, const void* w, int32_t w_dtype, double* s, double* acol,
-                         int64_t N, double n, int num_cu) {
+template <typename AT>
+static void launch_swa_dev_push_t(hipStream_t st, const void* w, int32_t w_dtype, double* s, AT* acol, int64_t N, double n, int num_cu) {
   const int grid = stream_grid(N >> 2, num_cu);
   const bool aligned = (reinterpret_cast<uintptr_t>(w) & 15u) == 0;
   const double np1 = n + 1.0;
   if (w_dtype == SI_F32) {
     const float* wf = static_cast<const float*>(w);
     if (aligned)
-      hipLaunchKernelGGL((swa_dev_push_kernel<float, true>), dim3(grid), dim3(256), 0, st, wf, s, acol, N, n, np1);
+      hipLaunchKernelGGL((swa_dev_push_kernel<float, true, AT>), dim3(grid), dim3(256), 0, st, wf, s, acol, N, n, np1);
     else
-      hipLaunchKernelGGL((swa_dev_push_kernel<float, false>), dim3(grid), dim3(256), 0, st, wf, s, acol, N, n, np1);
+      hipLaunchKernelGGL((swa_dev_push_kernel<float, false, AT>), dim3(grid), dim3(256), 0, st, wf, s, acol, N, n, np1);
   } else {
     const double* wd = static_cast<const double*>(w);
     if (aligned)
-      hipLaunchKernelGGL((swa_dev_push_kernel<double, true>), dim3(grid), dim3(256), 0, st, wd, s, acol, N, n, np1);
+      hipLaunchKernelGGL((swa_dev_push_kernel<double, true, AT>), dim3(grid), dim3(256), 0, st, wd, s, acol, N, n, np1);
     else
-      hipLaunchKernelGGL((swa_dev_push_kernel<double, false>), dim3(grid), dim3(256), 0, st, wd, s, acol, N, n, np1);
+      hipLaunchKernelGGL((swa_dev_push_kernel<double, false, AT>), dim3(grid), dim3(256), 0, st, wd, s, acol, N, n, np1);
   }
 }
+void launch_swa_dev_push(hipStream_t st, const void* w, int32_t w_dtype, double* s, void* acol, int64_t N, double n, int num_cu,
+                         int32_t a_dtype) {
+  if (a_dtype == SI_F32)
+    launch_swa_dev_push_t<float>(st, w, w_dtype, s, static_cast<float*>(acol), N, n, num_cu);
+  else
+    launch_swa_dev_push_t<double>(st, w, w_dtype, s, static_cast<double*>(acol), N, n, num_cu);
+}
 
-void launch_swa_dev_push_batch(hipStream_t st, const void* w, int32_t w_dtype, int64_t ld, double* s, double* A,
-                               int64_t ldA, int64_t N, int count, const double* nvals_dev, int64_t slot0, int64_t kcap,
-                               int num_cu) {
+template <typename AT>
+static void launch_swa_dev_push_batch_t(hipStream_t st, const void* w, int32_t w_dtype, int64_t ld, double* s, AT* A, int64_t ldA,
+                                        int64_t N, int count, const double* nvals_dev, int64_t slot0, int64_t kcap, int num_cu) {
   const int grid = stream_grid((N + 1) >> 1, num_cu);
   const size_t esz = w_dtype == SI_F32 ? 4 : 8;
   // vector loads need every snapshot row 2-element aligned and the last pair of an odd N inside the padded row
@@ -161,16 +178,23 @@ void launch_swa_dev_push_batch(hipStream_t st, const void* w, int32_t w_dtype, i
   if (w_dtype == SI_F32) {
     const float* wf = static_cast<const float*>(w);
     if (vec)
-      hipLaunchKernelGGL((swa_dev_push_batch_kernel<float, true>), dim3(grid), dim3(256), 0, st, wf, ld, s, A, ldA, N, count, nvals_dev, slot0, kcap);
+      hipLaunchKernelGGL((swa_dev_push_batch_kernel<float, true, AT>), dim3(grid), dim3(256), 0, st, wf, ld, s, A, ldA, N, count, nvals_dev, slot0, kcap);
     else
-      hipLaunchKernelGGL((swa_dev_push_batch_kernel<float, false>), dim3(grid), dim3(256), 0, st, wf, ld, s, A, ldA, N, count, nvals_dev, slot0, kcap);
+      hipLaunchKernelGGL((swa_dev_push_batch_kernel<float, false, AT>), dim3(grid), dim3(256), 0, st, wf, ld, s, A, ldA, N, count, nvals_dev, slot0, kcap);
   } else {
     const double* wd = static_cast<const double*>(w);
     if (vec)
-      hipLaunchKernelGGL((swa_dev_push_batch_kernel<double, true>), dim3(grid), dim3(256), 0, st, wd, ld, s, A, ldA, N, count, nvals_dev, slot0, kcap);
+      hipLaunchKernelGGL((swa_dev_push_batch_kernel<double, true, AT>), dim3(grid), dim3(256), 0, st, wd, ld, s, A, ldA, N, count, nvals_dev, slot0, kcap);
     else
-      hipLaunchKernelGGL((swa_dev_push_batch_kernel<double, false>), dim3(grid), dim3(256), 0, st, wd, ld, s, A, ldA, N, count, nvals_dev, slot0, kcap);
+      hipLaunchKernelGGL((swa_dev_push_batch_kernel<double, false, AT>), dim3(grid), dim3(256), 0, st, wd, ld, s, A, ldA, N, count, nvals_dev, slot0, kcap);
   }
+}
+void launch_swa_dev_push_batch(hipStream_t st, const void* w, int32_t w_dtype, int64_t ld, double* s, void* A, int64_t ldA, int64_t N,
+                               int count, const double* nvals_dev, int64_t slot0, int64_t kcap, int num_cu, int32_t a_dtype) {
+  if (a_dtype == SI_F32)
+    launch_swa_dev_push_batch_t<float>(st, w, w_dtype, ld, s, static_cast<float*>(A), ldA, N, count, nvals_dev, slot0, kcap, num_cu);
+  else
+    launch_swa_dev_push_batch_t<double>(st, w, w_dtype, ld, s, static_cast<double*>(A), ldA, N, count, nvals_dev, slot0, kcap, num_cu);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -425,14 +449,15 @@ void launch_prior_grad(hipStream_t st, double* g, const double* w, int64_t n, do
 }
 // At[k + ldt*r] = A[r + lda*k]: the deviation matrix transposed, for the K > N route of si_construct_finish (the Gram kernel
 // reads columns: the Gram matrix of A' is A A').  32 x 32 tiles through LDS, both sides coalesced.
-__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ A, int64_t lda, int64_t N, int64_t K,
+template <typename AT>
+__global__ __launch_bounds__(256) void transpose_kernel(const AT* __restrict__ A, int64_t lda, int64_t N, int64_t K,
                                                         double* __restrict__ At, int64_t ldt) {
   __shared__ double tile[32][33];
   const int64_t r0 = (int64_t)blockIdx.x * 32, k0 = (int64_t)blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int j = ty; j < 32; j += 8) {
     const int64_t r = r0 + tx, k = k0 + j;
-    tile[j][tx] = (r < N && k < K) ? A[r + lda * k] : 0.0;
+    tile[j][tx] = (r < N && k < K) ? (double)A[r + lda * k] : 0.0;
   }
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
@@ -440,8 +465,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
     if (k < K && r < N) At[k + ldt * r] = tile[tx][j];
   }
 }
-void launch_transpose(hipStream_t st, const double* A, int64_t lda, int64_t N, int64_t K, double* At, int64_t ldt) {
-  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((N + 31) / 32), (unsigned)((K + 31) / 32)), dim3(256), 0, st, A, lda, N, K, At, ldt);
+void launch_transpose(hipStream_t st, const void* A, int32_t a_dtype, int64_t lda, int64_t N, int64_t K, double* At, int64_t ldt) {
+  const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((K + 31) / 32));
+  if (a_dtype == SI_F32)
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, st, static_cast<const float*>(A), lda, N, K, At, ldt);
+  else
+    hipLaunchKernelGGL(transpose_kernel<double>, grid, dim3(256), 0, st, static_cast<const double*>(A), lda, N, K, At, ldt);
 }
 
 // dst[i] = (double)src[i]  (initial W_swa from Float32 weights: the non-default init = :pretrained option)

@@ -131,7 +131,10 @@ struct Ctx {
   int32_t max_cols = 0;
   int64_t npush = 0;
   double* d_swa = nullptr;    // N (padded) fp64
-  double* d_A = nullptr;      // ldA x Kcap fp64, column-major; with max_cols>0 a ring of max_cols columns
+  double* d_A = nullptr;      // ldA x Kcap, column-major (fp64; FLOATS behind the same pointer when a_dtype == SI_F32); with max_cols>0 a ring of max_cols columns
+  int32_t a_dtype = SI_F64;   // storage of the deviation matrix (si_construct_set_storage)
+  size_t a_bytes = 0;         // bytes allocated behind d_A
+  int32_t a_zero_dtype = -1;  // element type for which the padding rows of d_A are known to be zero (-1: unknown)
   void* d_wstage = nullptr;   // staging of si_construct_set_mean
   // pipelined host pushes (si_construct_push): two pinned host buffers -> two device buffers, events mark the H2D of each
   void* h_wpin[2] = {nullptr, nullptr};
@@ -271,19 +274,20 @@ struct ProfScope {
 
 // ---- kernel launchers (kernels_*.hip) -------------------------------------------------------
 // K1: s <- (n*s + w)/(n+1); acol <- w - s   (three rounded ops, no FMA; reference :46-47,51)
-void launch_swa_dev_push(hipStream_t st, const void* w, int32_t w_dtype, double* s, double* acol,
-                         int64_t N, double n, int num_cu);
-void launch_swa_dev_push_batch(hipStream_t st, const void* w, int32_t w_dtype, int64_t ld, double* s, double* A,
+// (a_dtype: element type of the deviation matrix -- SI_F64, the reference's, or the opt-in SI_F32 storage; ldA in ELEMENTS)
+void launch_swa_dev_push(hipStream_t st, const void* w, int32_t w_dtype, double* s, void* acol,
+                         int64_t N, double n, int num_cu, int32_t a_dtype = SI_F64);
+void launch_swa_dev_push_batch(hipStream_t st, const void* w, int32_t w_dtype, int64_t ld, double* s, void* A,
                                int64_t ldA, int64_t N, int count, const double* nvals_dev, int64_t slot0, int64_t kcap,
-                               int num_cu);
+                               int num_cu, int32_t a_dtype = SI_F64);
 // K2: G = A'A over columns [0,K) of A (ldA), rows [0,N); result K x K col-major symmetric in G
 // returns bytes of partial workspace required (if Gpart == nullptr nothing is launched)
-size_t launch_gram(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, double* Gpart,
-                   double* G, int num_cu, Ctx* prof);
+size_t launch_gram(hipStream_t st, const void* A, int64_t ldA, int64_t N, int64_t K, double* Gpart,
+                   double* G, int num_cu, Ctx* prof, int32_t a_dtype = SI_F64);
 // K3: P[:, m] = sum_k A[:, k] * V[k*Mpad + m], m < M;  Mpad = project_mpad(M) (V rows zero-padded)
 int project_mpad(int M);
-void launch_project(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, const double* V,
-                    int32_t M, int32_t Mpad, double* P, int64_t ldP, int num_cu);
+void launch_project(hipStream_t st, const void* A, int64_t ldA, int64_t N, int64_t K, const double* V,
+                    int32_t M, int32_t Mpad, double* P, int64_t ldP, int num_cu, int32_t a_dtype = SI_F64);
 // the same product on the matrix cores (kernels_bwd.hip gemm_f64_kernel); launch_project uses it for M > 32
 void launch_project_mfma(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, const double* V, int32_t M,
                          int32_t Mpad, double* P, int64_t ldP);
@@ -461,7 +465,7 @@ void launch_weights_select(hipStream_t st, const int32_t* flag, const double* wp
                            int64_t ldd, int64_t N, int32_t C, int num_cu);
 void launch_prior_grad(hipStream_t st, double* g, const double* w, int64_t n, double inv_s2, int num_cu);
 void launch_widen_f32(hipStream_t st, const float* src, double* dst, int64_t n, int num_cu);
-void launch_transpose(hipStream_t st, const double* A, int64_t lda, int64_t N, int64_t K, double* At, int64_t ldt);
+void launch_transpose(hipStream_t st, const void* A, int32_t a_dtype, int64_t lda, int64_t N, int64_t K, double* At, int64_t ldt);
 
 // host copy pool (host_copy.cpp): parallel memcpy between pageable caller arrays and pinned staging
 void host_copy(void* dst, const void* src, size_t bytes);

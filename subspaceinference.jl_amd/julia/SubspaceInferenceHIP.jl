@@ -225,12 +225,14 @@ end
 # init = :zeros is what the reference's code does (W_swa = zeros, :31); :pretrained is what its docs describe (nn_example.md:44)
 function subspace_construction(model, cost, data, opt; T = 10, c = 1, M = 3, print_freq = 1, device = 0,
                                ctx = Ctx(device), max_cols = 0, keep_on_device = false, device_training = false,
-                               init = :zeros, data_parallel = false)
+                               init = :zeros, data_parallel = false, a_storage = :f64)
     training_loss = 0.0
     ps = Flux.params(model)
     N = sum(length, ps)
     npush = count(i -> mod(i, c) == 0, 1:T) * length(data)
     check(ctx, ccall((:si_construct_begin, LIB), Int32, (Ptr{Cvoid}, Int64, Int64, Int32), ctx.h, N, npush, max_cols))
+    # a_storage = :f32 (opt-in): the deviation columns rounded once to Float32 on the device (half the memory / bytes of A)
+    a_storage == :f32 && check(ctx, ccall((:si_construct_set_storage, LIB), Int32, (Ptr{Cvoid}, Int32), ctx.h, SI_F32))
     if init == :pretrained
         W0 = extract_params(ps)
         GC.@preserve W0 check(ctx, ccall((:si_construct_set_mean, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32),

@@ -106,7 +106,7 @@ def test_the_wrapper_binds_the_whole_single_process_path():
     unbound = set(header_prototypes()) - bound
     for name in unbound:
         assert re.search(r"_dev$|_ptr$|gram_get|gram_set|rwmh_|train_grad|train_apply|allreduce_grad|profiling|stats|stream|synchronize|"
-                         r"version|device_name|get_A|host_sym_eig|host_jacobi|host_copy_plan|host_parse_cpu_max|set_chain_loop|si_forward|push_batch|si_sample_rwmh$", name), "unbound without a reason: " + name
+                         r"version|device_name|get_A|host_sym_eig|host_jacobi|host_copy_plan|host_parse_cpu_max|set_chain_loop|set_storage|si_forward|push_batch|si_sample_rwmh$", name), "unbound without a reason: " + name
     jl = open(JL).read()
     assert "function init_gpus" in jl and "ngpu = 1, nchains = ngpu" in jl and "remotecall" in jl
 
