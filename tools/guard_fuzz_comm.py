@@ -44,6 +44,8 @@ for case in range(cases):
         for j, w in enumerate(snaps):
             c.construct_push(w, float(1 + j))
     try:
+        if k > n:   # si_construct_finish alone would take its K > N route (A A'); the sharded flow sums the K x K Gram matrix:
+            plain.construct_gram()   # same route on both sides, so that "same bits" stays the assertion
         w0, p0, s0, _ = plain.construct_finish(m)
     except si.BoundsError:
         continue
