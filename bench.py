@@ -85,8 +85,6 @@ def parse_args(argv=None):
     ap.add_argument("--config", choices=sorted(CFG), default="cfg5", help="construct-sharded: which N / K / M")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--two-chains", action="store_true",
-                    help="also time two independent chains per GPU (second context / host thread); reported beside the headline")
     ap.add_argument("--dry-run-launcher", action="store_true",
                     help="ranks join a gloo group, count themselves and print a line with value null: exercises the "
                          "launch / relay / failure logic on a machine without GPUs (tests/test_bench_launcher.py)")
@@ -100,6 +98,13 @@ def parse_args(argv=None):
     return args
 
 
+# tools/bench_rehearsal.py flips these: the N-rank flow of this file on ONE GPU (ranks share the device over gloo).
+# bench.py itself has no such mode -- what the driver runs is always one rank per GPU over the in-library RCCL.
+REHEARSAL = False
+FORCE_DIST = False   # tools/bench_rehearsal.py --world1-rccl: take the N-rank code path (in-library RCCL) with ONE rank
+ENTRY = os.path.abspath(__file__)   # the script torchrun starts in every rank
+
+
 def launch_ranks(args, argv):
     """Parent of an N-rank run.  Imports neither torch nor the HIP library: the ranks are CHILD processes (a process
     that has initialised the GPU must never exec another program), and a failed child is a failed run."""
@@ -107,7 +112,7 @@ def launch_ranks(args, argv):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+           "--master-addr", "127.0.0.1", "--master-port", str(port), ENTRY] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
@@ -273,14 +278,12 @@ class Rank:
         self.dist = None
         self.args = args
         self.backend = None
-        # rehearsal knob: N ranks over gloo on however many GPUs are visible (ranks share devices) -- exercises the whole
-        # N-rank flow of this file and of dist.py's host-staged collectives on a 1-GPU box; the timings mean nothing
-        self.share_gpu = os.environ.get("SI_BENCH_SHARE_GPU") == "1"
+        self.share_gpu = REHEARSAL   # tools/bench_rehearsal.py only: the ranks share the visible GPU(s) over gloo
         self.ctx = None   # the si ctx whose in-library communicator carries the data plane (attach)
 
     def init(self, backend="gloo"):
         self.backend = backend
-        if self.world > 1 or os.environ.get("SI_BENCH_FORCE_DIST") == "1":  # the env knob rehearses the N-rank path on one GPU
+        if self.world > 1 or FORCE_DIST:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
@@ -290,8 +293,8 @@ class Rank:
             self.dist = dist
 
     def attach(self, ctx):
-        """join the in-library RCCL communicator (one rank per GPU); under SI_BENCH_SHARE_GPU the ranks share a device,
-        which RCCL refuses, so the rehearsal stays on the gloo test double of dist.py.  Should the communicator fail to
+        """join the in-library RCCL communicator (one rank per GPU); in tools/bench_rehearsal.py the ranks share
+        a device, which RCCL refuses, so the rehearsal stays on the gloo test double of dist.py.  Should the communicator fail to
         come up on ANY rank (it has never met more than one GPU before the driver's 8-GPU run), every rank drops it and
         the run goes on over the gloo control plane -- the headline mode exchanges nothing per step -- with the error
         reported in the line (`comm_error`) instead of a lost scaling curve."""
@@ -380,8 +383,8 @@ class Rank:
 
 
 def emit(real_stdout, out):
-    if os.environ.get("SI_BENCH_SHARE_GPU") == "1":
-        out["rehearsal"] = "SI_BENCH_SHARE_GPU=1: the ranks share the visible GPU(s) over gloo -- flow check, NOT a measurement"
+    if REHEARSAL:
+        out["rehearsal"] = "tools/bench_rehearsal.py: the ranks share the visible GPU(s) over gloo -- flow check, NOT a measurement"
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
@@ -578,28 +581,6 @@ def run_chains(args, rk, real_stdout):
     z1k, lp1k, _ = ctx.sample_rwmh(1000, SIGMA_Z, seed=100, chain_id0=rank)
     barrier()
     dt_1000 = rk.max_over_ranks(time.perf_counter() - t0)
-    # two independent chains per GPU (a second ctx = second stream, driven from a second host thread): the fill / drain
-    # phases and the store drain of one chain's launches run under the other's MFMAs.  Reported BESIDE
-    # `value`, which stays BASELINE's one chain per GPU.
-    dt_two = None
-    if args.two_chains:
-      import threading
-      w2, p2, _ = ctx.construct_get_result()
-      with si.Context(rk.local_rank) as ctx2:
-          ctx2.infer_setup(table, n_par, M, w2, p2, x, y, SIGMA_M)
-          del w2, p2
-          ctx2.sample_rwmh(max(1, args.warmup), SIGMA_Z, seed=100, chain_id0=world + rank, want_z=False)
-          pair = [(ctx, rank), (ctx2, world + rank)]
-          barrier()
-          t0 = time.perf_counter()
-          th = [threading.Thread(target=lambda c=c, cid=cid: c.sample_rwmh(args.steps, SIGMA_Z, seed=100, chain_id0=cid, want_z=False))
-                for c, cid in pair]
-          for t in th:
-              t.start()
-          for t in th:
-              t.join()
-          barrier()
-          dt_two = rk.max_over_ranks(time.perf_counter() - t0)
     bsteps = 20
     ctx.set_profiling(True)
     ctx.reset_stats()
@@ -691,10 +672,6 @@ def run_chains(args, rk, real_stdout):
                                "sample (8.4 MB) streamed to a fresh pageable host array under the following transitions; "
                                "bit-identical to si_reconstruct: %s" % (args.steps, map_ok),
             "chain_1000_steps_samples_per_s": n_seen * 1000 / dt_1000,
-            "two_chains_per_gpu_samples_per_s": (2 * n_seen * args.steps / dt_two) if dt_two else None,
-            "two_chains_per_gpu_note": "two independent cfg2 chains per GPU from two contexts / host threads, %d transitions each "
-                                       "(chain ids rank and world + rank); NOT the headline: BASELINE's cfg2 / cfg3 are one chain per GPU; "
-                                       "measured with --two-chains only (its concurrent launches would blur a kernel trace of the default run)" % args.steps,
             "comm": ("in-library RCCL (si_comm_*), world %d" % n_seen) if rk.ctx is not None else
                     ("none (one rank)" if rk.dist is None else "gloo control plane only"),
             "comm_error": getattr(rk, "comm_error", None),
@@ -957,7 +934,7 @@ def main(argv=None):
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     if rk.share_gpu:
         rk.local_rank %= torch.cuda.device_count()
-        log("bench.py: SI_BENCH_SHARE_GPU=1 -- rank %d uses GPU %d over gloo (rehearsal: timings are not a result)" % (rk.rank, rk.local_rank))
+        log("bench.py: rehearsal -- rank %d uses GPU %d over gloo (timings are not a result)" % (rk.rank, rk.local_rank))
     if rk.local_rank >= torch.cuda.device_count():
         raise SystemExit("bench.py: --gpus %d exceeds the %d visible GPUs" % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(rk.local_rank)

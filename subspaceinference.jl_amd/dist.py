@@ -13,7 +13,7 @@ is sharded is what the hot path allows:
 
 torch.distributed appears in two roles only: (1) shipping the 128-byte RCCL id when the ranks were started by torchrun
 (`comm_init`; a file rendezvous works without torch), and (2) as the CPU TEST DOUBLE: under a `gloo` group and a ctx
-without a communicator (tests/test_dist_cpu.py's stand-in contexts, bench.py's SI_BENCH_SHARE_GPU rehearsal) the same
+without a communicator (tests/test_dist_cpu.py's stand-in contexts, tools/bench_rehearsal.py) the same
 functions stage the small arrays through the host.  No arithmetic happens here.
 """
 import os

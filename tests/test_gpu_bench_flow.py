@@ -1,4 +1,4 @@
-"""The N-rank flow of bench.py on real GPU contexts (SI_BENCH_SHARE_GPU=1: the ranks share the visible GPU over gloo -- a
+"""The N-rank flow of bench.py on real GPU contexts (tools/bench_rehearsal.py: the ranks share the visible GPU over gloo -- a
 rehearsal of what the driver starts on an 8-GPU node, everything but RCCL itself): the self-launcher, one rank per
 process, barrier + max-over-ranks timing, exactly ONE JSON line from rank 0 with n_gpus = ranks counted by the backend."""
 import json
@@ -14,10 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("mode", [["--mode", "chains"], ["--mode", "data-sharded"]])
 def test_two_ranks_share_the_gpu(gpu_ctx, mode):
-    env = dict(os.environ, SI_BENCH_SHARE_GPU="1")
+    env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_rehearsal.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--no-cpu-baseline"] + mode, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

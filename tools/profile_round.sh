@@ -40,7 +40,7 @@ cd $R
 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 python3 bench.py --steps 1000 --warmup 10 --no-cpu-baseline > $O/bench_itr1000.json 2>> $O/bench_n1.err
 for m in "construct-sharded --config cfg4" "construct-sharded --config cfg5" "data-sharded"; do
-  SI_BENCH_FORCE_DIST=1 python3 bench.py --mode $m >> $O/bench_modes.json 2>> $O/bench_modes.err
+  python3 tools/bench_rehearsal.py --world1-rccl --mode $m >> $O/bench_modes.json 2>> $O/bench_modes.err
 done
 python3 tools/small_model_steps.py > $O/small_model_steps.log 2>&1
 echo done
