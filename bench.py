@@ -429,6 +429,10 @@ def run_chains(args, rk, real_stdout):
     torch.cuda.synchronize()
     ns = np.arange(1, K_SNAP + 1, dtype=np.float64)   # T = 100 epochs, full batch, c = 1: n = i
 
+    def phase(what):   # progress on stderr (rank 0): a run under a profiler that dies says where
+        if rank == 0:
+            log("bench.py: %s" % what)
+
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
@@ -467,6 +471,7 @@ def run_chains(args, rk, real_stdout):
             ctx.synchronize()
             runs.append((time.perf_counter() - t0) * 1e3)
         return sorted(runs)[1], [round(t, 4) for t in runs]
+    phase("construct: per-push and batched")
     ctx.set_profiling(True)
     construct("per_push")  # warm-up (allocations, code-object load)
     ctx.reset_stats()
@@ -481,6 +486,7 @@ def run_chains(args, rk, real_stdout):
     construct_ms, construct_runs = wall3("per_push")
     construct_b_ms, construct_b_runs = wall3("batched")
     # the same with the deviation matrix stored in fp32 (opt-in; W_swa, G, the eigen-decomposition and P stay fp64)
+    phase("construct: fp32-stored A")
     ctx.set_profiling(True)
     construct("per_push", True)
     ctx.reset_stats()
@@ -490,6 +496,7 @@ def run_chains(args, rk, real_stdout):
     ctx.set_profiling(False)
     construct32_ms, construct32_runs = wall3("per_push", True)
     construct32_b_ms, _ = wall3("batched", True)
+    phase("construct: host push")
     host_push = None
     if rank == 0:
         snaps_host = snaps[:, :n_par].cpu().numpy()   # 100 pageable Float32 vectors (419 MB)
@@ -529,6 +536,7 @@ def run_chains(args, rk, real_stdout):
                      "note": "100 x si_construct_push of a pageable 4.19 MB Float32 vector: host copy pool -> pinned double "
                              "buffer -> async H2D + K1, no synchronisation per push; then Gram + eig + projection"}
         del snaps_host
+    phase("construct: end to end through api.subspace_construction")
     # end to end through the drop-in call itself: subspace_construction(model, mse, data, ADAM; T = 100, M = 20) with the
     # training step on the device (src/subspace_construction.jl:37-59 as a whole: 100 x [gradient + update! + push] + psvd)
     e2e = None
@@ -548,6 +556,7 @@ def run_chains(args, rk, real_stdout):
 
     # ---- sampling.  The timed region carries event pairs around the DOMINANT kernel only (roofline.achieved is its
     # live average launch duration); the per-class breakdown comes from a short untimed pass afterwards.
+    phase("sampling: the timed region (fp64)")
     ctx.infer_setup(table, n_par, M, None, None, x, y, SIGMA_M)
     # every rank evaluates the density at the same point: identical (W_swa, P) after the broadcast <=> identical bits
     lp0_per_rank = rk.gather_floats(float(ctx.logdensity(np.full((M, 1), 0.25))[0]))
@@ -567,6 +576,7 @@ def run_chains(args, rk, real_stdout):
     ctx.set_profiling(False)
     # the same K transitions WITH the reference's output map (a13, src/space_inference.jl:125): every weight sample
     # delivered to a fresh pageable host array while the chain runs -- what the drop-in sub_inference call does
+    phase("sampling: with the output map")
     ctx.sample_rwmh_weights(5, SIGMA_Z, seed=100, chain_id0=rank)   # warm-up: weight ring, pinned staging, copy pool
     barrier()
     t0 = time.perf_counter()
@@ -576,6 +586,7 @@ def run_chains(args, rk, real_stdout):
     map_ok = bool(np.array_equal(zw, z) and np.array_equal(wmap[:, -1, 0], ctx.reconstruct(z[:, -1:, 0])[:, 0]))
     del wmap
     # one long chain, reported beside `value`: itr = 1000 is what BASELINE's cfg2 names; a short --steps run is corroborated
+    phase("sampling: 1000-step chain")
     barrier()
     t0 = time.perf_counter()
     z1k, lp1k, _ = ctx.sample_rwmh(1000, SIGMA_Z, seed=100, chain_id0=rank)
@@ -591,6 +602,7 @@ def run_chains(args, rk, real_stdout):
 
     # ---- compute_dtype = SI_F32 (SURVEY section 0 Q6 / 8(b),(d)): the same chain with X, the per-step weights and the activations
     # in fp32 on v_mfma_f32_32x32x2_f32 (head + SSE in fp64), reported BESIDE the fp64 headline, never instead of it
+    phase("sampling: compute_dtype = SI_F32")
     from subspaceinference_jl_amd import _capi
     ctx.infer_setup(table, n_par, M, None, None, x, y, SIGMA_M, compute_dtype=_capi.SI_F32)
     ctx.set_profiling(True, classes=["dense_main"])
@@ -610,6 +622,7 @@ def run_chains(args, rk, real_stdout):
     f32_lp_rel = float(np.max(np.abs(lp32k[:nsame, 0] - lp1k[:nsame, 0]) / np.abs(lp1k[:nsame, 0]))) if nsame else None
     ctx.infer_setup(table, n_par, M, None, None, x, y, SIGMA_M)   # back to the reference's arithmetic for what follows
 
+    phase("next rows: gradient, training step")
     extras = {}
     if rank == 0:
         # the "next" rows at the same workload (outside every timed region above)

@@ -41,7 +41,8 @@ rec = {
     "kernel": ("si::dense_f32_dma_kernel<192,128,2,4,3,4,true> (fp32, layer 960x960 + fused 960->1 head), cfg2" if F32 else
                "si::dense_f64_kernel<96,128,2,4,4,true,false,true> (layer 960x960 + fused 960->1 tail), cfg2"),
     "source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
-              "bench.py --steps 10 --warmup 2; medians over %d launches; %s" % (launches, os.path.basename(src)),
+              "tools/f32_after_f64.py f64 (the cfg2 construct, a 50-step fp64 chain and a 12-step fp32 chain: bench.py itself makes more dispatches "
+              "than rocprofv3's counter collection survives); medians over %d launches; %s" % (launches, os.path.basename(src)),
     "FETCH_SIZE_KB": fetch_kb,
     "WRITE_SIZE_KB": write_kb,
     "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) "

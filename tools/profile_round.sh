@@ -12,10 +12,17 @@ echo "[1] bench.py under rocprofv3 --kernel-trace --stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_kt -o b -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 python3 $R/tools/kstats.py $O/bench_kt 25 > $O/bench_kernel_stats.txt
 cp $(find $O/bench_kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
-echo "[2] PMC passes on bench.py (dense kernels)"
+echo "[2] PMC passes (dense kernels, Gram) on the short target tools/f32_after_f64.py: the cfg2 construct, an fp64 and an fp32 chain"
+# (NOT on bench.py: rocprofv3's counter collection dies -- SIGSEGV in one of its threads, or "AQL packet is malformed" -- once a
+#  process has made ~16 K dispatches: 14 564 pass, 18 764 do not, on the plain fp64 chain alone (tools/pmc_bisect*.sh, round 4);
+#  the default bench.py makes ~25 K.  Same kernels, same shapes, same launch parameters.)
+rm -f $O/pmc_dense_summary.txt $O/pmc_dense_f32_summary.txt $O/pmc_gram_summary.txt
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   tag=$(echo $c | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$tag -o p -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pmc_$tag.err
+  echo "    --pmc $c"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$tag -o p -- python3 $R/tools/f32_after_f64.py f64 > /dev/null 2> $O/pmc_$tag.err
+  rc=$?
+  if [ $rc -ne 0 ]; then echo "    pass failed (rc $rc): stopping"; exit 1; fi
   echo "== --pmc $c" >> $O/pmc_dense_summary.txt
   python3 $R/tools/pmc_summary.py $O/pmc_$tag dense_f64 >> $O/pmc_dense_summary.txt
   echo "== --pmc $c" >> $O/pmc_dense_f32_summary.txt
