@@ -138,6 +138,163 @@ static void launch_gemm(hipStream_t st, const double* A, int64_t lda, const doub
   }
 }
 
+// ---- weight gradient with LDS-DMA staging (round 4) -------------------------------------------------------------
+// dW = Delta * Hprev' contracts over the BATCH: both operands are "row-fast" (X[r + ld*k], one k = one observation = R
+// contiguous doubles), the k loop is ~1000 tiles long and nothing but MFMAs happens in it.  The register-staged kernel above
+// needs 20 staging VGPRs, so a 3 x 3 tile layout per wave (96 x 192 per workgroup: no padded columns for widths like 960,
+// 9 MFMAs per 6 fragment reads) spills (measured: 100 VGPRs spilled at the 128 budget of 4 waves per SIMD).  Here a tile's
+// 16 x (BM + BN) doubles go global -> LDS directly (global_load_lds_dwordx4, 16 B per lane, linear destination), two stages:
+//   tile kt:  s_waitcnt vmcnt(0); s_barrier;  issue the DMA of tile kt+1 into the other stage;  36 MFMAs per wave on tile kt
+// so a DMA has a whole tile's compute time to land.  LDS image of one operand: [k][R] doubles UNPADDED; the operand read of
+// lane (q, c) is element [4s + q][blk*16 + c], and rows of R = 96 / 128 / 192 doubles are a multiple of 64 banks apart, so rows
+// q and q+1 would collide: odd k rows are stored with neighbouring 16-double blocks exchanged (block ^ 1) -- done on the DMA
+// SOURCE address, the destination stays linear -- and the 32 lanes of a ds_read_b64 pass cover all 64 banks.
+// Needs: whole k tiles in every split (B % 16 == 0), even out / in, 16-byte aligned operands; anything else takes the
+// register-staged kernel.
+typedef __attribute__((address_space(3))) void* lds_void_ptr_d;
+
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void bwd_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    bwd_static_for<N, I + 1>(f);
+  }
+}
+
+// (body and kernel apart: a __global__ template with device builtins inside lambdas loses its host stub)
+template <int BM, int BN>
+__device__ __forceinline__ void dw_f64_dma_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ Bm,
+                                                int64_t ldb, double* __restrict__ C, int64_t ldc, int Mrows, int64_t Ncols,
+                                                int64_t Kdim, int64_t ksplit, int nMt, double* smem) {
+  constexpr int WM = 2, WN = 4, NWAVES = 8;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int STAGE = 16 * (BM + BN);              // doubles per stage
+  constexpr int NA = 16 * BM / 128, NBI = 16 * BN / 128;   // 1 KiB DMA instructions per tile: A part, B part
+  constexpr int NSLOT = (NA + NBI + NWAVES - 1) / NWAVES;
+  static_assert(BM % 32 == 0 && BN % 64 == 0 && (BM / 16) % 2 == 0 && (BN / 16) % 2 == 0, "tile shape");
+
+  const int mt = (int)(blockIdx.x % nMt);
+  const int64_t nt = blockIdx.x / nMt;
+  const int64_t split = blockIdx.y;
+  const int64_t k0 = split * ksplit;
+  int64_t klen = Kdim - k0;
+  if (klen > ksplit) klen = ksplit;
+  if (klen <= 0) return;
+  const int nk = (int)(klen / 16);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int m0 = mt * BM;
+  const int64_t n0 = nt * BN;
+  const int q = lane >> 4, c = lane & 15;
+
+  // DMA plan of this wave: slot s is instruction id = wave + 8 s of the tile's NA + NBI
+  const double* src[NSLOT];
+  int64_t adv[NSLOT];
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int id = wave + NWAVES * s;
+    if (id < NA) {
+      const int d = id * 64 + lane;                   // 16-byte pair inside the A image: row k = d / (BM/2)
+      const int k = d / (BM / 2), pp = d % (BM / 2);
+      int m = m0 + 2 * (pp ^ ((k & 1) << 3));
+      if (m > Mrows - 2) m = Mrows - 2;               // clamped rows only feed outputs that are never stored
+      src[s] = A + m + lda * (k0 + k);
+      adv[s] = lda * 16;
+    } else if (id < NA + NBI) {
+      const int d = (id - NA) * 64 + lane;
+      const int k = d / (BN / 2), pp = d % (BN / 2);
+      int64_t n = n0 + 2 * (pp ^ ((k & 1) << 3));
+      if (n > Ncols - 2) n = Ncols - 2;
+      src[s] = Bm + n + ldb * (k0 + k);
+      adv[s] = ldb * 16;
+    } else {
+      src[s] = A;
+      adv[s] = 0;
+    }
+  }
+  auto issue = [&](int kt, int buf) {
+    double* dst = smem + buf * STAGE;
+    bwd_static_for<NSLOT>([&](auto SC) {
+      constexpr int s = decltype(SC)::value;
+      if (wave + NWAVES * s < NA + NBI)
+        __builtin_amdgcn_global_load_lds(src[s] + adv[s] * kt, (lds_void_ptr_d)(dst + (wave + NWAVES * s) * 128), 16, 0, 0);
+    });
+  };
+
+  d4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  // fragment offsets (doubles inside a stage) of k step 0; step s adds 4 s BM / 4 s BN
+  int offA[TM], offB[TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) offA[a] = q * BM + (((wm * TM + a) ^ (q & 1)) << 4) + c;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) offB[b] = 16 * BM + q * BN + (((wn * TN + b) ^ (q & 1)) << 4) + c;
+
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave's pieces of tile kt are in; every wave is done reading tile kt-1
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const double* st = smem + (kt & 1) * STAGE;
+    double fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) fa[0][a] = st[offA[a]];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) fb[0][b] = st[offB[b]];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < 3) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) fa[(s + 1) & 1][a] = st[offA[a] + 4 * (s + 1) * BM];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) fb[(s + 1) & 1][b] = st[offB[b] + 4 * (s + 1) * BN];
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[s & 1][b], fa[s & 1][a], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  double* Cout = C + split * ldc * Ncols;
+  gemm_epilogue<BM, BN, WM, WN, true, 2 * STAGE>(acc, smem, Cout, ldc, m0, n0, Mrows, Ncols, wm, wn, lane, wave,
+                                                 [&](double v, int64_t, int) { return v; });
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(512, 4) void dw_f64_dma_kernel(const double* __restrict__ A, int64_t lda,
+                                                            const double* __restrict__ Bm, int64_t ldb, double* __restrict__ C,
+                                                            int64_t ldc, int Mrows, int64_t Ncols, int64_t Kdim, int64_t ksplit,
+                                                            int nMt) {
+  extern __shared__ double smem_dw[];
+  dw_f64_dma_body<BM, BN>(A, lda, Bm, ldb, C, ldc, Mrows, Ncols, Kdim, ksplit, nMt, smem_dw);
+}
+
+template <int BM, int BN>
+static void launch_dw_dma(hipStream_t st, const double* Delta, const double* Hprev, double* part, int32_t out, int32_t in,
+                          int64_t B, int nsplit, int64_t ks) {
+  constexpr size_t lds = 2 * 16 * (BM + BN) * sizeof(double);
+  const int nMt = (out + BM - 1) / BM;
+  const int64_t nNt = (in + BN - 1) / BN;
+  auto kern = dw_f64_dma_kernel<BM, BN>;
+  static LdsOptIn optin;
+  optin.ensure(reinterpret_cast<const void*>(kern), lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nMt * nNt), (unsigned)nsplit), dim3(512), lds, st, Delta, (int64_t)out, Hprev,
+                     (int64_t)in, part, (int64_t)out, out, (int64_t)in, B, ks, nMt);
+}
+
+static bool dw_dma_ok(const double* Delta, const double* Hprev, const double* part, int32_t out, int32_t in, int64_t B) {
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  return B % 16 == 0 && B >= 16 && out % 2 == 0 && in % 2 == 0 && out >= 2 && in >= 2 && al(Delta) && al(Hprev) && al(part);
+}
+
 // row tile that pads `rows` least (same rule as the forward kernel)
 static int pick_bm_bwd(int32_t rows) {
   if (rows <= 64) return 64;
@@ -174,32 +331,41 @@ void launch_backward_data(hipStream_t st, const double* W, const double* Delta, 
 // k ranges of the SAME tile and share no operand data, where the 80 tiles of one split walk the same k range of Delta
 // and H together and find it in the L2 / Infinity Cache.
 struct DwPlan {
-  int bm;
+  int bm, bn;
   int nsplit;
   int64_t ks;
 };
-static DwPlan plan_dw(int32_t out, int32_t in, int64_t B, int num_cu) {
+// (row tile, column tile) candidates.  96 x 192 (3 x 3 MFMA tiles per wave, 80 KiB of staging LDS: exactly two workgroups
+// per CU) exists for widths like cfg2's 960 = 7.5 x 128: 50 tiles x 10 splits = 500 of 512 slots and no padded columns,
+// where 96 x 128 computes 960 x 1024 on 480 slots.
+static constexpr int DW_NCAND = 4;
+static constexpr int DW_BM[DW_NCAND] = {96, 128, 64, 96};
+static constexpr int DW_BN[DW_NCAND] = {128, 128, 128, 192};
+static DwPlan plan_dw(int32_t out, int32_t in, int64_t B, int num_cu, bool dma = true) {
   const int64_t slots = (int64_t)num_cu * 2;
   const int64_t maxsplit = (B + 255) / 256;
-  DwPlan best{96, 1, B};
+  DwPlan best{96, 128, 1, B};
   double best_score = -1.0;
-  const int bms[3] = {96, 128, 64};
-  for (int bm : bms) {
-    const int64_t pm = (out + bm - 1) / bm, pn = (in + 127) / 128;
+  for (int c = 0; c < DW_NCAND; ++c) {
+    const int bm = DW_BM[c], bn = DW_BN[c];
+    if (bn != 128 && !dma) continue;   // the register-staged kernel has 128-column tiles only
+    const int64_t pm = (out + bm - 1) / bm, pn = (in + bn - 1) / bn;
     const int64_t tiles = pm * pn;
     int64_t ns = slots / tiles;
     if (ns > maxsplit) ns = maxsplit;
     if (ns < 1) ns = 1;
-    const double useful = ((double)out * in) / ((double)pm * bm * (double)pn * 128);
+    const double useful = ((double)out * in) / ((double)pm * bm * (double)pn * bn);
     const double fill = (double)(tiles * ns) / (double)((tiles * ns + slots - 1) / slots * slots);
     if (useful * fill > best_score * 1.0001) {
       best_score = useful * fill;
       best.bm = bm;
+      best.bn = bn;
       best.nsplit = (int)ns;
     }
   }
 #ifdef SI_BWD_DEBUG_KNOB
   if (const char* e = getenv("SI_BWD_BM")) best.bm = atoi(e);
+  if (const char* e = getenv("SI_BWD_BN")) best.bn = atoi(e);
   if (const char* e = getenv("SI_BWD_NSPLIT")) best.nsplit = atoi(e);
 #endif
   // k-range per split rounded up to whole 16-deep tiles; only splits that hold columns are launched
@@ -213,13 +379,12 @@ static DwPlan plan_dw(int32_t out, int32_t in, int64_t B, int num_cu) {
 // the split count is not monotonic in the batch: out = 95, in = 33 takes 243 splits at B = 66 003 and 256 at 65 536) and
 // can pick another row tile -- a training step on a last, smaller batch of an epoch wrote behind a buffer sized from
 // the plan of the full batch (found by tools/guard_fuzz.py under the guard-page allocator, round 3).  The bound: no plan
-// exceeds min(slots / tiles, ceil(B / 256)) splits for its row tile.
+// exceeds min(slots / tiles, ceil(B / 256)) splits for its tile shape.
 size_t backward_weight_part_elems(int32_t out, int32_t in, int64_t B, int num_cu) {
   const int64_t slots = (int64_t)num_cu * 2, maxsplit = (B + 255) / 256;
   int64_t worst = 1;
-  const int bms[3] = {96, 128, 64};
-  for (int bm : bms) {
-    const int64_t tiles = (int64_t)((out + bm - 1) / bm) * ((in + 127) / 128);
+  for (int c = 0; c < DW_NCAND; ++c) {
+    const int64_t tiles = (int64_t)((out + DW_BM[c] - 1) / DW_BM[c]) * ((in + DW_BN[c] - 1) / DW_BN[c]);
     worst = std::max(worst, std::max<int64_t>(1, std::min(slots / tiles, maxsplit)));
   }
   return (size_t)worst * out * in;
@@ -228,12 +393,22 @@ size_t backward_weight_part_elems(int32_t out, int32_t in, int64_t B, int num_cu
 // dW[out x in] = Delta * Hprev' into dW: split-K GEMM into `part`, then the splits added in fixed order
 void launch_backward_weight(hipStream_t st, const double* Delta, const double* Hprev, double* part, int32_t out,
                             int32_t in, int64_t B, int num_cu, double* dW) {
-  const DwPlan p = plan_dw(out, in, B, num_cu);
+  bool dma = dw_dma_ok(Delta, Hprev, part, out, in, B);
+#ifdef SI_BWD_DEBUG_KNOB
+  if (getenv("SI_BWD_NODMA")) dma = false;
+#endif
+  const DwPlan p = plan_dw(out, in, B, num_cu, dma);
   // A(m = out idx, k = b) = Delta[m + out*k]: row-fast;  B(k = b, n = in idx) = Hprev[n + in*k]: row-fast
-  switch (p.bm) {
-    case 96: launch_gemm<96, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, p.nsplit, p.ks, nullptr, 0); break;
-    case 128: launch_gemm<128, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, p.nsplit, p.ks, nullptr, 0); break;
-    default: launch_gemm<64, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, p.nsplit, p.ks, nullptr, 0); break;
+  if (dma && p.bm == 96 && p.bn == 192) {
+    launch_dw_dma<96, 192>(st, Delta, Hprev, part, out, in, B, p.nsplit, p.ks);
+  } else if (dma && p.bm == 96 && p.bn == 128) {
+    launch_dw_dma<96, 128>(st, Delta, Hprev, part, out, in, B, p.nsplit, p.ks);
+  } else {
+    switch (p.bm) {
+      case 96: launch_gemm<96, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, p.nsplit, p.ks, nullptr, 0); break;
+      case 128: launch_gemm<128, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, p.nsplit, p.ks, nullptr, 0); break;
+      default: launch_gemm<64, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, p.nsplit, p.ks, nullptr, 0); break;
+    }
   }
   launch_split_reduce(st, part, p.nsplit, (int64_t)out * in, dW);
 }

@@ -1073,6 +1073,36 @@ def test_random_shape_sweep_training_gradient(si, gpu_ctx):
         gpu_ctx.train_apply()
 
 
+@pytest.mark.parametrize("dims,nb", [
+    ([6, 100, 190, 2], 4096),       # 190 x 100 and 100 x 6: one ragged 96-row / 192-column tile each
+    ([20, 386, 98, 1], 1024),       # in = 386: three 192-column tiles, the last with two live columns
+    ([128, 960, 960, 1], 3200),     # cfg2's layers: 96 x 192 tiles, no padding
+    ([64, 192, 96, 3], 160),        # exactly one tile, ten k tiles
+    ([30, 130, 258, 2], 2064),      # 16 | B, ragged rows and columns, pairs at the clamp
+])
+def test_weight_gradient_dma_kernel(si, gpu_ctx, dims, nb):
+    """The LDS-DMA weight-gradient kernel (kernels_bwd.hip dw_f64_dma_kernel: batches that are whole 16-deep k tiles, even
+    widths) -- the FULL weight gradient of si_train_grad, entry by entry, against the host stand-in of Zygote's gradient."""
+    from subspaceinference_jl_amd import flux
+    wr = np.random.default_rng(sum(dims) + nb)
+    acts = [flux.relu, flux.tanh, flux.identity]
+    model = flux.Chain(*[flux.Dense(dims[i], dims[i + 1], acts[i], rng=wr) for i in range(3)])
+    for l in model.layers:
+        l.b[...] = (0.1 * wr.standard_normal(l.b.shape)).astype(np.float32)
+    x, y = wr.standard_normal((dims[0], nb)), wr.standard_normal((dims[-1], nb))
+    table, n = flux.layer_table(model)
+    gpu_ctx.train_setup(table, n, flux.extract_params(flux.params(model)), x, y, nb, 0, 0.1)
+    ids = np.arange(nb)
+    sse = gpu_ctx.train_grad(ids, nb)
+    g = gpu_ctx.train_grad_get()
+    loss, gs = flux.mse.value_and_grad(model, x, y)
+    gref = np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1, order="F") for a in gs])
+    assert np.isclose(sse / (dims[-1] * nb), loss, rtol=1e-10)
+    assert np.allclose(g, gref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(gref).max()))
+    sse2 = gpu_ctx.train_grad(ids, nb)
+    assert sse2 == sse and np.array_equal(gpu_ctx.train_grad_get(), g)   # fixed-order split reduction: same bits
+
+
 def test_random_shape_sweep_construction(gpu_ctx):
     """Seeded sweep of the construction path: N from 1 to ~30 000 (odd, below / across the 64-row slab and tile sizes),
     K from 1 to 300 (one, two and three 128-column Gram panels), fp32 / fp64 snapshots, M up to 70 (VALU and MFMA

@@ -53,14 +53,14 @@ int main(int argc, char** argv) {
   for (auto& v : hW) v = rnd() * 0.1;
   double *dD, *dH, *dW, *dPart, *dG, *dDp;
   hipMalloc(&dD, hD.size() * 8); hipMalloc(&dH, hH.size() * 8); hipMalloc(&dW, hW.size() * 8);
-  hipMalloc(&dPart, backward_weight_part_elems(out, in, B, ncu) * 8); hipMalloc(&dG, (size_t)out * in * 8); hipMalloc(&dDp, (size_t)in * B * 8);
+  hipMalloc(&dPart, std::max<size_t>(backward_weight_part_elems(out, in, B, ncu), (size_t)(plan_dw(out, in, B, ncu).nsplit + 1) * out * in) * 8); hipMalloc(&dG, (size_t)out * in * 8); hipMalloc(&dDp, (size_t)in * B * 8);
   hipMemcpy(dD, hD.data(), hD.size() * 8, hipMemcpyHostToDevice);
   hipMemcpy(dH, hH.data(), hH.size() * 8, hipMemcpyHostToDevice);
   hipMemcpy(dW, hW.data(), hW.size() * 8, hipMemcpyHostToDevice);
   const double flops = 2.0 * out * in * (double)B;
   {
     const DwPlan p = plan_dw(out, in, B, ncu);
-    printf("out %d in %d B %lld  CUs %d  dW: %d-row tiles, nsplit %d ksplit %lld\n", out, in, (long long)B, ncu, p.bm, p.nsplit, (long long)p.ks);
+    printf("out %d in %d B %lld  CUs %d  dW: %d x %d tiles, nsplit %d ksplit %lld\n", out, in, (long long)B, ncu, p.bm, p.bn, p.nsplit, (long long)p.ks);
   }
   float ms = best_ms([&] { launch_backward_weight(0, dD, dH, dPart, out, in, B, ncu, dG); });
   printf("dW   gemm + reduce     %8.3f ms  %6.2f TFLOP/s\n", ms, flops / (ms * 1e-3) / 1e12);

@@ -1,13 +1,15 @@
 #!/bin/bash
-# dW / dX of cfg2's 960 x 960 layer under the harness knobs (1 = cache-hot operands, 2 = no global loads in the k loop) and
-# with other row tiles / split counts for dW.  Log: gpurun_out/bwd_knobs.log
+# dW / dX of cfg2's layers: the LDS-DMA weight-gradient kernel (96 x 192 and 96 x 128 tiles) against the register-staged one.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 L=$R/gpurun_out/bwd_knobs.log
 : > $L
-for k in 0 1 2 0; do $R/tools/bin/bwd_bench 960 960 100000 $k >> $L 2>&1 || exit 1; done
-for cfg in "96 6" "128 8" "96 19" "96 32" "64 4" "128 16"; do
-  set -- $cfg
-  echo "== SI_BWD_BM=$1 SI_BWD_NSPLIT=$2" >> $L
-  SI_BWD_BM=$1 SI_BWD_NSPLIT=$2 $R/tools/bin/bwd_bench 960 960 100000 0 >> $L 2>&1 || exit 1
-done
+run() { echo "== $*" >> $L; env "$@" timeout -k 5 60 $R/tools/bin/bwd_bench ${SHAPE:-960 960 100000} >> $L 2>&1 || { echo "FAILED" >> $L; cat $L; exit 1; }; }
+run SI_BWD_NODMA=1
+run X=0
+run SI_BWD_BN=128 SI_BWD_NSPLIT=6
+run SI_BWD_NODMA=1
+run X=0
+SHAPE="960 128 100000" run SI_BWD_NODMA=1
+SHAPE="960 128 100000" run X=0
+SHAPE="950 962 65536" run X=0
 cat $L
