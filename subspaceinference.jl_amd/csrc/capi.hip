@@ -217,8 +217,9 @@ int32_t dense_reverse_sweep(Ctx* ctx, hipStream_t st, const DenseSweep& s) {
   for (size_t li = top; li-- > 0;) {
     const si_layer& ly = s.layers[li];
     const double* hprev = li > 0 ? s.hs[li - 1] : s.X;
-    if (!(have_db && li + 1 == top)) launch_rowsum(st, s.delta[cur], ly.out, s.B, s.rspart, s.gw + ly.b_off);
-    launch_backward_weight(st, s.delta[cur], hprev, s.bwpart, ly.out, ly.in, s.B, ctx->num_cu, s.gw + ly.w_off);
+    // (db of this layer rides along with its weight gradient unless the fused tail has produced it already)
+    launch_backward_weight(st, s.delta[cur], hprev, s.bwpart, ly.out, ly.in, s.B, ctx->num_cu, s.gw + ly.w_off,
+                           (have_db && li + 1 == top) ? nullptr : s.gw + ly.b_off);
     if (li > 0) {
       launch_backward_data(st, s.w + ly.w_off, s.delta[cur], hprev, s.delta[cur ^ 1], ly.out, ly.in, s.B, s.layers[li - 1].act);
       cur ^= 1;

@@ -22,6 +22,7 @@
 namespace si {
 
 enum { EPI_DACT = 1, EPI_RAW = 2 };
+constexpr int RS_CHUNKS = 64;   // column chunks of the row-sum kernels (db = rowsum(Delta))
 
 #ifdef SI_BWD_DEBUG_KNOB
 __device__ int si_bwd_dbg = 0;  // harness only: 1 = every block reads split 0 / tile (0,0) (cache-hot), 2 = no global loads in the k loop
@@ -165,12 +166,12 @@ __device__ __forceinline__ void bwd_static_for(F&& f) {
 template <int BM, int BN>
 __device__ __forceinline__ void dw_f64_dma_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ Bm,
                                                 int64_t ldb, double* __restrict__ C, int64_t ldc, int Mrows, int64_t Ncols,
-                                                int64_t Kdim, int64_t ksplit, int nMt, double* smem) {
+                                                int64_t Kdim, int64_t ksplit, int nMt, double* __restrict__ dbpart,
+                                                double* smem) {
   constexpr int WM = 2, WN = 4, NWAVES = 8;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   constexpr int STAGE = 16 * (BM + BN);              // doubles per stage
   constexpr int NA = 16 * BM / 128, NBI = 16 * BN / 128;   // 1 KiB DMA instructions per tile: A part, B part
-  constexpr int NSLOT = (NA + NBI + NWAVES - 1) / NWAVES;
   static_assert(BM % 32 == 0 && BN % 64 == 0 && (BM / 16) % 2 == 0 && (BN / 16) % 2 == 0, "tile shape");
 
   const int mt = (int)(blockIdx.x % nMt);
@@ -189,37 +190,44 @@ __device__ __forceinline__ void dw_f64_dma_body(const double* __restrict__ A, in
   const int64_t n0 = nt * BN;
   const int q = lane >> 4, c = lane & 15;
 
-  // DMA plan of this wave: slot s is instruction id = wave + 8 s of the tile's NA + NBI
-  const double* src[NSLOT];
-  int64_t adv[NSLOT];
+  // DMA plan of this wave: the A image takes NA instructions (1 KiB each), the B image NBI; slot s of an operand is instruction
+  // wave + 8 s of that operand, so which operand a slot belongs to is known at compile time and only the last A slot can be
+  // partial (BM = 96: 12 instructions = one slot of all waves + one of waves 0-3).  A lane keeps one 32-bit BYTE offset per slot
+  // (its element inside the tile's 16 columns); the tile's base address is wave-uniform: the scalar-base form of the load.
+  constexpr int SA_N = (NA + NWAVES - 1) / NWAVES, SB_N = (NBI + NWAVES - 1) / NWAVES;
+  static_assert(NBI % NWAVES == 0, "the B image is whole slots");
+  uint32_t aoff[SA_N], boff[SB_N];
 #pragma unroll
-  for (int s = 0; s < NSLOT; ++s) {
+  for (int s = 0; s < SA_N; ++s) {
     const int id = wave + NWAVES * s;
-    if (id < NA) {
-      const int d = id * 64 + lane;                   // 16-byte pair inside the A image: row k = d / (BM/2)
-      const int k = d / (BM / 2), pp = d % (BM / 2);
-      int m = m0 + 2 * (pp ^ ((k & 1) << 3));
-      if (m > Mrows - 2) m = Mrows - 2;               // clamped rows only feed outputs that are never stored
-      src[s] = A + m + lda * (k0 + k);
-      adv[s] = lda * 16;
-    } else if (id < NA + NBI) {
-      const int d = (id - NA) * 64 + lane;
-      const int k = d / (BN / 2), pp = d % (BN / 2);
-      int64_t n = n0 + 2 * (pp ^ ((k & 1) << 3));
-      if (n > Ncols - 2) n = Ncols - 2;
-      src[s] = Bm + n + ldb * (k0 + k);
-      adv[s] = ldb * 16;
-    } else {
-      src[s] = A;
-      adv[s] = 0;
-    }
+    const int d = (id < NA ? id : 0) * 64 + lane;   // 16-byte pair inside the A image: row k = d / (BM/2)
+    const int k = d / (BM / 2), pp = d % (BM / 2);
+    int m = m0 + 2 * (pp ^ ((k & 1) << 3));
+    if (m > Mrows - 2) m = Mrows - 2;               // clamped rows only feed outputs that are never stored
+    aoff[s] = (uint32_t)(m + (int)lda * k) * 8u;
+  }
+#pragma unroll
+  for (int s = 0; s < SB_N; ++s) {
+    const int d = (wave + NWAVES * s) * 64 + lane;
+    const int k = d / (BN / 2), pp = d % (BN / 2);
+    int64_t n = n0 + 2 * (pp ^ ((k & 1) << 3));
+    if (n > Ncols - 2) n = Ncols - 2;
+    boff[s] = (uint32_t)((int)n + (int)ldb * k) * 8u;
   }
   auto issue = [&](int kt, int buf) {
     double* dst = smem + buf * STAGE;
-    bwd_static_for<NSLOT>([&](auto SC) {
+    const char* ta = reinterpret_cast<const char*>(A + lda * (k0 + 16 * (int64_t)kt));
+    const char* tb = reinterpret_cast<const char*>(Bm + ldb * (k0 + 16 * (int64_t)kt));
+    bwd_static_for<SA_N>([&](auto SC) {
       constexpr int s = decltype(SC)::value;
-      if (wave + NWAVES * s < NA + NBI)
-        __builtin_amdgcn_global_load_lds(src[s] + adv[s] * kt, (lds_void_ptr_d)(dst + (wave + NWAVES * s) * 128), 16, 0, 0);
+      if ((s + 1) * NWAVES <= NA || wave + NWAVES * s < NA)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(ta + aoff[s]),
+                                         (lds_void_ptr_d)(dst + (wave + NWAVES * s) * 128), 16, 0, 0);
+    });
+    bwd_static_for<SB_N>([&](auto SC) {
+      constexpr int s = decltype(SC)::value;
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(tb + boff[s]),
+                                       (lds_void_ptr_d)(dst + 16 * BM + (wave + NWAVES * s) * 128), 16, 0, 0);
     });
   };
 
@@ -236,30 +244,53 @@ __device__ __forceinline__ void dw_f64_dma_body(const double* __restrict__ A, in
 #pragma unroll
   for (int b = 0; b < TN; ++b) offB[b] = 16 * BM + q * BN + (((wn * TN + b) ^ (q & 1)) << 4) + c;
 
-  issue(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // every wave's pieces of tile kt are in; every wave is done reading tile kt-1
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-    const double* st = smem + (kt & 1) * STAGE;
-    double fa[2][TM], fb[2][TN];
+  // db = rowsum(Delta) rides along (dbpart != nullptr): the waves of the first column tile that hold distinct rows (wn == 0) add up
+  // their A fragments -- every element of the tile's rows passes through them exactly once -- in the fixed order of the k loop
+  const bool do_rs = dbpart != nullptr && nt == 0 && wn == 0;   // wave-uniform
+  double rs[TM];
 #pragma unroll
-    for (int a = 0; a < TM; ++a) fa[0][a] = st[offA[a]];
+  for (int a = 0; a < TM; ++a) rs[a] = 0.0;
+
+  // (two copies of the loop, chosen once: as one loop with a wave-uniform `if` the row sums were compiled to unconditional
+  //  adds + selects in every wave)
+  auto mainloop = [&](auto RS) {
+    constexpr bool with_rs = decltype(RS)::value;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // every wave's pieces of tile kt are in; every wave is done reading tile kt-1
+      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+      const double* st = smem + (kt & 1) * STAGE;
+      // (one fragment set: the other three waves of the SIMD cover the LDS latency; a second, software-pipelined set costs 12
+      //  registers and pushed the kernel over its 128-register budget -- spills inside the loop)
 #pragma unroll
-    for (int b = 0; b < TN; ++b) fb[0][b] = st[offB[b]];
+      for (int s = 0; s < 4; ++s) {
+        double fa[TM], fb[TN];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s < 3) {
+        for (int a = 0; a < TM; ++a) fa[a] = st[offA[a] + 4 * s * BM];
 #pragma unroll
-        for (int a = 0; a < TM; ++a) fa[(s + 1) & 1][a] = st[offA[a] + 4 * (s + 1) * BM];
+        for (int b = 0; b < TN; ++b) fb[b] = st[offB[b] + 4 * s * BN];
 #pragma unroll
-        for (int b = 0; b < TN; ++b) fb[(s + 1) & 1][b] = st[offB[b] + 4 * (s + 1) * BN];
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0);
+        if constexpr (with_rs) {
+#pragma unroll
+          for (int a = 0; a < TM; ++a) rs[a] += fa[a];
+        }
       }
+    }
+  };
+  if (do_rs) mainloop(std::true_type{});
+  else mainloop(std::false_type{});
+  if (do_rs) {
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[s & 1][b], fa[s & 1][a], acc[a][b], 0, 0, 0);
+    for (int a = 0; a < TM; ++a) {
+      double t = rs[a];
+      t += __shfl_xor(t, 16);   // the four q groups hold k = 4s + q of the same row
+      t += __shfl_xor(t, 32);
+      const int gm = m0 + wm * (BM / WM) + a * 16 + c;
+      if (q == 0 && gm < Mrows) dbpart[split * Mrows + gm] = t;
     }
   }
 
@@ -272,14 +303,14 @@ template <int BM, int BN>
 __global__ __launch_bounds__(512, 4) void dw_f64_dma_kernel(const double* __restrict__ A, int64_t lda,
                                                             const double* __restrict__ Bm, int64_t ldb, double* __restrict__ C,
                                                             int64_t ldc, int Mrows, int64_t Ncols, int64_t Kdim, int64_t ksplit,
-                                                            int nMt) {
+                                                            int nMt, double* __restrict__ dbpart) {
   extern __shared__ double smem_dw[];
-  dw_f64_dma_body<BM, BN>(A, lda, Bm, ldb, C, ldc, Mrows, Ncols, Kdim, ksplit, nMt, smem_dw);
+  dw_f64_dma_body<BM, BN>(A, lda, Bm, ldb, C, ldc, Mrows, Ncols, Kdim, ksplit, nMt, dbpart, smem_dw);
 }
 
 template <int BM, int BN>
 static void launch_dw_dma(hipStream_t st, const double* Delta, const double* Hprev, double* part, int32_t out, int32_t in,
-                          int64_t B, int nsplit, int64_t ks) {
+                          int64_t B, int nsplit, int64_t ks, double* dbpart) {
   constexpr size_t lds = 2 * 16 * (BM + BN) * sizeof(double);
   const int nMt = (out + BM - 1) / BM;
   const int64_t nNt = (in + BN - 1) / BN;
@@ -287,7 +318,7 @@ static void launch_dw_dma(hipStream_t st, const double* Delta, const double* Hpr
   static LdsOptIn optin;
   optin.ensure(reinterpret_cast<const void*>(kern), lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)(nMt * nNt), (unsigned)nsplit), dim3(512), lds, st, Delta, (int64_t)out, Hprev,
-                     (int64_t)in, part, (int64_t)out, out, (int64_t)in, B, ks, nMt);
+                     (int64_t)in, part, (int64_t)out, out, (int64_t)in, B, ks, nMt, dbpart);
 }
 
 static bool dw_dma_ok(const double* Delta, const double* Hprev, const double* part, int32_t out, int32_t in, int64_t B) {
@@ -387,23 +418,27 @@ size_t backward_weight_part_elems(int32_t out, int32_t in, int64_t B, int num_cu
     const int64_t tiles = (int64_t)((out + DW_BM[c] - 1) / DW_BM[c]) * ((in + DW_BN[c] - 1) / DW_BN[c]);
     worst = std::max(worst, std::max<int64_t>(1, std::min(slots / tiles, maxsplit)));
   }
-  return (size_t)worst * out * in;
+  // + the row-sum partials of the fused db (one row of `out` per split) or the scratch of launch_rowsum
+  return (size_t)worst * out * in + (size_t)std::max<int64_t>(worst, RS_CHUNKS) * out;
 }
 
 // dW[out x in] = Delta * Hprev' into dW: split-K GEMM into `part`, then the splits added in fixed order
+// db != nullptr: db = rowsum(Delta) as well (fused into the LDS-DMA kernel where that runs, else by the row-sum kernels)
 void launch_backward_weight(hipStream_t st, const double* Delta, const double* Hprev, double* part, int32_t out,
-                            int32_t in, int64_t B, int num_cu, double* dW) {
+                            int32_t in, int64_t B, int num_cu, double* dW, double* db) {
   bool dma = dw_dma_ok(Delta, Hprev, part, out, in, B);
 #ifdef SI_BWD_DEBUG_KNOB
   if (getenv("SI_BWD_NODMA")) dma = false;
 #endif
   const DwPlan p = plan_dw(out, in, B, num_cu, dma);
   // A(m = out idx, k = b) = Delta[m + out*k]: row-fast;  B(k = b, n = in idx) = Hprev[n + in*k]: row-fast
-  if (dma && p.bm == 96 && p.bn == 192) {
-    launch_dw_dma<96, 192>(st, Delta, Hprev, part, out, in, B, p.nsplit, p.ks);
-  } else if (dma && p.bm == 96 && p.bn == 128) {
-    launch_dw_dma<96, 128>(st, Delta, Hprev, part, out, in, B, p.nsplit, p.ks);
+  double* extra = part + (size_t)p.nsplit * out * in;   // behind the dW partials: row-sum partials / launch_rowsum's scratch
+  if (dma && p.bm == 96 && (p.bn == 192 || p.bn == 128)) {
+    if (p.bn == 192) launch_dw_dma<96, 192>(st, Delta, Hprev, part, out, in, B, p.nsplit, p.ks, db ? extra : nullptr);
+    else launch_dw_dma<96, 128>(st, Delta, Hprev, part, out, in, B, p.nsplit, p.ks, db ? extra : nullptr);
+    if (db) launch_split_reduce(st, extra, p.nsplit, out, db);
   } else {
+    if (db) launch_rowsum(st, Delta, out, B, extra, db);
     switch (p.bm) {
       case 96: launch_gemm<96, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, p.nsplit, p.ks, nullptr, 0); break;
       case 128: launch_gemm<128, 128, 0, 0, EPI_RAW>(st, Delta, out, Hprev, in, part, out, out, in, B, p.nsplit, p.ks, nullptr, 0); break;
@@ -460,7 +495,6 @@ void launch_delta_out(hipStream_t st, const double* Y, const double* Yhat, int64
 }
 
 // db[i] = sum_b Delta[i + out*b]: stage 1 gives one partial per (column chunk, i); stage 2 sums chunks in order
-constexpr int RS_CHUNKS = 64;
 __global__ __launch_bounds__(256) void rowsum_partial_kernel(const double* __restrict__ D, int out, int64_t B,
                                                              double* __restrict__ part) {
   // block = (32 rows) x (8 column lanes); grid.x = row groups, grid.y = column chunk
@@ -490,7 +524,32 @@ __global__ __launch_bounds__(256) void rowsum_final_kernel(const double* __restr
   for (int ch = 0; ch < RS_CHUNKS; ++ch) s += part[(int64_t)ch * out + i];
   db[i] = s;
 }
+// the same for a handful of rows (regression heads: out = 1): the 256 threads of a block walk the COLUMNS of one row's chunk
+// (rowsum_partial_kernel keeps 8 threads per row busy: 85 us for 1 x 100 000, latency-bound), fixed-order tree in LDS
+__global__ __launch_bounds__(256) void rowsum_narrow_kernel(const double* __restrict__ D, int out, int64_t B,
+                                                            double* __restrict__ part) {
+  __shared__ double red[256];
+  const int i = blockIdx.x;
+  const int64_t per = (B + RS_CHUNKS - 1) / RS_CHUNKS;
+  const int64_t b0 = (int64_t)blockIdx.y * per;
+  int64_t b1 = b0 + per;
+  if (b1 > B) b1 = B;
+  double s = 0.0;
+  for (int64_t b = b0 + threadIdx.x; b < b1; b += 256) s += D[i + (int64_t)out * b];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[(int64_t)blockIdx.y * out + i] = red[0];
+}
 void launch_rowsum(hipStream_t st, const double* D, int32_t out, int64_t B, double* part /* RS_CHUNKS*out */, double* db) {
+  if (out <= 8) {
+    hipLaunchKernelGGL(rowsum_narrow_kernel, dim3(out, RS_CHUNKS), dim3(256), 0, st, D, (int)out, B, part);
+    hipLaunchKernelGGL(rowsum_final_kernel, dim3(1), dim3(256), 0, st, part, (int)out, db);
+    return;
+  }
   hipLaunchKernelGGL(rowsum_partial_kernel, dim3((out + 31) / 32, RS_CHUNKS), dim3(256), 0, st, D, (int)out, B, part);
   hipLaunchKernelGGL(rowsum_final_kernel, dim3((out + 255) / 256), dim3(256), 0, st, part, (int)out, db);
 }

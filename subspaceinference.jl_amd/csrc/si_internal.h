@@ -358,10 +358,11 @@ struct DenseSweep {
   int64_t B;
 };
 int32_t dense_reverse_sweep(Ctx* ctx, hipStream_t st, const DenseSweep& s);
-// dW[out x in] = Delta * Hprev' into dW, through `part` (backward_weight_part_elems doubles): stream-K / split-K GEMM + fixed-order reduction
+// dW[out x in] = Delta * Hprev' into dW, through `part` (backward_weight_part_elems doubles): split-K GEMM + fixed-order reduction;
+// db != nullptr: db[out] = rowsum(Delta) as well (inside the GEMM where the LDS-DMA kernel runs, else by launch_rowsum)
 size_t backward_weight_part_elems(int32_t out, int32_t in, int64_t B, int num_cu);
 void launch_backward_weight(hipStream_t st, const double* Delta, const double* Hprev, double* part, int32_t out,
-                            int32_t in, int64_t B, int num_cu, double* dW);
+                            int32_t in, int64_t B, int num_cu, double* dW, double* db = nullptr);
 void launch_split_reduce(hipStream_t st, const double* part, int nsplit, int64_t elems, double* dst);
 void launch_delta_out(hipStream_t st, const double* Y, const double* Yhat, int64_t d, double scale, int act, double* delta);
 void launch_rowsum(hipStream_t st, const double* D, int32_t out, int64_t B, double* part, double* db);

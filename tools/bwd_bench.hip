@@ -51,7 +51,8 @@ int main(int argc, char** argv) {
   for (auto& v : hD) v = rnd();
   for (auto& v : hH) v = rnd();
   for (auto& v : hW) v = rnd() * 0.1;
-  double *dD, *dH, *dW, *dPart, *dG, *dDp;
+  double *dD, *dH, *dW, *dPart, *dG, *dDp, *dDb;
+  hipMalloc(&dDb, (size_t)out * 8);
   hipMalloc(&dD, hD.size() * 8); hipMalloc(&dH, hH.size() * 8); hipMalloc(&dW, hW.size() * 8);
   hipMalloc(&dPart, std::max<size_t>(backward_weight_part_elems(out, in, B, ncu), (size_t)(plan_dw(out, in, B, ncu).nsplit + 1) * out * in) * 8); hipMalloc(&dG, (size_t)out * in * 8); hipMalloc(&dDp, (size_t)in * B * 8);
   hipMemcpy(dD, hD.data(), hD.size() * 8, hipMemcpyHostToDevice);
@@ -62,7 +63,7 @@ int main(int argc, char** argv) {
     const DwPlan p = plan_dw(out, in, B, ncu);
     printf("out %d in %d B %lld  CUs %d  dW: %d x %d tiles, nsplit %d ksplit %lld\n", out, in, (long long)B, ncu, p.bm, p.bn, p.nsplit, (long long)p.ks);
   }
-  float ms = best_ms([&] { launch_backward_weight(0, dD, dH, dPart, out, in, B, ncu, dG); });
+  float ms = best_ms([&] { launch_backward_weight(0, dD, dH, dPart, out, in, B, ncu, dG, dDb); });
   printf("dW   gemm + reduce     %8.3f ms  %6.2f TFLOP/s\n", ms, flops / (ms * 1e-3) / 1e12);
   // check dW against a host dot product on a few entries
   {
@@ -76,6 +77,16 @@ int main(int argc, char** argv) {
       maxrel = fmax(maxrel, fabs(g[i + (size_t)out * j] - ref) / (fabs(ref) + 1e-9));
     }
     printf("dW   max rel err vs host on 24 entries: %.2e\n", maxrel);
+    std::vector<double> db((size_t)out);
+    hipMemcpy(db.data(), dDb, db.size() * 8, hipMemcpyDeviceToHost);
+    double maxabs = 0;
+    for (int t = 0; t < 12; ++t) {
+      const int i = (int)((t * 7919u) % out);
+      double ref = 0;
+      for (int64_t b = 0; b < B; ++b) ref += hD[i + (size_t)out * b];
+      maxabs = fmax(maxabs, fabs(db[i] - ref));
+    }
+    printf("db   max abs err vs host on 12 rows (sums of %lld values in [-0.5, 0.5)): %.2e\n", (long long)B, maxabs);
   }
   ms = best_ms([&] { launch_backward_data(0, dW, dD, dH, dDp, out, in, B, SI_ACT_RELU); });
   printf("dX   W' * Delta .* act' %8.3f ms  %6.2f TFLOP/s\n", ms, flops / (ms * 1e-3) / 1e12);
