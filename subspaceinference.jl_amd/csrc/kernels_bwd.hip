@@ -166,17 +166,28 @@ __device__ __forceinline__ void bwd_static_for(F&& f) {
 template <int BM, int BN>
 __device__ __forceinline__ void dw_f64_dma_body(const double* __restrict__ A, int64_t lda, const double* __restrict__ Bm,
                                                 int64_t ldb, double* __restrict__ C, int64_t ldc, int Mrows, int64_t Ncols,
-                                                int64_t Kdim, int64_t ksplit, int nMt, double* __restrict__ dbpart,
-                                                double* smem) {
+                                                int64_t Kdim, int64_t ksplit, int nMt, int nNt, int nsplit,
+                                                double* __restrict__ dbpart, double* smem) {
   constexpr int WM = 2, WN = 4, NWAVES = 8;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   constexpr int STAGE = 16 * (BM + BN);              // doubles per stage
   constexpr int NA = 16 * BM / 128, NBI = 16 * BN / 128;   // 1 KiB DMA instructions per tile: A part, B part
   static_assert(BM % 32 == 0 && BN % 64 == 0 && (BM / 16) % 2 == 0 && (BN / 16) % 2 == 0, "tile shape");
 
-  const int mt = (int)(blockIdx.x % nMt);
-  const int64_t nt = blockIdx.x / nMt;
-  const int64_t split = blockIdx.y;
+  // Workgroup -> (tile, split): the launch is ONE round of workgroups, dealt to the 8 XCDs round-robin by the dispatcher.  XCD x
+  // takes the contiguous range [x * per_xcd, (x+1) * per_xcd) of the split-major work list, i.e. one or two whole k ranges with
+  // all their tiles: the tiles of a split walk the same columns of Delta and H together and find them in that XCD's L2.
+  // (Tiles numbered plainly over blockIdx: FETCH_SIZE 10.7 GB per launch at cfg2 -- every tile fetched its operands past the
+  // L2 -- against 1.5 GB of operands.)
+  const int tiles = nMt * nNt;
+  const int total = tiles * nsplit;
+  const int per_xcd = (total + 7) >> 3;
+  const int work = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || work >= total) return;   // uniform per workgroup, before any barrier
+  const int64_t split = work / tiles;
+  const int tile = work % tiles;
+  const int mt = tile % nMt;
+  const int64_t nt = tile / nMt;
   const int64_t k0 = split * ksplit;
   int64_t klen = Kdim - k0;
   if (klen > ksplit) klen = ksplit;
@@ -303,9 +314,9 @@ template <int BM, int BN>
 __global__ __launch_bounds__(512, 4) void dw_f64_dma_kernel(const double* __restrict__ A, int64_t lda,
                                                             const double* __restrict__ Bm, int64_t ldb, double* __restrict__ C,
                                                             int64_t ldc, int Mrows, int64_t Ncols, int64_t Kdim, int64_t ksplit,
-                                                            int nMt, double* __restrict__ dbpart) {
+                                                            int nMt, int nNt, int nsplit, double* __restrict__ dbpart) {
   extern __shared__ double smem_dw[];
-  dw_f64_dma_body<BM, BN>(A, lda, Bm, ldb, C, ldc, Mrows, Ncols, Kdim, ksplit, nMt, dbpart, smem_dw);
+  dw_f64_dma_body<BM, BN>(A, lda, Bm, ldb, C, ldc, Mrows, Ncols, Kdim, ksplit, nMt, nNt, nsplit, dbpart, smem_dw);
 }
 
 template <int BM, int BN>
@@ -317,8 +328,9 @@ static void launch_dw_dma(hipStream_t st, const double* Delta, const double* Hpr
   auto kern = dw_f64_dma_kernel<BM, BN>;
   static LdsOptIn optin;
   optin.ensure(reinterpret_cast<const void*>(kern), lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(nMt * nNt), (unsigned)nsplit), dim3(512), lds, st, Delta, (int64_t)out, Hprev,
-                     (int64_t)in, part, (int64_t)out, out, (int64_t)in, B, ks, nMt, dbpart);
+  const int64_t total = (int64_t)nMt * nNt * nsplit;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((total + 7) / 8 * 8)), dim3(512), lds, st, Delta, (int64_t)out, Hprev,
+                     (int64_t)in, part, (int64_t)out, out, (int64_t)in, B, ks, nMt, (int)nNt, nsplit, dbpart);
 }
 
 static bool dw_dma_ok(const double* Delta, const double* Hprev, const double* part, int32_t out, int32_t in, int64_t B) {

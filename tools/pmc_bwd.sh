@@ -10,7 +10,7 @@ for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_
   tag=$(echo $c | tr ' ' '_' | cut -c1-40)
   timeout -k 10 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/p_$tag -o p -- $R/tools/bin/bwd_bench 960 960 100000 > /dev/null 2> $O/p_$tag.err || { echo "pass $c failed"; tail -3 $O/p_$tag.err; }
   echo "== --pmc $c" >> $O/summary.txt
-  python3 $R/tools/pmc_summary.py $O/p_$tag gemm_f64 >> $O/summary.txt
+  python3 $R/tools/pmc_summary.py $O/p_$tag _f64_ >> $O/summary.txt
   rm -rf $O/p_$tag
 done
 cat $O/summary.txt
