@@ -6,6 +6,7 @@
 // leave the GPU: si_train_push feeds K1 from the device-resident Float32 vector.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <string>
 
 #include "si_internal.h"
@@ -89,6 +90,10 @@ void free_train(Ctx* c) {
   release(t->scratch.bwpart); release(t->scratch.rspart); release(t->scratch.wt); release(t->scratch.dbtmp);
   for (auto& h : t->hs) release(h);
   for (auto& h : t->pidx) release(h);
+  for (int b = 0; b < 2; ++b) {
+    if (t->idx_pin[b]) (void)hipHostFree(t->idx_pin[b]);
+    if (t->idx_ev[b]) (void)hipEventDestroy(t->idx_ev[b]);
+  }
   delete t;
   c->train = nullptr;
 }
@@ -144,7 +149,12 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
             (!plan.input_spatial || alloc(&t->Xc, (size_t)plan.in_elems * batch_max)) &&
             alloc(&t->X, (size_t)in_dim * B_total) && alloc(&t->Y, (size_t)out_dim * B_total) &&
             alloc(&t->Xb, (size_t)in_dim * batch_max) && alloc(&t->Yb, (size_t)out_dim * batch_max) &&
-            alloc(&t->idx, (size_t)batch_max) && alloc(&t->w32, (size_t)N) && alloc(&t->m32, (size_t)N) &&
+            alloc(&t->idx, (size_t)batch_max) &&
+            hipHostMalloc((void**)&t->idx_pin[0], (size_t)batch_max * sizeof(int64_t), hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void**)&t->idx_pin[1], (size_t)batch_max * sizeof(int64_t), hipHostMallocDefault) == hipSuccess &&
+            hipEventCreateWithFlags(&t->idx_ev[0], hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&t->idx_ev[1], hipEventDisableTiming) == hipSuccess &&
+            alloc(&t->w32, (size_t)N) && alloc(&t->m32, (size_t)N) &&
             alloc(&t->v32, (size_t)N) && alloc(&t->w64, (size_t)pad_ld(N)) && alloc(&t->gw, (size_t)pad_ld(N)) &&
             alloc(&t->delta[0], (size_t)maxw * batch_max) && alloc(&t->delta[1], (size_t)maxw * batch_max) &&
             alloc(&t->bwpart, maxpart) && alloc(&t->rspart, (size_t)rowsum_chunks() * maxw) &&
@@ -179,43 +189,58 @@ static int32_t train_gradient(si_ctx* ctx, const char* who, const int64_t* idx, 
   TrainState* t = ctx->train;
   if (!t) return fail(ctx, SI_ERR_STATE, std::string(who) + ": call si_train_setup first");
   if (!idx || nb <= 0 || nb > t->Bmax) return fail(ctx, SI_ERR_INVALID, std::string(who) + ": bad batch");
-  for (int64_t j = 0; j < nb; ++j)
+  bool in_order = true;   // idx = 0, 1, ..., nb-1 (a full batch of an unshuffled DataLoader): the data are used in place
+  for (int64_t j = 0; j < nb; ++j) {
     if (idx[j] < 0 || idx[j] >= t->Btot)
       return fail(ctx, SI_ERR_INVALID, std::string(who) + ": BoundsError: batch index out of range");
+    in_order = in_order && idx[j] == j;
+  }
   SI_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int64_t N = t->N;
   const size_t nl = t->layers.size();
-  SI_HIP(ctx, hipMemcpyAsync(t->idx, idx, (size_t)nb * sizeof(int64_t), hipMemcpyHostToDevice, st));
-  SI_HIP(ctx, hipStreamSynchronize(st));  // idx is caller-owned
-  hipLaunchKernelGGL(gather_cols_kernel, dim3(grid_for((int64_t)t->in_dim * nb, ctx->num_cu)), dim3(256), 0, st, t->X,
-                     t->in_dim, t->idx, nb, t->Xb);
-  hipLaunchKernelGGL(gather_cols_kernel, dim3(grid_for((int64_t)t->out_dim * nb, ctx->num_cu)), dim3(256), 0, st, t->Y,
-                     t->out_dim, t->idx, nb, t->Yb);
+  const double *Xb = t->X, *Yb = t->Y;
+  if (!in_order) {
+    // idx is caller-owned: copied into a pinned buffer, shipped asynchronously; the buffer is free again once its event has
+    // passed (two steps later at the earliest) -- no synchronisation of the stream, the call returns while the GPU works
+    const int b = t->idx_slot;
+    t->idx_slot ^= 1;
+    if (t->idx_busy[b]) SI_HIP(ctx, hipEventSynchronize(t->idx_ev[b]));
+    std::memcpy(t->idx_pin[b], idx, (size_t)nb * sizeof(int64_t));
+    SI_HIP(ctx, hipMemcpyAsync(t->idx, t->idx_pin[b], (size_t)nb * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    SI_HIP(ctx, hipEventRecord(t->idx_ev[b], st));
+    t->idx_busy[b] = true;
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(grid_for((int64_t)t->in_dim * nb, ctx->num_cu)), dim3(256), 0, st, t->X,
+                       t->in_dim, t->idx, nb, t->Xb);
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(grid_for((int64_t)t->out_dim * nb, ctx->num_cu)), dim3(256), 0, st, t->Y,
+                       t->out_dim, t->idx, nb, t->Yb);
+    Xb = t->Xb;
+    Yb = t->Yb;
+  }
   hipLaunchKernelGGL(widen_kernel, dim3(grid_for(N, ctx->num_cu)), dim3(256), 0, st, t->w32, N, t->w64);
   if (t->plan.has_conv) {
     // chains with Conv / MaxPool / flatten layers: the generic forward / reverse sweep of capi_net.hip
     const NetPlan& p = t->plan;
-    const double* xin = t->Xb;
+    const double* xin = Xb;
     if (p.input_spatial) {
-      net_input(ctx, p, t->Xb, t->Xc, nb);
+      net_input(ctx, p, Xb, t->Xc, nb);
       xin = t->Xc;
     }
     int32_t rc = net_forward(ctx, p, t->w64, xin, nb, t->hs.data(), t->wpack, false, nullptr, t->pidx.data());
     if (rc != SI_OK) return rc;
     const int64_t d = (int64_t)t->out_dim * nb;
     const double* yhat = t->hs[nl - 1];
-    launch_sse(st, yhat, t->Yb, d, t->ssepart, sse_num_blocks(d, ctx->num_cu), t->sse);
+    launch_sse(st, yhat, Yb, d, t->ssepart, sse_num_blocks(d, ctx->num_cu), t->sse);
     ProfScope ps(ctx, SI_K_BACKWARD, 0.0, 0.0);
     SI_HIP(ctx, hipMemsetAsync(t->gw, 0, (size_t)pad_ld(N) * sizeof(double), st));
-    launch_delta_out(st, t->Yb, yhat, d, -2.0 / d_total, SI_ACT_IDENTITY, t->delta[0]);   // d mse / d yhat = 2 (yhat - y) / d
+    launch_delta_out(st, Yb, yhat, d, -2.0 / d_total, SI_ACT_IDENTITY, t->delta[0]);   // d mse / d yhat = 2 (yhat - y) / d
     if ((rc = net_backward(ctx, p, t->w64, xin, nb, t->hs.data(), t->delta[0], t->delta[1], t->gw, t->scratch)) != SI_OK) return rc;
     SI_HIP(ctx, hipGetLastError());
     t->grad_ready = true;
     return SI_OK;
   }
   // forward with every layer's output kept; a narrow head is fed from the epilogue of the layer in front of it
-  const double* h = t->Xb;
+  const double* h = Xb;
   const size_t nplain = t->fuse_tail ? nl - 2 : nl;
   for (size_t l = 0; l < nplain; ++l) {
     const si_layer& ly = t->layers[l];
@@ -233,12 +258,12 @@ static int32_t train_gradient(si_ctx* ctx, const char* who, const int64_t* idx, 
       launch_dense_f64_fused(st, t->w64 + ly.w_off, t->w64 + ly.b_off, h, ly.out, ly.in, nb, ly.act, t->w64 + ll.w_off, ll.out,
                              t->part, ChainBatch(), t->hs[nl - 2]);
     }
-    launch_tail_sse(st, t->part, t->fuse_slots, ll.out, nb, t->w64 + ll.b_off, ll.act, t->Yb, t->hs[nl - 1], t->ssepart,
+    launch_tail_sse(st, t->part, t->fuse_slots, ll.out, nb, t->w64 + ll.b_off, ll.act, Yb, t->hs[nl - 1], t->ssepart,
                     sse_blocks);
     launch_sse_final(st, t->ssepart, sse_blocks, t->sse);
     h = t->hs[nl - 1];
   } else {
-    launch_sse(st, h, t->Yb, d, t->ssepart, sse_blocks, t->sse);
+    launch_sse(st, h, Yb, d, t->ssepart, sse_blocks, t->sse);
   }
   {
     double bflops = 0.0;
@@ -246,8 +271,8 @@ static int32_t train_gradient(si_ctx* ctx, const char* who, const int64_t* idx, 
     ProfScope ps(ctx, SI_K_BACKWARD, bflops, 0.0);
     SI_HIP(ctx, hipMemsetAsync(t->gw, 0, (size_t)pad_ld(N) * sizeof(double), st));
     // d mse / d yhat = 2 (yhat - y) / d
-    launch_delta_out(st, t->Yb, h, d, -2.0 / d_total, t->layers[nl - 1].act, t->delta[0]);
-    DenseSweep sw{t->layers.data(), nl, t->fuse_tail, t->w64, t->Xb, t->hs.data(), {t->delta[0], t->delta[1]}, t->gw, t->rspart,
+    launch_delta_out(st, Yb, h, d, -2.0 / d_total, t->layers[nl - 1].act, t->delta[0]);
+    DenseSweep sw{t->layers.data(), nl, t->fuse_tail, t->w64, Xb, t->hs.data(), {t->delta[0], t->delta[1]}, t->gw, t->rspart,
                   t->bwpart, nb};
     const int32_t rcs = dense_reverse_sweep(ctx, st, sw);
     if (rcs != SI_OK) return rcs;

@@ -66,6 +66,12 @@ struct TrainState {
   int32_t in_dim = 0, out_dim = 0;
   double *X = nullptr, *Y = nullptr, *Xb = nullptr, *Yb = nullptr;
   int64_t* idx = nullptr;
+  // batch indices travel through two pinned buffers (copy in, async H2D, event): a step never synchronises the stream, so the
+  // caller's work between two steps (its next batch, the K1 push) overlaps the GPU's
+  int64_t* idx_pin[2] = {nullptr, nullptr};
+  hipEvent_t idx_ev[2] = {nullptr, nullptr};
+  bool idx_busy[2] = {false, false};
+  int idx_slot = 0;
   float *w32 = nullptr, *m32 = nullptr, *v32 = nullptr;
   double *w64 = nullptr, *gw = nullptr;
   std::vector<double*> hs;
