@@ -12,8 +12,9 @@
 //   C/D: lane l, reg r holds D[b = (r&3) + 8*(r>>2) + 4*(l>>5)][i = l&31]
 //
 // Fast kernel (in % 16 == 0, out % 4 == 0, 16-byte aligned operands): the k tiles (16 deep) of both operands go
-// global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write) into a ring of NB = 3 stages,
-// retired by a counted s_waitcnt vmcnt + ONE raw s_barrier per k tile.  LDS images are LINEAR (the DMA writes
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write) into TWO stages: per k tile
+// s_waitcnt vmcnt(0), ONE raw s_barrier, issue of tile kt+1 into the stage tile kt-1 has just left, MFMAs of tile kt
+// (the body also carries a ring of NB >= 3 stages with counted waits, and 32-deep tiles: measured, not shipped).  LDS images are LINEAR (the DMA writes
 // wave-uniform base + lane*16 B):
 //   sW[k][BM]   rows of BM floats;  the B fragment of k step (g, j), half h reads sW[8g + 4h + j][i0 + (l&31)]: 32
 //               consecutive floats per half -> conflict-free ds_read_b32
@@ -86,20 +87,21 @@ __device__ __forceinline__ void f32_fused_head(const f16v (&acc)[TM][TN], const 
 
 // (MINW only keeps the body's instantiation 1:1 with its kernel's: two __global__ instantiations sharing one body with device
 //  builtins inside lambdas do not survive the host-side pass)
-template <int BM, int BN, int WM, int WN, int NB, int MINW, bool FUSE>
+template <int BM, int BN, int WM, int WN, int NB, int MINW, bool FUSE, int BK>
 __device__ __forceinline__ void dense_f32_dma_body(const float* __restrict__ W, const float* __restrict__ bias,
                                                    const float* __restrict__ Hin, float* __restrict__ Hout, int out, int in,
                                                    int64_t B, int act, int nMt, int64_t nNt, const float* __restrict__ Wlast,
                                                    int out_last, double* __restrict__ part, const ChainBatch& cb, float* smem) {
   constexpr int NWAVES = WM * WN;
-  constexpr int BK = 16;
+  constexpr int KG = BK / 8;          // groups of 8 k values (one ds_read_b128 of H per half feeds four MFMA steps)
+  constexpr int SPR = BK / 4;         // 16-byte slots per H row
   constexpr int TM = BM / WM / 32;   // feature tiles per wave
   constexpr int TN = BN / WN / 32;   // batch tiles per wave
   constexpr int NWI = BK * BM / 256; // LDS-DMA instructions (1 KiB each) per k tile: W part
   constexpr int NHI = BN * BK / 256; //                                               H part
   constexpr int NSLOT = (NWI + NHI + NWAVES - 1) / NWAVES;
   constexpr int STAGE = BK * BM + BN * BK;  // floats per ring stage
-  static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && (BK * BM) % 256 == 0 && (BN * BK) % 256 == 0 && NB >= 3, "tile shape");
+  static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && (BK * BM) % 256 == 0 && (BN * BK) % 256 == 0 && NB >= 2 && (BK == 16 || BK == 32), "tile shape");
 
   const int64_t bid = blockIdx.x;
   const int xcd = (int)(bid & 7);
@@ -133,9 +135,9 @@ __device__ __forceinline__ void dense_f32_dma_body(const float* __restrict__ W, 
       dsto[s] = id * 256;
       ++nvalid;
     } else if (id < NWI + NHI) {
-      const int S = (id - NWI) * 64 + lane;      // 16-byte slot inside sH: row b = S >> 2, slot' = S & 3
-      const int b = S >> 2;
-      const int slot = (S & 3) ^ ((b >> 2) & 3); // source-side swizzle
+      const int S = (id - NWI) * 64 + lane;      // 16-byte slot inside sH: row b = S / SPR, slot' = S % SPR
+      const int b = S / SPR;
+      const int slot = (S % SPR) ^ (BK == 16 ? (b >> 2) & 3 : (b >> 1) & 7); // source-side swizzle
       int64_t gb = b0 + b;
       if (gb > B - 1) gb = B - 1;
       src[s] = Hin + (int64_t)in * gb + 4 * slot;
@@ -170,29 +172,17 @@ __device__ __forceinline__ void dense_f32_dma_body(const float* __restrict__ W, 
 
   // fragment addresses (floats inside a stage)
   const int wfo = wm * (BM / WM) + c;            // + (8g + 4h + j) * BM + 32 a
-  int hfo[TN][2];
+  int hfo[TN][KG];
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int bl = wn * (BN / WN) + 32 * b + c;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) hfo[b][g] = BK * BM + bl * BK + 4 * ((2 * g + h) ^ ((bl >> 2) & 3));
+    for (int g = 0; g < KG; ++g) hfo[b][g] = BK * BM + bl * BK + 4 * ((2 * g + h) ^ (BK == 16 ? (bl >> 2) & 3 : (bl >> 1) & 7));
   }
 
-  issue(0, 0);
-  issue(1, 1);
-  int ring = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed once at most the DMAs of tile kt+1 (this wave's nvalid newest) are still in flight
-    if (nvalid == NSLOT)
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSLOT) : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSLOT > 1 ? NSLOT - 1 : 0) : "memory");
-    __builtin_amdgcn_s_barrier();   // everyone's pieces of tile kt are in; everyone is done reading tile kt-1
-    const int nxt = ring + 2 >= NB ? ring + 2 - NB : ring + 2;
-    issue(kt + 2, nxt);             // refills the stage of tile kt-1 (NB = 3) / an idle one (NB > 3)
-    const float* st = smem + ring * STAGE;
+  auto compute = [&](const float* st) {
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < KG; ++g) {
       f4v hf[TN];
 #pragma unroll
       for (int b = 0; b < TN; ++b) hf[b] = *reinterpret_cast<const f4v*>(st + hfo[b][g]);
@@ -208,7 +198,33 @@ __device__ __forceinline__ void dense_f32_dma_body(const float* __restrict__ W, 
 #pragma unroll
           for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(hf[b][j], wf[j][a], acc[a][b], 0, 0, 0);
     }
-    ring = ring + 1 == NB ? 0 : ring + 1;
+  };
+  if constexpr (NB == 2) {
+    // two stages (32-deep tiles: 2 x 40 KB per workgroup, two workgroups per CU): tile kt+1 is issued right behind the barrier
+    // that retires tile kt-1 and has the whole compute time of tile kt to land
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+      compute(smem + (kt & 1) * STAGE);
+    }
+  } else {
+    issue(0, 0);
+    issue(1, 1);
+    int ring = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // tile kt has landed once at most the DMAs of tile kt+1 (this wave's nvalid newest) are still in flight
+      if (nvalid == NSLOT)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSLOT) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSLOT > 1 ? NSLOT - 1 : 0) : "memory");
+      __builtin_amdgcn_s_barrier();   // everyone's pieces of tile kt are in; everyone is done reading tile kt-1
+      const int nxt = ring + 2 >= NB ? ring + 2 - NB : ring + 2;
+      issue(kt + 2, nxt);             // refills the stage of tile kt-1 (NB = 3) / an idle one (NB > 3)
+      compute(smem + ring * STAGE);
+      ring = ring + 1 == NB ? 0 : ring + 1;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail fetches must land before the workgroup retires
 
@@ -275,7 +291,7 @@ __device__ __forceinline__ void dense_f32_dma_body(const float* __restrict__ W, 
     f32_fused_head<TM, TN>(acc, gi, out, Wlast, out_last, part, cb.part_ld ? cb.part_ld : B, (int64_t)mt * WM + wm, bw0, B, lane);
 }
 
-template <int BM, int BN, int WM, int WN, int NB, int MINW, bool FUSE>
+template <int BM, int BN, int WM, int WN, int NB, int MINW, bool FUSE, int BK = 16>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f32_dma_kernel(
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ Hin, float* __restrict__ Hout, int out,
     int in, int64_t B, int act, int nMt, int64_t nNt, const float* __restrict__ Wlast, int out_last, double* __restrict__ part,
@@ -292,7 +308,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f32_dma_kernel(
     }
   }
   extern __shared__ float smem_f32[];
-  dense_f32_dma_body<BM, BN, WM, WN, NB, MINW, FUSE>(W, bias, Hin, Hout, out, in, B, act, nMt, nNt, Wlast, out_last, part, cb, smem_f32);
+  dense_f32_dma_body<BM, BN, WM, WN, NB, MINW, FUSE, BK>(W, bias, Hin, Hout, out, in, B, act, nMt, nNt, Wlast, out_last, part, cb, smem_f32);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -369,15 +385,15 @@ struct FuseArgsF32 {
   ChainBatch cb;
 };
 
-template <int BM, int BN, int WM, int WN, int NB, int MINW, bool FUSE>
+template <int BM, int BN, int WM, int WN, int NB, int MINW, bool FUSE, int BK = 16>
 static void launch_f32_dma(hipStream_t st, const float* W, const float* bias, const float* Hin, float* Hout, int32_t out, int32_t in,
                            int64_t B, int32_t act, const FuseArgsF32& fa) {
-  constexpr size_t lds = (size_t)NB * (16 * BM + BN * 16) * sizeof(float);
+  constexpr size_t lds = (size_t)NB * (BK * BM + BN * BK) * sizeof(float);
   const int nMt = (out + BM - 1) / BM;
   const int64_t nNt = (B + BN - 1) / BN;
   const int64_t groups = (nNt + 7) / 8;
   const int64_t grid = groups * nMt * 8;
-  auto kern = dense_f32_dma_kernel<BM, BN, WM, WN, NB, MINW, FUSE>;
+  auto kern = dense_f32_dma_kernel<BM, BN, WM, WN, NB, MINW, FUSE, BK>;
   static LdsOptIn optin;
   optin.ensure(reinterpret_cast<const void*>(kern), lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)fa.cb.n), dim3(64 * WM * WN), lds, st, W, bias, Hin, Hout, (int)out, (int)in, B,
@@ -413,10 +429,12 @@ static void launch_f32_any(hipStream_t st, const float* W, const float* bias, co
     launch_f32_generic<FUSE>(st, W, bias, Hin, Hout, out, in, B, act, fa);
     return;
   }
+  // two stages of 16-deep tiles (measured against the three-stage ring with counted waits on one device, tools/f32_bk32.sh:
+  // 1.45 against 1.49 ms on cfg2's 960 x 960 layer; 32-deep tiles in two stages: the same 1.45)
   if (f32_pick_bm(out) == 192)
-    launch_f32_dma<192, 128, 2, 4, 3, 4, FUSE>(st, W, bias, Hin, Hout, out, in, B, act, fa);
+    launch_f32_dma<192, 128, 2, 4, 2, 4, FUSE>(st, W, bias, Hin, Hout, out, in, B, act, fa);
   else
-    launch_f32_dma<128, 128, 2, 4, 3, 4, FUSE>(st, W, bias, Hin, Hout, out, in, B, act, fa);
+    launch_f32_dma<128, 128, 2, 4, 2, 4, FUSE>(st, W, bias, Hin, Hout, out, in, B, act, fa);
 }
 
 __global__ __launch_bounds__(256) void act_inplace_f32_kernel(float* __restrict__ H, int64_t n, int act) {

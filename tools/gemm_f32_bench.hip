@@ -35,6 +35,10 @@ struct Variant { const char* name; launch_fn plain; launch_fn fused; int bm, wm;
   [](hipStream_t st, const float* W, const float* b, const float* X, float* Y, int32_t o, int32_t i, int64_t B, int32_t a, const FuseArgsF32& fa) { launch_f32_dma<BM, BN, WM, WN, NB, MINW, false>(st, W, b, X, Y, o, i, B, a, fa); }, \
   [](hipStream_t st, const float* W, const float* b, const float* X, float* Y, int32_t o, int32_t i, int64_t B, int32_t a, const FuseArgsF32& fa) { launch_f32_dma<BM, BN, WM, WN, NB, MINW, true>(st, W, b, X, Y, o, i, B, a, fa); }, BM, WM}
 
+#define VK(BM, BN, WM, WN, NB, MINW, BK) {#BM "x" #BN " " #WM "x" #WN " nb" #NB " w" #MINW " bk" #BK, \
+  [](hipStream_t st, const float* W, const float* b, const float* X, float* Y, int32_t o, int32_t i, int64_t B, int32_t a, const FuseArgsF32& fa) { launch_f32_dma<BM, BN, WM, WN, NB, MINW, false, BK>(st, W, b, X, Y, o, i, B, a, fa); }, \
+  [](hipStream_t st, const float* W, const float* b, const float* X, float* Y, int32_t o, int32_t i, int64_t B, int32_t a, const FuseArgsF32& fa) { launch_f32_dma<BM, BN, WM, WN, NB, MINW, true, BK>(st, W, b, X, Y, o, i, B, a, fa); }, BM, WM}
+
 int main(int argc, char** argv) {
   const int out = argc > 1 ? atoi(argv[1]) : 960, in = argc > 2 ? atoi(argv[2]) : 960;
   const int64_t B = argc > 3 ? atoll(argv[3]) : 100000;
@@ -62,6 +66,8 @@ int main(int argc, char** argv) {
   std::vector<Variant> vs = {
     V(192, 128, 2, 4, 3, 4), V(128, 128, 2, 4, 3, 4), V(192, 128, 2, 4, 4, 2), V(192, 256, 2, 4, 3, 2), V(192, 64, 2, 2, 3, 3),
     V(96, 128, 1, 4, 3, 3), V(192, 128, 2, 4, 3, 2), V(192, 256, 2, 8, 3, 4),
+    VK(192, 128, 2, 4, 2, 4, 32), VK(128, 128, 2, 4, 2, 4, 32), VK(192, 128, 2, 4, 2, 4, 16), VK(192, 128, 2, 4, 3, 2, 32),
+    VK(192, 128, 2, 4, 2, 6, 16), VK(128, 128, 2, 4, 2, 6, 16), VK(128, 128, 2, 4, 2, 4, 16), V(192, 128, 2, 4, 3, 4),
   };
 
 

@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = sys.argv[1], sys.argv[2]
 F32 = len(sys.argv) > 3 and sys.argv[3] == "f32"
-KERNEL = "3, 4, true>" if F32 else "true, false, true>"   # the FUSE = true instantiation: layer 2 + fused head
+KERNEL = "2, 4, true, 16>" if F32 else "true, false, true>"   # the FUSE = true instantiation: layer 2 + fused head
 KNAME = "dense_f32_dma_kernel<192, 128" if F32 else "dense_f64_kernel<96, 128"
 KSRC = "kernels_gemm_f32.hip" if F32 else "kernels_gemm.hip"
 vals, launches, cur = {}, None, None
@@ -38,7 +38,7 @@ sha = hashlib.sha256(_code.encode()).hexdigest()[:16]   # code only: `//` commen
 busy = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (vals["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
 dur = sorted(vals["duration_ms_med"])[len(vals["duration_ms_med"]) // 2]
 rec = {
-    "kernel": ("si::dense_f32_dma_kernel<192,128,2,4,3,4,true> (fp32, layer 960x960 + fused 960->1 head), cfg2" if F32 else
+    "kernel": ("si::dense_f32_dma_kernel<192,128,2,4,2,4,true,16> (fp32, layer 960x960 + fused 960->1 head), cfg2" if F32 else
                "si::dense_f64_kernel<96,128,2,4,4,true,false,true> (layer 960x960 + fused 960->1 tail), cfg2"),
     "source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
               "tools/f32_after_f64.py f64 (the cfg2 construct, a 50-step fp64 chain and a 12-step fp32 chain: bench.py itself makes more dispatches "
