@@ -58,8 +58,29 @@ for case in range(cases):
     assert np.array_equal(zc[:, :, nch - 1], z1[:, :, 0]) and np.array_equal(lpc[:, nch - 1], lp1[:, 0])
     zw, lpw, _, wmap = ctx.sample_rwmh_weights(5, 0.1, seed=case + 1, nchains=nch)
     assert np.array_equal(wmap[:, :, 0], ctx.reconstruct(np.asfortranarray(zw[:, :, 0])))
+    # the device-resident transition loop (small chains: one launch for all transitions) == the launch-per-step loop, bit for bit
+    ctx.set_chain_loop(False)
+    z_off, lp_off, acc_off = ctx.sample_rwmh(6, 0.1, seed=case + 2, nchains=nch)
+    ctx.set_chain_loop(True)
+    z_on, lp_on, acc_on = ctx.sample_rwmh(6, 0.1, seed=case + 2, nchains=nch)
+    assert np.array_equal(z_on, z_off) and np.array_equal(lp_on, lp_off) and np.array_equal(acc_on, acc_off)
+    # compute_dtype = SI_F32 (round 4): the same density with fp32 layers -- outputs and lp against the fp64 oracle at the
+    # tolerance the header states, stacked chains == one chain at a time
+    ctx.infer_setup(table, n, m, w_swa, p, x, y, 0.8, compute_dtype=si._capi.SI_F32)
+    y32 = ctx.forward(zs[:, 0])
+    assert np.max(np.abs(y32 - yref)) <= 5e-5 * max(1.0, np.abs(yref).max()), np.max(np.abs(y32 - yref))
+    lp32 = ctx.logdensity(zs)
+    assert np.all(np.abs(lp32 - lp_ref) <= 1e-4 * np.abs(lp_ref)), (lp32, lp_ref)
+    zc32, lpc32, _ = ctx.sample_rwmh(4, 0.1, seed=case, nchains=nch)
+    z132, lp132, _ = ctx.sample_rwmh(4, 0.1, seed=case, chain_id0=nch - 1, nchains=1)
+    assert np.array_equal(zc32[:, :, nch - 1], z132[:, :, 0]) and np.array_equal(lpc32[:, nch - 1], lp132[:, 0])
+    if os.environ.get("SI_FUZZ_REPEAT"):
+        assert np.array_equal(ctx.logdensity(zs), lp32)
     # training gradient on a random batch against the restatement of Zygote's, then one optimiser step
+    # (half of the cases with a batch of whole 16-deep k tiles: the LDS-DMA weight-gradient kernel where the widths are even)
     nb = int(rng.integers(1, b + 1))
+    if b >= 16 and rng.random() < 0.5:
+        nb = max(16, nb // 16 * 16)
     opt_kind = int(rng.integers(0, 3))
     w32 = w_swa.astype(np.float32)
     ctx.train_setup(table, n, w32, x, y, b, opt_kind, 0.01, 0.9, 0.999)
