@@ -23,6 +23,46 @@ namespace {
 
 inline double& at(double* a, int n, int i, int j) { return a[i + (size_t)n * j]; }
 
+// Dot products with 16 independent partial sums (two vectors of 8 lanes): a single running sum is one chain of dependent
+// additions, 4 cycles each whatever the vector width -- the Householder reduction of a 100 x 100 matrix spent 0.3 ms in
+// exactly that chain.  The order of the additions is fixed (lane j takes elements j, j + 16, ...; lanes summed pairwise in a
+// fixed tree), so results are reproducible from run to run.
+constexpr int DL = 16;
+inline double lanes_sum(const double* l) {
+  double t[8];
+  for (int j = 0; j < 8; ++j) t[j] = l[j] + l[j + 8];
+  return ((t[0] + t[4]) + (t[1] + t[5])) + ((t[2] + t[6]) + (t[3] + t[7]));
+}
+inline double dot_lanes(const double* x, const double* y, int n) {   // (x and y may be the same vector)
+  double l[DL] = {0.0};
+  int i = 0;
+  for (; i + DL <= n; i += DL)
+    for (int j = 0; j < DL; ++j) l[j] += x[i + j] * y[i + j];
+  for (int j = 0; i + j < n; ++j) l[j] += x[i + j] * y[i + j];
+  return lanes_sum(l);
+}
+// y -= a * x (the two never overlap: said so, or the compiler keeps the loop scalar)
+inline void axpy_neg(double* __restrict y, const double* __restrict x, double a, int n) {
+  for (int i = 0; i < n; ++i) y[i] -= a * x[i];
+}
+// acc = sum_r col[r] * x[r]  and  p[r] += col[r] * vc  in one sweep over col (one column of the symmetric rank-2 step)
+inline double dot_axpy_lanes(const double* __restrict col, const double* __restrict x, double* __restrict p, double vc, int n) {
+  double l[DL] = {0.0};
+  int i = 0;
+  for (; i + DL <= n; i += DL)
+    for (int j = 0; j < DL; ++j) {
+      const double cv = col[i + j];
+      l[j] += cv * x[i + j];
+      p[i + j] += cv * vc;
+    }
+  for (int j = 0; i + j < n; ++j) {
+    const double cv = col[i + j];
+    l[j] += cv * x[i + j];
+    p[i + j] += cv * vc;
+  }
+  return lanes_sum(l);
+}
+
 // Householder tridiagonalisation.  On exit `a` holds the accumulated orthogonal matrix Q (columns), d the
 // diagonal and e the sub-diagonal (e[0] = 0) of T = Q' A Q.
 void tridiagonalize(int n, double* a, double* d, double* e) {
@@ -174,11 +214,24 @@ int ql_implicit(int n, double* a, double* d, double* e) {
 // on exit d, e (e[i] couples i and i+1) describe T; column i of `a` below the sub-diagonal holds v_i[2:] (v_i[1] = 1)
 // and tau[i] its scale;  Q = H_0 H_1 ... H_{n-3},  H_i = I - tau_i v_i v_i'.
 void tridiagonalize_factored(int n, double* a, double* d, double* e, double* tau, double* work) {
+  // One sweep over the trailing block per step instead of two: the symmetric rank-2 update of step i-1 (A -= v w' + w v') is
+  // applied to a column in the same pass that accumulates step i's product A v' from it -- half the passes over the matrix and
+  // half the short column loops (at K = 100 .. 700 those loops, not the arithmetic, are what the reduction costs).
+  double* pvec = work;            // [n]  p = tau A v, then w
+  double* vprev = work + n;       // [n]  reflector of the previous step (v[0] = 1 explicit), indexed from its first row
+  double* wprev = work + 2 * n;   // [n]  its w
+  double* vcur = work + 3 * n;    // [n]  reflector of this step, v[0] = 1 explicit
+  bool pending = false;           // (vprev, wprev) of length n - i still to be applied to A[i.., i..]
   for (int i = 0; i < n - 1; ++i) {
     const int s = n - i - 1;            // length of the column below the diagonal
-    double* x = &at(a, n, i + 1, i);    // x[0..s)
-    double xnorm2 = 0.0;
-    for (int k = 1; k < s; ++k) xnorm2 += x[k] * x[k];
+    double* ci = &at(a, n, i, i);       // column i from its diagonal: ci[0] = A(i,i), ci[1..s] = x
+    if (pending) {                      // bring column i up to date: rows i .. n-1 are vprev / wprev [0 .. s]
+      const double v0 = vprev[0], w0 = wprev[0];
+      for (int r = 0; r <= s; ++r) ci[r] -= vprev[r] * w0 + wprev[r] * v0;
+    }
+    d[i] = ci[0];
+    double* x = ci + 1;                 // x[0..s)
+    const double xnorm2 = dot_lanes(x + 1, x + 1, s - 1);
     const double alpha = x[0];
     double t = 0.0, beta = alpha;
     if (xnorm2 > 0.0) {
@@ -189,38 +242,41 @@ void tridiagonalize_factored(int n, double* a, double* d, double* e, double* tau
     }
     e[i] = beta;
     tau[i] = t;
-    d[i] = at(a, n, i, i);
-    if (t != 0.0) {
-      x[0] = 1.0;
-      // p = tau * A22 * v  (A22 = trailing s x s block, lower triangle stored)
-      double* pvec = work;
+    x[0] = beta;                        // T's sub-diagonal in place of v[0] (v[0] = 1 is implicit in the stored reflector)
+    vcur[0] = 1.0;
+    for (int k = 1; k < s; ++k) vcur[k] = x[k];
+    const bool symv = t != 0.0;
+    if (symv)
       for (int r = 0; r < s; ++r) pvec[r] = 0.0;
+    if (pending || symv) {
+      // trailing block A[i+1.., i+1..], lower triangle by columns: update with (vprev, wprev)[1 + .], product with vcur
+      const double* vp = vprev + 1;
+      const double* wp = wprev + 1;
       for (int c = 0; c < s; ++c) {
-        const double* col = &at(a, n, i + 1 + c, i + 1 + c);  // col[0] = diagonal, col[r - c] for r > c
-        const double vc = x[c];
-        double acc = col[0] * vc;
-        for (int r = c + 1; r < s; ++r) {
-          acc += col[r - c] * x[r];
-          pvec[r] += col[r - c] * vc;
+        double* col = &at(a, n, i + 1 + c, i + 1 + c);  // col[0] = diagonal, col[r - c] for r > c
+        const int len = s - c;
+        if (pending) {
+          const double vc = vp[c], wc = wp[c];
+          for (int r = 0; r < len; ++r) col[r] -= vp[c + r] * wc + wp[c + r] * vc;
         }
-        pvec[c] += acc;
-      }
-      double pv = 0.0;
-      for (int r = 0; r < s; ++r) {
-        pvec[r] *= t;
-        pv += pvec[r] * x[r];
-      }
-      const double half = 0.5 * t * pv;
-      for (int r = 0; r < s; ++r) pvec[r] -= half * x[r];   // w = p - (tau/2)(p'v) v
-      // A22 -= v w' + w v'  (lower triangle)
-      for (int c = 0; c < s; ++c) {
-        double* col = &at(a, n, i + 1 + c, i + 1 + c);
-        const double vc = x[c], wc = pvec[c];
-        for (int r = c; r < s; ++r) col[r - c] -= x[r] * wc + pvec[r] * vc;
+        if (symv) {
+          const double vc = vcur[c];
+          pvec[c] += col[0] * vc + dot_axpy_lanes(col + 1, vcur + c + 1, pvec + c + 1, vc, len - 1);
+        }
       }
     }
-    x[0] = beta;  // keep T's sub-diagonal in place of v[0] (v[0] = 1 is implicit)
+    pending = symv;
+    if (symv) {
+      for (int r = 0; r < s; ++r) pvec[r] *= t;
+      const double pv = dot_lanes(pvec, vcur, s);
+      const double half = 0.5 * t * pv;
+      for (int r = 0; r < s; ++r) {
+        wprev[r] = pvec[r] - half * vcur[r];   // w = p - (tau/2)(p'v) v
+        vprev[r] = vcur[r];
+      }
+    }
   }
+  if (pending) at(a, n, n - 1, n - 1) -= 2.0 * vprev[0] * wprev[0];
   d[n - 1] = at(a, n, n - 1, n - 1);
   if (n >= 2) tau[n - 2] = 0.0;  // the last "reflector" acts on a single element: H = I
 }
@@ -370,13 +426,10 @@ int sym_eig_top_unverified(int n, double* a, int m, double* w_top, double* V) {
       tridiag_shift_solve(n, u0, u1, u2, l, sw.data(), x);
       for (int c = cluster0; c < k; ++c) {  // modified Gram-Schmidt inside the cluster
         const double* vc = V + (size_t)c * n;
-        double dot = 0.0;
-        for (int i = 0; i < n; ++i) dot += vc[i] * x[i];
-        for (int i = 0; i < n; ++i) x[i] -= dot * vc[i];
+        const double dot = dot_lanes(vc, x, n);
+        axpy_neg(x, vc, dot, n);
       }
-      double nrm = 0.0;
-      for (int i = 0; i < n; ++i) nrm += x[i] * x[i];
-      nrm = std::sqrt(nrm);
+      const double nrm = std::sqrt(dot_lanes(x, x, n));
       if (!(nrm > 0.0) || !std::isfinite(nrm)) return 1;
       for (int i = 0; i < n; ++i) x[i] /= nrm;
     }
@@ -390,11 +443,9 @@ int sym_eig_top_unverified(int n, double* a, int m, double* w_top, double* V) {
     const int s = n - i - 1;
     for (int c = 0; c < m; ++c) {
       double* z = V + (size_t)c * n + i + 1;
-      double dot = z[0];
-      for (int r = 1; r < s; ++r) dot += v[r] * z[r];
-      dot *= t;
+      const double dot = (z[0] + dot_lanes(v + 1, z + 1, s - 1)) * t;
       z[0] -= dot;
-      for (int r = 1; r < s; ++r) z[r] -= dot * v[r];
+      axpy_neg(z + 1, v + 1, dot, s - 1);
     }
   }
   return 0;
@@ -440,24 +491,17 @@ int sym_eig_top(int n, const double* g, int m, double* w_top, double* V) {
   std::vector<double> a(g, g + (size_t)n * n);
   if (sym_eig_top_unverified(n, a.data(), m, w_top, V) != 0) return 1;
   double fro = 0.0;
-  for (size_t i = 0; i < (size_t)n * n; ++i) fro += g[i] * g[i];
+  for (int j = 0; j < n; ++j) fro += dot_lanes(g + (size_t)j * n, g + (size_t)j * n, n);
   fro = std::sqrt(fro);
   std::vector<double> r(n);
   for (int k = 0; k < m; ++k) {
     const double* v = V + (size_t)k * n;
-    for (int i = 0; i < n; ++i) r[i] = -w_top[k] * v[i];
-    for (int j = 0; j < n; ++j) {
-      const double vj = v[j];
-      const double* col = g + (size_t)j * n;
-      for (int i = 0; i < n; ++i) r[i] += col[i] * vj;
-    }
-    double res = 0.0;
-    for (int i = 0; i < n; ++i) res += r[i] * r[i];
+    for (int i = 0; i < n; ++i) r[i] = dot_lanes(g + (size_t)i * n, v, n) - w_top[k] * v[i];   // g is symmetric: row i = column i
+    const double res = dot_lanes(r.data(), r.data(), n);
     if (!(std::sqrt(res) <= 1e-12 * fro)) return 1;
     for (int c = 0; c <= k; ++c) {
       const double* vc = V + (size_t)c * n;
-      double dot = 0.0;
-      for (int i = 0; i < n; ++i) dot += vc[i] * v[i];
+      const double dot = dot_lanes(vc, v, n);
       if (!(std::fabs(dot - (c == k ? 1.0 : 0.0)) <= 1e-10)) return 1;
     }
   }
