@@ -31,7 +31,8 @@ for case in range(cases):
     dt = np.float32 if rng.random() < 0.6 else np.float64
     how = int(rng.integers(0, 3))            # 0 host pushes, 1 device pushes, 2 one batched device push with a padded ld
     max_cols = int(rng.integers(1, k + 1)) if rng.random() < 0.2 else 0
-    print("case %d N %d K %d %s how %d max_cols %d" % (case, n, k, dt.__name__, how, max_cols), flush=True)
+    a32 = rng.random() < 0.25               # the opt-in fp32 storage of the deviation matrix (si_construct_set_storage)
+    print("case %d N %d K %d %s how %d max_cols %d%s" % (case, n, k, dt.__name__, how, max_cols, " A fp32" if a32 else ""), flush=True)
     base = 0.3 * rng.standard_normal(n)
     snaps = []
     for j in range(k):
@@ -39,6 +40,8 @@ for case in range(cases):
         snaps.append(base.astype(dt))
     ns = [float(1 + j // 2) for j in range(k)]
     ctx.construct_begin(n, k, max_cols)
+    if a32:
+        ctx.construct_set_storage(0)
     code = 0 if dt == np.float32 else 1
     if how == 0:
         for w, nn in zip(snaps, ns):
@@ -57,6 +60,8 @@ for case in range(cases):
         ctx.synchronize()
         del dev
     w_ref, a_ref = so.construct_stream(snaps, ns)
+    if a32:
+        a_ref = a_ref.astype(np.float32).astype(np.float64)   # columns formed in fp64, stored rounded once
     if max_cols:
         a_ref = a_ref[:, -max_cols:]     # the paper's column shift: the newest max_cols deviation columns
     kk = a_ref.shape[1]
