@@ -1304,12 +1304,12 @@ static int32_t eval_density_f32(si_ctx* ctx, int c0, int nc, const double** yhat
       // the head's bias is added in fp64 from the fp64 weight vector (same number the fp32 copy was rounded from)
       launch_tail_sse(ctx->stream, ctx->d_part, ctx->fuse_slots32, ll.out, B, ctx->d_w + ll.b_off, ll.act, ctx->d_Y,
                       yhat_out ? ctx->d_yhat : nullptr, ctx->d_ssepart, ctx->sse_blocks, cb);
-      launch_sse_final(ctx->stream, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, nc);
+      if (!ctx->defer_sse_final) launch_sse_final(ctx->stream, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, nc);
     }
   } else {
     ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d * dn, 12.0 * (double)d * dn);
     launch_sse_f32(ctx->stream, h, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, nc, ctx->act_elems,
-                   yhat_out ? ctx->d_yhat : nullptr, d);
+                   yhat_out ? ctx->d_yhat : nullptr, d, !ctx->defer_sse_final);
   }
   SI_HIP(ctx, hipGetLastError());
   if (yhat_out) *yhat_out = ctx->d_yhat;   // slot j at + j * out_dim*B
@@ -1339,7 +1339,7 @@ static int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out
     const int64_t d = (int64_t)ctx->out_dim * B;
     {
       ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d, 16.0 * (double)d);
-      launch_sse(ctx->stream, last, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, 1, ctx->act_elems);
+      launch_sse(ctx->stream, last, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, 1, ctx->act_elems, !ctx->defer_sse_final);
     }
     SI_HIP(ctx, hipGetLastError());
     if (yhat_out) *yhat_out = last;
@@ -1392,7 +1392,7 @@ static int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out
       ProfScope ps(ctx, SI_K_SSE, (3.0 + ctx->fuse_slots) * (double)d, (16.0 + 8.0 * ctx->fuse_slots) * (double)d);
       launch_tail_sse(ctx->stream, ctx->d_part, ctx->fuse_slots, ll.out, B, ctx->d_w + ll.b_off, ll.act, ctx->d_Y, nullptr,
                       ctx->d_ssepart, ctx->sse_blocks, cb1);
-      launch_sse_final(ctx->stream, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, 1);
+      if (!ctx->defer_sse_final) launch_sse_final(ctx->stream, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, 1);
     }
     SI_HIP(ctx, hipGetLastError());
     return SI_OK;
@@ -1438,12 +1438,12 @@ static int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out
       ProfScope ps(ctx, SI_K_SSE, (3.0 + ctx->fuse_slots) * (double)d * dn, (16.0 + 8.0 * ctx->fuse_slots) * (double)d * dn);
       launch_tail_sse(ctx->stream, ctx->d_part, ctx->fuse_slots, ll.out, B, ctx->d_w + ll.b_off, ll.act, ctx->d_Y,
                       yhat_out ? ctx->d_yhat : nullptr, ctx->d_ssepart, ctx->sse_blocks, cb);
-      launch_sse_final(ctx->stream, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, nc);
+      if (!ctx->defer_sse_final) launch_sse_final(ctx->stream, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, nc);
     }
     h = ctx->d_yhat;
   } else {
     ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d * dn, 16.0 * (double)d * dn);
-    launch_sse(ctx->stream, h, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, nc, ctx->act_elems);
+    launch_sse(ctx->stream, h, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, nc, ctx->act_elems, !ctx->defer_sse_final);
   }
   SI_HIP(ctx, hipGetLastError());
   if (yhat_out) *yhat_out = h;
@@ -1889,18 +1889,31 @@ static int32_t sample_rwmh_impl(si_ctx* ctx, const char* who, int64_t itr, doubl
   }
   // the proposal weights of ALL chains are still in d_w at accept time only when one pass of launches carries them all
   const bool select_path = W_out && C <= ctx->fw_slots;
-  // one transition for all chains; the transition index is a device-side counter, so the launches are identical
+  // one transition for all chains; the transition index is a device-side counter, so the launches are identical.
+  // When one pass of launches carries all chains (and the prior term is off) the tail of a transition is ONE launch: the last
+  // stage of the SSE reduction, the accept step and the next transition's proposal (rwmh_tail_kernel) -- same functions, same
+  // order, same bits; otherwise sse_final / accept / propose stay separate kernels.
+  const bool fused_tail = C <= ctx->fw_slots && !(ctx->sigma_p > 0.0) && ctx->chain_loop_enabled;
+  int64_t tdone = 0;
   auto transition = [&]() -> int32_t {
-    {
+    if (!fused_tail || tdone == 0) {
       ProfScope ps(ctx, SI_K_RWMH, 0, 0);
       launch_rwmh_propose(ctx->stream, ctx->d_zcur, ctx->d_zprop, M, C, sigma_z, seed, chain_id0, ctx->d_steps);
     }
+    ctx->defer_sse_final = fused_tail;
     const int32_t r = eval_density_all(ctx, C);
+    ctx->defer_sse_final = false;
     if (r != SI_OK) return r;
     ProfScope ps(ctx, SI_K_RWMH, 0, 0);
-    launch_rwmh_accept(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->d_lpcur, ctx->d_sse, ctx->d_nacc, M, C, c0, s2, seed,
-                       chain_id0, ctx->d_steps, dZ, dlp, itr, ctx->sigma_p > 0.0 ? ctx->d_wsq : nullptr, prior_c0(ctx),
-                       ctx->sigma_p * ctx->sigma_p, select_path ? ctx->d_accflag : nullptr);
+    if (fused_tail)
+      launch_rwmh_tail(ctx->stream, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse, ctx->d_zcur, ctx->d_zprop, ctx->d_lpcur, ctx->d_nacc, M,
+                       C, c0, s2, sigma_z, seed, chain_id0, ctx->d_steps, dZ, dlp, itr, select_path ? ctx->d_accflag : nullptr,
+                       tdone + 1 < itr);
+    else
+      launch_rwmh_accept(ctx->stream, ctx->d_zcur, ctx->d_zprop, ctx->d_lpcur, ctx->d_sse, ctx->d_nacc, M, C, c0, s2, seed,
+                         chain_id0, ctx->d_steps, dZ, dlp, itr, ctx->sigma_p > 0.0 ? ctx->d_wsq : nullptr, prior_c0(ctx),
+                         ctx->sigma_p * ctx->sigma_p, select_path ? ctx->d_accflag : nullptr);
+    ++tdone;
     return SI_OK;
   };
   hipError_t e = hipSuccess;

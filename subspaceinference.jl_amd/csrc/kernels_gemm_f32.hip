@@ -516,9 +516,9 @@ __global__ __launch_bounds__(256) void sse_partial_f32_kernel(const float* __res
   if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 void launch_sse_f32(hipStream_t st, const float* yhat, const double* y, int64_t d, double* part, int nblocks, double* sse_out, int nch,
-                    int64_t yhat_stride, double* yhat64, int64_t yhat64_stride) {
+                    int64_t yhat_stride, double* yhat64, int64_t yhat64_stride, bool with_final) {
   hipLaunchKernelGGL(sse_partial_f32_kernel, dim3(nblocks, nch), dim3(256), 0, st, yhat, y, d, part, yhat_stride, yhat64, yhat64_stride);
-  launch_sse_final(st, part, nblocks, sse_out, nch);
+  if (with_final) launch_sse_final(st, part, nblocks, sse_out, nch);
 }
 #endif
 

@@ -328,9 +328,9 @@ void launch_sse_final(hipStream_t st, const double* blockpart, int nblocks, doub
 }
 
 void launch_sse(hipStream_t st, const double* yhat, const double* y, int64_t d, double* part,
-                int nblocks, double* sse_out, int nch, int64_t yhat_stride) {
+                int nblocks, double* sse_out, int nch, int64_t yhat_stride, bool with_final) {
   hipLaunchKernelGGL(sse_partial_kernel, dim3(nblocks, nch), dim3(256), 0, st, yhat, y, d, part, yhat_stride);
-  hipLaunchKernelGGL(sse_final_kernel, dim3(nch), dim3(256), 0, st, part, nblocks, sse_out);
+  if (with_final) hipLaunchKernelGGL(sse_final_kernel, dim3(nch), dim3(256), 0, st, part, nblocks, sse_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -404,6 +404,72 @@ __global__ void rwmh_accept_kernel(double* __restrict__ zcur, const double* __re
   }
 }
 
+// The tail of a transition in ONE launch (the fused sampler loop, all chains in one pass of launches): the last stage of the
+// SSE reduction (sse_final_kernel: same 256-thread sweep, same wave sums, same (r0 + r1) + (r2 + r3)), the accept step
+// (rwmh_accept_kernel) and the NEXT transition's proposal (rwmh_propose_kernel) -- three dependent 5-us launches less per
+// transition, which is a fifth of a transition for a model of the size of docs/src/nn_example.md.  Same functions in the same
+// order: the chain is bit-identical to the three-kernel form (tests/test_gpu_chain.py keeps both).
+__global__ __launch_bounds__(256) void rwmh_tail_kernel(const double* __restrict__ ssepart, int nparts, double* __restrict__ sse,
+                                                        double* __restrict__ zcur, double* __restrict__ zprop,
+                                                        double* __restrict__ lpcur, int64_t* __restrict__ nacc, int32_t M, double c0,
+                                                        double sigma2, double sigma_z, uint64_t seed, int32_t chain_id0,
+                                                        uint64_t* __restrict__ steps, double* __restrict__ Z_out,
+                                                        double* __restrict__ lp_out, int64_t itr, int32_t* __restrict__ accflag,
+                                                        int propose_next) {
+  __shared__ double red[4];
+  __shared__ double sse_s;
+  const int c = blockIdx.x;
+  {
+    double acc = 0.0;
+    const double* part = ssepart + (int64_t)c * nparts;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double t = (red[0] + red[1]) + (red[2] + red[3]);
+      sse[c] = t;
+      sse_s = t;
+    }
+    __syncthreads();
+  }
+  const uint64_t step = steps[c];
+  const uint32_t chain = (uint32_t)(chain_id0 + c);
+  const double lp_new = c0 - (sse_s / sigma2) / 2.0;
+  const double lp_old = lpcur[c];
+  bool accept;
+  if (step == 0) {
+    accept = true;
+  } else {
+    const double e = philox_randexp(seed, chain, step);
+    accept = (-e < lp_new - lp_old);  // NaN compares false => reject, as in Julia
+  }
+  const double lp_keep = accept ? lp_new : lp_old;
+  for (int m = threadIdx.x; m < M; m += blockDim.x) {
+    const double zv = accept ? zprop[m + c * M] : zcur[m + c * M];
+    zcur[m + c * M] = zv;
+    Z_out[m + (int64_t)M * (step + (uint64_t)itr * c)] = zv;
+  }
+  __syncthreads();   // zcur complete (and every thread has read steps / lpcur) before thread 0 advances them
+  if (threadIdx.x == 0) {
+    lpcur[c] = lp_keep;
+    lp_out[step + (uint64_t)itr * c] = lp_keep;
+    if (accept && step > 0) nacc[c] += 1;
+    steps[c] = step + 1;
+    if (accflag) accflag[c] = accept ? 1 : 0;
+  }
+  if (propose_next) {   // rwmh_propose_kernel of transition step + 1 on the state just written
+    const int nblk = (M + 1) >> 1;
+    for (int j = threadIdx.x; j < nblk; j += blockDim.x) {
+      double n0, n1;
+      philox_normal2(seed, chain, step + 1, (uint32_t)j, n0, n1);
+      const int m0 = 2 * j;
+      zprop[m0 + c * M] = zcur[m0 + c * M] + sigma_z * n0;
+      if (m0 + 1 < M) zprop[m0 + 1 + c * M] = zcur[m0 + 1 + c * M] + sigma_z * n1;
+    }
+  }
+}
+
 // Output map (src/space_inference.jl:125) without a second K4 pass: K4 already produced W_swa + P z' for the proposal;
 // the chain's current weights are that vector when the proposal was kept, the previous sample's otherwise.
 __global__ __launch_bounds__(256) void weights_select_kernel(const int32_t* __restrict__ flag, const double* __restrict__ wprop,
@@ -432,6 +498,12 @@ void launch_rwmh_accept(hipStream_t st, double* zcur, const double* zprop, doubl
                         int32_t* accflag) {
   hipLaunchKernelGGL(rwmh_accept_kernel, dim3(C), dim3(64), 0, st, zcur, zprop, lpcur, sse, nacc, M, c0,
                      sigma2, seed, chain_id0, steps, Z_out, lp_out, itr, wsq, c0p, sigma_p2, accflag);
+}
+void launch_rwmh_tail(hipStream_t st, const double* ssepart, int nparts, double* sse, double* zcur, double* zprop, double* lpcur,
+                      int64_t* nacc, int32_t M, int32_t C, double c0, double sigma2, double sigma_z, uint64_t seed, int32_t chain_id0,
+                      uint64_t* steps, double* Z_out, double* lp_out, int64_t itr, int32_t* accflag, bool propose_next) {
+  hipLaunchKernelGGL(rwmh_tail_kernel, dim3(C), dim3(256), 0, st, ssepart, nparts, sse, zcur, zprop, lpcur, nacc, M, c0, sigma2, sigma_z,
+                     seed, chain_id0, steps, Z_out, lp_out, itr, accflag, propose_next ? 1 : 0);
 }
 void launch_weights_select(hipStream_t st, const int32_t* flag, const double* wprop, int64_t ldw, const double* prev, double* dst,
                            int64_t ldd, int64_t N, int32_t C, int num_cu) {

@@ -236,6 +236,7 @@ struct Ctx {
   uint64_t sw_seed = 0;
   int32_t sw_chain0 = 0, sw_C = 0;
   bool sw_evaluated = false;
+  bool defer_sse_final = false;   // eval_density leaves the SSE block partials in d_ssepart (sample_rwmh_impl's fused tail sums them)
   bool chain_loop_enabled = true;   // si_set_chain_loop: 0 forces the launch-per-step loop (the parity tests compare the two)
 };
 
@@ -333,7 +334,7 @@ void launch_dense_f32_fused(hipStream_t st, const float* W, const float* bias, c
                             float* Hkeep = nullptr);
 void launch_narrow_f32(hipStream_t st, const double* src, float* dst, int64_t n);
 void launch_sse_f32(hipStream_t st, const float* yhat, const double* y, int64_t d, double* part, int nblocks, double* sse_out,
-                    int nch = 1, int64_t yhat_stride = 0, double* yhat64 = nullptr, int64_t yhat64_stride = 0);
+                    int nch = 1, int64_t yhat_stride = 0, double* yhat64 = nullptr, int64_t yhat64_stride = 0, bool with_final = true);
 void launch_tail_sse(hipStream_t st, const double* part, int slots, int out_last, int64_t B, const double* bias_last,
                      int act_last, const double* Y, double* yhat, double* blockpart, int nblocks,
                      const ChainBatch& cb = ChainBatch());
@@ -342,8 +343,9 @@ void launch_sse_final(hipStream_t st, const double* blockpart, int nblocks, doub
 // K5: sse = sum (y - yhat)^2 over d elements; deterministic two-stage
 int sse_num_blocks(int64_t d, int num_cu);
 // (nch chain slots: yhat advances by yhat_stride per slot, y is shared, part holds nch*nblocks partials)
+// (with_final = false: the block partials stay in `part`; the fused sampler loop sums them inside its accept kernel)
 void launch_sse(hipStream_t st, const double* yhat, const double* y, int64_t d, double* part,
-                int nblocks, double* sse_out, int nch = 1, int64_t yhat_stride = 0);
+                int nblocks, double* sse_out, int nch = 1, int64_t yhat_stride = 0, bool with_final = true);
 // backward pass (kernels_bwd.hip): gradient of the log-density w.r.t. the flat weights and its pull-back P' g
 void launch_backward_data(hipStream_t st, const double* W, const double* Delta, const double* Hprev, double* DeltaPrev,
                           int32_t out, int32_t in, int64_t B, int32_t act_prev);
@@ -462,6 +464,10 @@ int dense_fused_slot_feats(int32_t out);   // features per head slot of the fuse
 void launch_rwmh_init(hipStream_t st, double* zcur, double* lpcur, int64_t* nacc, uint64_t* steps, int32_t M, int32_t C);
 void launch_rwmh_propose(hipStream_t st, const double* zcur, double* zprop, int32_t M, int32_t C,
                          double sigma_z, uint64_t seed, int32_t chain_id0, const uint64_t* steps);
+// last stage of the SSE reduction + accept + the next transition's proposal in one launch (kernels_stream.hip rwmh_tail_kernel)
+void launch_rwmh_tail(hipStream_t st, const double* ssepart, int nparts, double* sse, double* zcur, double* zprop, double* lpcur,
+                      int64_t* nacc, int32_t M, int32_t C, double c0, double sigma2, double sigma_z, uint64_t seed, int32_t chain_id0,
+                      uint64_t* steps, double* Z_out, double* lp_out, int64_t itr, int32_t* accflag, bool propose_next);
 void launch_rwmh_accept(hipStream_t st, double* zcur, const double* zprop, double* lpcur,
                         const double* sse, int64_t* nacc, int32_t M, int32_t C, double c0,
                         double sigma2, uint64_t seed, int32_t chain_id0, uint64_t* steps,
