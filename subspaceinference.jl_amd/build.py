@@ -22,6 +22,7 @@ SOURCES = [
     ("kernels_stream.hip", ["-ffp-contract=off"]),
     ("kernels_chain.hip", ["-ffp-contract=off"]),
     ("kernels_gemm.hip", []),
+    ("kernels_gemm_small.hip", []),
     ("kernels_gemm_f32.hip", []),
     ("kernels_gram.hip", []),
     ("kernels_gram_wave.hip", ["-DSI_GW_PART=0"], "kernels_gram_wave0"),   # same source, three slices of the tile counts

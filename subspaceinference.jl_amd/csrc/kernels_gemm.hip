@@ -476,11 +476,18 @@ static int pick_bm(int32_t out) {
   return p128 <= p64 ? 128 : 64;
 }
 
+int dense_fused_slot_feats(int32_t out);
+int dense_fused_slots(int32_t out);
+
 void launch_dense_f64(hipStream_t st, const double* W, const double* bias, const double* Hin,
                       double* Hout, int32_t out, int32_t in, int64_t B, int32_t act, const ChainBatch& cb) {
   if (act_is_extra(act)) {   // leakyrelu / elu / softplus / selu: identity in the GEMM, one elementwise pass behind it
     launch_dense_f64(st, W, bias, Hin, Hout, out, in, B, SI_ACT_IDENTITY, cb);
     for (int s = 0; s < cb.n; ++s) launch_act_inplace(st, Hout + (int64_t)s * cb.hout, (int64_t)out * B, act);
+    return;
+  }
+  if (dense_small_applies(out, in, B, cb.n, pick_bm(out))) {   // a handful of big tiles: all latency (kernels_gemm_small.hip, same bits)
+    launch_dense_small_f64(st, W, bias, Hin, Hout, out, in, B, act, dense_fused_slot_feats(out), cb);
     return;
   }
   FuseArgs fa;
@@ -509,6 +516,11 @@ int dense_fused_slot_feats(int32_t out) {
 void launch_dense_f64_fused(hipStream_t st, const double* W, const double* bias, const double* Hin, int32_t out,
                             int32_t in, int64_t B, int32_t act, const double* Wlast, int32_t out_last, double* part,
                             const ChainBatch& cb, double* Hkeep) {
+  if (dense_small_applies(out, in, B, cb.n, pick_bm(out))) {
+    launch_dense_small_f64_fused(st, W, bias, Hin, out, in, B, act, dense_fused_slot_feats(out), dense_fused_slots(out), Wlast, out_last,
+                                 part, cb, Hkeep);
+    return;
+  }
   FuseArgs fa;
   fa.Wlast = Wlast;
   fa.out_last = out_last;

@@ -324,6 +324,14 @@ int dense_fused_slots(int32_t out);
 void launch_dense_f64_fused(hipStream_t st, const double* W, const double* bias, const double* Hin, int32_t out,
                             int32_t in, int64_t B, int32_t act, const double* Wlast, int32_t out_last, double* part,
                             const ChainBatch& cb = ChainBatch(), double* Hkeep = nullptr /* also store the layer's output */);
+// K5 for small layers (kernels_gemm_small.hip): one wave per (feature slot, 16 observations) tile, operands straight from global
+// memory; same bits as the big-tile kernel.  launch_dense_f64 / _fused route to it by shape (dense_small_applies).
+bool dense_small_applies(int32_t out, int32_t in, int64_t B, int nchains, int32_t bm);
+void launch_dense_small_f64(hipStream_t st, const double* W, const double* bias, const double* Hin, double* Hout, int32_t out,
+                            int32_t in, int64_t B, int32_t act, int32_t slot_feats, const ChainBatch& cb);
+void launch_dense_small_f64_fused(hipStream_t st, const double* W, const double* bias, const double* Hin, int32_t out, int32_t in,
+                                  int64_t B, int32_t act, int32_t slot_feats, int32_t nslots, const double* Wlast, int32_t out_last,
+                                  double* part, const ChainBatch& cb, double* Hkeep);
 // K5 in fp32 (kernels_gemm_f32.hip; compute_dtype = SI_F32): same operation and chain batching, fp32 operands / outputs on
 // v_mfma_f32_32x32x2_f32; the fused head writes fp64 partials that launch_tail_sse sums as in the fp64 path
 void launch_dense_f32(hipStream_t st, const float* W, const float* bias, const float* Hin, float* Hout, int32_t out, int32_t in,
