@@ -260,7 +260,7 @@ __device__ __forceinline__ void gemm_epilogue(d4 (&acc)[BM / WM / 16][BN / WN / 
                                               int wave, F f) {
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   constexpr int WI = BM / WM;
-  constexpr bool WIDE = VEC && (64 % (WI / 2) == 0) && (WM * WN * 16 * WI <= SMEM_ELEMS);
+  constexpr bool WIDE = VEC && ((16 * (WI / 2)) % 64 == 0) && (WM * WN * 16 * WI <= SMEM_ELEMS);   // WI = 32 / 48 / 64 / 128
   const int q = lane >> 4, c = lane & 15;
   const int mw0 = m0 + wm * WI;
   const int64_t nw0 = n0 + wn * (BN / WN);

@@ -302,8 +302,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f64_kernel(
   // one 16-row block at a time through its own slice of the (now idle) staging LDS and writes 16 B per lane with
   // consecutive lanes on consecutive features: every store instruction covers whole rows of the output tile.
   constexpr int WI = BM / WM;  // features per wave
-  constexpr bool WIDE = VEC && (64 % (WI / 2) == 0 || (WI / 2) % 64 == 0) &&
-                        (WM * WN * 16 * WI <= 2 * (BK * BMP + BN * BKP));
+  // (any WI whose 16-row block is a whole number of 64-lane sweeps: 32 / 64 / 128 features keep one feature pair per lane, 48
+  //  -- the 96-row tile -- walks three of them and reloads its bias pair per chunk)
+  constexpr bool WIDE = VEC && ((16 * (WI / 2)) % 64 == 0) && (WM * WN * 16 * WI <= 2 * (BK * BMP + BN * BKP));
   const int iw0 = i0 + wm * WI;
   const int64_t bw0 = b0 + wn * (BN / WN);
   auto finish = [&](double v) -> double {
@@ -363,9 +364,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f64_kernel(
     constexpr int NCH = 16 * CH_ROW / 64;       // chunks per lane per 16-row block
     double* reg = smem + wave * (16 * WI);      // wave-private: no workgroup barrier needed (LDS is in-order per wave)
     // with 64 % CH_ROW == 0 a lane keeps the same feature pair for every chunk: its bias pair is loaded once
+    constexpr bool FIXCOL = 64 % CH_ROW == 0;   // the lane's feature pair is the same for every chunk
     const int col2_fixed = lane % CH_ROW;
     double2 bfix = make_double2(0.0, 0.0);
-    if (CH_ROW <= 64) {
+    if (FIXCOL) {
       const int gi = iw0 + 2 * col2_fixed;
       if (gi + 1 < out) bfix = *reinterpret_cast<const double2*>(bias + gi);
     }
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f64_kernel(
         const int gi = iw0 + 2 * col2;
         const int64_t gb = bw0 + bt * 16 + row;
         double2 bv = bfix;
-        if (CH_ROW > 64) bv = (gi + 1 < out) ? *reinterpret_cast<const double2*>(bias + gi) : make_double2(0.0, 0.0);
+        if (!FIXCOL) bv = (gi + 1 < out) ? *reinterpret_cast<const double2*>(bias + gi) : make_double2(0.0, 0.0);
         if (gi + 1 < out && gb < B && !(dbg & 16))
           *reinterpret_cast<double2*>(Hout + gi + (int64_t)out * gb) = make_double2(finish(v.x + bv.x), finish(v.y + bv.y));
       }
