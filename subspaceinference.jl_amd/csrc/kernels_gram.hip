@@ -608,8 +608,12 @@ static void project_valu(hipStream_t st, const AT* A, int64_t ldA, int64_t N, in
 
 void launch_project(hipStream_t st, const void* Av, int64_t ldA, int64_t N, int64_t K, const double* V,
                     int32_t M, int32_t Mpad, double* P, int64_t ldP, int num_cu, int32_t a_dtype) {
-  if (a_dtype == SI_F32) {   // fp32-stored A: the streaming kernel in passes of <= 32 columns (HBM-bound: half the bytes per pass)
-    project_valu<float>(st, static_cast<const float*>(Av), ldA, N, K, V, M, Mpad, P, ldP, num_cu);
+  if (a_dtype == SI_F32) {   // fp32-stored A: half the bytes per row of A
+    const float* A32 = static_cast<const float*>(Av);
+    // wide subspace: one pass on the matrix cores (kernels_project.hip, fp32 slabs widened on the operand read); else the
+    // streaming VALU kernel in passes of <= 32 columns
+    if (M > 32 && launch_project_stream_f32(st, A32, ldA, N, K, V, M, Mpad, P, ldP, num_cu)) return;
+    project_valu<float>(st, A32, ldA, N, K, V, M, Mpad, P, ldP, num_cu);
     return;
   }
   const double* A = static_cast<const double*>(Av);

@@ -194,6 +194,173 @@ static void launch_project_nt(hipStream_t st, const double* A, int64_t ldA, int6
                      M, P, ldP);
 }
 
+// ---- the same stream for an fp32-STORED deviation matrix (si_construct_set_storage(SI_F32), round 4): half the bytes per row
+// of A.  The slab image is [column][32 rows] of floats (128 bytes per column: one LDS-DMA instruction moves 8 columns), the
+// operand read is a ds_read_b32 widened to fp64 on the way into the MFMA (2 conversions per 2 MFMAs), V and the accumulators
+// are fp64 as before.  Conflict-free reads: lanes q = 0..3 read columns 4s + q, 128 bytes = 32 banks apart, so columns whose
+// bit 1 is set store their two 16-row halves exchanged (done on the DMA source: slot j of column c holds row quad
+// j ^ (4 * ((c >> 1) & 1))).  Two workgroups per CU, two buffers each.
+template <int NT>
+__device__ __forceinline__ void project_glds_f32_body(const float* __restrict__ A, int64_t ldA, int64_t N, int K,
+                                                      const double* __restrict__ V, int Mpad, int m0, int M, double* __restrict__ P,
+                                                      int64_t ldP, float* sA) {
+  constexpr int NB = 2;
+  constexpr int BUF = NT * 16 * PR;              // floats per buffer
+  constexpr int NI = 2 * NT;                     // DMA instructions (8 columns each) per slab
+  constexpr int NP = (NI + PJ_WAVES - 1) / PJ_WAVES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, c = lane & 15;
+  const float* src[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int i = p * PJ_WAVES + wave;           // instruction i: columns 8 i .. 8 i + 7
+    const int col = 8 * (i < NI ? i : 0) + (lane >> 3);
+    const int jq = (lane & 7) ^ (4 * ((col >> 1) & 1));
+    src[p] = A + (int64_t)(col < K ? col : K - 1) * ldA + 4 * jq;   // columns past K meet zero rows of V
+  }
+  auto issue_one = [&](int64_t roff, float* dst, auto PC) {
+    constexpr int p = decltype(PC)::value;
+    if (p * PJ_WAVES + wave < NI)
+      __builtin_amdgcn_global_load_lds(src[p] + roff, (lds_void_ptr)(dst + (p * PJ_WAVES + wave) * 8 * PR), 16, 0, 0);
+  };
+  auto issue = [&](int64_t slab, int buf) {
+    const int64_t roff = slab * PR;
+    float* dst = sA + buf * BUF;
+    pj_static_for<NP>([&](auto PC) { issue_one(roff, dst, PC); });
+  };
+  const int mcol = m0 + 16 * wave + c;
+  double vf[4 * NT];
+#pragma unroll
+  for (int s = 0; s < 4 * NT; ++s) {
+    const int k = 4 * s + q;
+    vf[s] = (k < K && mcol < M) ? V[(int64_t)k * Mpad + mcol] : 0.0;
+  }
+  int fa[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) fa[rt] = q * PR + ((16 * rt + c) ^ (16 * ((q >> 1) & 1)));
+  const int64_t nslab = (N + PR - 1) / PR;
+  const int64_t stride = gridDim.x;
+  int64_t slab = blockIdx.x;
+  if (slab >= nslab) return;
+  const int64_t last = nslab - 1;
+  auto clamp = [&](int64_t sl) { return sl < last ? sl : last; };
+#pragma unroll
+  for (int b = 0; b < NB; ++b) issue(clamp(slab + b * stride), b);
+  int ring = 0;
+  const bool store_cols = 16 * wave < M - m0;
+  d4 accp[2];
+  int64_t prow0 = 0;
+  auto one_slab = [&](auto FIRST) {
+    constexpr bool first = decltype(FIRST)::value;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float* cur = sA + ring * BUF;
+    const int prv = ring ^ 1;
+    const int64_t roff = clamp(slab + stride) * PR;
+    float* pdst = sA + prv * BUF;
+    d4 acc[2];
+    float an0[4 * NT + 2], an1[4 * NT + 2];   // operand reads two k steps ahead of their MFMAs (measured: 2 % on this kernel)
+    an0[0] = cur[fa[0]];
+    an1[0] = cur[fa[1]];
+    an0[1] = cur[fa[0] + 4 * PR];
+    an1[1] = cur[fa[1] + 4 * PR];
+    pj_static_for<4 * NT>([&](auto SC) {
+      constexpr int s = decltype(SC)::value;
+      if constexpr (s + 2 < 4 * NT) {
+        an0[s + 2] = cur[fa[0] + 4 * (s + 2) * PR];
+        an1[s + 2] = cur[fa[1] + 4 * (s + 2) * PR];
+      }
+      const double a0 = (double)an0[s];
+      const double a1 = (double)an1[s];
+      if constexpr (s == 0) {
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[s], a0, (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[s], a1, (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+      } else {
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[s], a0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[s], a1, acc[1], 0, 0, 0);
+      }
+      if constexpr (!first) {
+        // the refill of the buffer slab n-1 has left (NP pieces, one behind every 8th k step) and the 8 stores of its accumulators
+        if constexpr (s % 8 == 1 && s / 8 < NP) issue_one(roff, pdst, std::integral_constant<int, s / 8>{});
+        if constexpr (s % 4 == 3 && s / 4 < 8) {
+          constexpr int j = s / 4, rt = j / 4, r = j % 4;
+          const int m = m0 + 16 * wave + q + 4 * r;
+          if (store_cols && m < M) P[prow0 + 16 * rt + c + (int64_t)m * ldP] = accp[rt][r];
+        }
+      }
+    });
+    if constexpr (!first) {
+      // pieces and stores that found no k step to hide behind (short K)
+      pj_static_for<NP>([&](auto PC) {
+        constexpr int p = decltype(PC)::value;
+        if constexpr (8 * p + 1 >= 4 * NT) issue_one(roff, pdst, PC);
+      });
+      if constexpr (NT < 8) {
+        pj_static_for<8 - NT>([&](auto JC) {
+          constexpr int j = NT + decltype(JC)::value, rt = j / 4, r = j % 4;
+          const int m = m0 + 16 * wave + q + 4 * r;
+          if (store_cols && m < M) P[prow0 + 16 * rt + c + (int64_t)m * ldP] = accp[rt][r];
+        });
+      }
+    }
+    accp[0] = acc[0];
+    accp[1] = acc[1];
+    prow0 = slab * PR;
+    ring ^= 1;
+    slab += stride;
+  };
+  one_slab(std::true_type{});
+  while (slab < nslab) one_slab(std::false_type{});
+  if (store_cols) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 16 * wave + q + 4 * r;
+        if (m < M) P[prow0 + 16 * rt + c + (int64_t)m * ldP] = accp[rt][r];
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * PJ_WAVES, 2) void project_glds_f32_kernel(const float* __restrict__ A, int64_t ldA, int64_t N, int K,
+                                                                          const double* __restrict__ V, int Mpad, int m0, int M,
+                                                                          double* __restrict__ P, int64_t ldP) {
+  extern __shared__ float sA32[];  // [2][NT*16][32]
+  project_glds_f32_body<NT>(A, ldA, N, K, V, Mpad, m0, M, P, ldP, sA32);
+}
+
+template <int NT>
+static void launch_project_f32_nt(hipStream_t st, const float* A, int64_t ldA, int64_t N, int K, const double* V, int Mpad, int m0,
+                                  int M, double* P, int64_t ldP, int num_cu) {
+  const int64_t nslab = (N + PR - 1) / PR;
+  constexpr size_t lds = (size_t)2 * NT * 16 * PR * sizeof(float);
+  const int64_t grid = std::min<int64_t>((int64_t)num_cu * 2, nslab);
+  hipLaunchKernelGGL((project_glds_f32_kernel<NT>), dim3((unsigned)grid), dim3(64 * PJ_WAVES), lds, st, A, ldA, N, K, V, Mpad, m0, M, P,
+                     ldP);
+}
+
+// fp32-stored A: P[:, m] for m < M in 64-column panels; false when the shape is not covered (K > 128)
+bool launch_project_stream_f32(hipStream_t st, const float* A, int64_t ldA, int64_t N, int64_t K, const double* V, int32_t M,
+                               int32_t Mpad, double* P, int64_t ldP, int num_cu) {
+  if (K > 128 || K <= 0) return false;
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    switch ((int)(K + 15) / 16) {
+      case 1: launch_project_f32_nt<1>(st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP, num_cu); break;
+      case 2: launch_project_f32_nt<2>(st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP, num_cu); break;
+      case 3: launch_project_f32_nt<3>(st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP, num_cu); break;
+      case 4: launch_project_f32_nt<4>(st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP, num_cu); break;
+      case 5: launch_project_f32_nt<5>(st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP, num_cu); break;
+      case 6: launch_project_f32_nt<6>(st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP, num_cu); break;
+      case 7: launch_project_f32_nt<7>(st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP, num_cu); break;
+      default: launch_project_f32_nt<8>(st, A, ldA, N, (int)K, V, Mpad, m0, M, P, ldP, num_cu); break;
+    }
+  }
+  return true;
+}
+
 // P[:, m] for m < M in 64-column panels; false when the shape is not covered (K > 128): the caller falls back to the GEMM
 bool launch_project_stream(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, const double* V, int32_t M,
                            int32_t Mpad, double* P, int64_t ldP, int num_cu) {

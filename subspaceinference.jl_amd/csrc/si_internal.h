@@ -301,6 +301,8 @@ void launch_project_mfma(hipStream_t st, const double* A, int64_t ldA, int64_t N
 // K3 for wide subspaces as a slab stream (kernels_project.hip; K <= 128, else returns false)
 bool launch_project_stream(hipStream_t st, const double* A, int64_t ldA, int64_t N, int64_t K, const double* V, int32_t M,
                            int32_t Mpad, double* P, int64_t ldP, int num_cu);
+bool launch_project_stream_f32(hipStream_t st, const float* A, int64_t ldA, int64_t N, int64_t K, const double* V, int32_t M,
+                               int32_t Mpad, double* P, int64_t ldP, int num_cu);   // the same for an fp32-stored A
 // K4: w[c*ldw + r] = swa[r] + sum_m P[r + m*ldP] * Z[m + c*M]
 void launch_reconstruct(hipStream_t st, const double* swa, const double* P, int64_t ldP, int64_t N,
                         int32_t M, const double* Z, int32_t C, double* w, int64_t ldw, int num_cu,

@@ -22,7 +22,10 @@ def _align(p, ref):
 
 
 @pytest.mark.parametrize("n,k,m,how", [(682, 12, 3, "host"), (4099, 100, 20, "host"), (20001, 200, 40, "batch"),
-                                       (1047361, 30, 20, "dev"), (300, 500, 5, "host"), (5000, 37, 7, "batch")])
+                                       (1047361, 30, 20, "dev"), (300, 500, 5, "host"), (5000, 37, 7, "batch"),
+                                       # wide subspaces, K <= 128: the fp32 slab-stream projection on the matrix cores
+                                       (5003, 128, 64, "batch"), (4099, 100, 40, "host"), (33, 50, 33, "host"),
+                                       (70001, 73, 70, "batch"), (1000, 128, 100, "batch")])
 def test_fp32_stored_deviation_matrix(si, gpu_ctx, n, k, m, how):
     import torch
     from subspaceinference_jl_amd import _capi

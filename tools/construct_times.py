@@ -8,6 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import subspaceinference_jl_amd as si  # noqa: E402
 
+if os.environ.get("SI_PROBE_LIB"):   # another build of the library, for A/B runs on one device
+    si._capi.LIB_PATH = os.path.abspath(os.environ["SI_PROBE_LIB"])
 N, K, M = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 A32 = len(sys.argv) > 4 and sys.argv[4] == "a32"   # si_construct_set_storage(SI_F32): the opt-in fp32 storage of the deviation matrix
 ldw = N + (N & 1)
