@@ -27,40 +27,69 @@ inline double& at(double* a, int n, int i, int j) { return a[i + (size_t)n * j];
 // additions, 4 cycles each whatever the vector width -- the Householder reduction of a 100 x 100 matrix spent 0.3 ms in
 // exactly that chain.  The order of the additions is fixed (lane j takes elements j, j + 16, ...; lanes summed pairwise in a
 // fixed tree), so results are reproducible from run to run.
-constexpr int DL = 16;
-inline double lanes_sum(const double* l) {
-  double t[8];
-  for (int j = 0; j < 8; ++j) t[j] = l[j] + l[j + 8];
+typedef double v8d __attribute__((vector_size(64)));      // explicit 8-lane vectors: hipcc's clang compiles this file, and
+inline v8d ld8(const double* p) {                           // left loops over an array of partial sums scalar
+  v8d v;
+  __builtin_memcpy(&v, p, sizeof(v8d));
+  return v;
+}
+inline void st8(double* p, v8d v) { __builtin_memcpy(p, &v, sizeof(v8d)); }
+inline double lanes_sum(v8d a, v8d b) {
+  const v8d t = a + b;
   return ((t[0] + t[4]) + (t[1] + t[5])) + ((t[2] + t[6]) + (t[3] + t[7]));
 }
 inline double dot_lanes(const double* x, const double* y, int n) {   // (x and y may be the same vector)
-  double l[DL] = {0.0};
+  v8d a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
   int i = 0;
-  for (; i + DL <= n; i += DL)
-    for (int j = 0; j < DL; ++j) l[j] += x[i + j] * y[i + j];
-  for (int j = 0; i + j < n; ++j) l[j] += x[i + j] * y[i + j];
-  return lanes_sum(l);
+  for (; i + 16 <= n; i += 16) {
+    a0 += ld8(x + i) * ld8(y + i);
+    a1 += ld8(x + i + 8) * ld8(y + i + 8);
+  }
+  if (i + 8 <= n) {
+    a0 += ld8(x + i) * ld8(y + i);
+    i += 8;
+  }
+  double tail = 0.0;
+  for (; i < n; ++i) tail += x[i] * y[i];
+  return lanes_sum(a0, a1) + tail;
+}
+// acc = sum_r col[r] * x[r]  and  p[r] += col[r] * vc  in one sweep over col (one column of the symmetric rank-2 step)
+inline double dot_axpy_lanes(const double* __restrict col, const double* __restrict x, double* __restrict p, double vc, int n) {
+  v8d a0 = {0, 0, 0, 0, 0, 0, 0, 0};
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    const v8d cv = ld8(col + i);
+    a0 += cv * ld8(x + i);
+    st8(p + i, ld8(p + i) + cv * vc);
+  }
+  double tail = 0.0;
+  for (; i < n; ++i) {
+    tail += col[i] * x[i];
+    p[i] += col[i] * vc;
+  }
+  const v8d zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  return lanes_sum(a0, zero) + tail;
+}
+// Whole-vector forms for the Householder reduction (n8 = a multiple of 8, no scalar tails: at K ~ 100 the column loops
+// average 50 elements and their heads and tails cost more than their bodies).  The caller guarantees that the operands may be
+// read (and p / col written) up to n8 and that x (resp. vp, wp) holds ZEROS past the logical length, so the extra lanes add
+// exact zeros to the sums and leave the extra matrix entries -- the unused upper triangle, or padding -- unchanged.
+inline double dot_axpy8(const double* __restrict col, const double* __restrict x, double* __restrict p, double vc, int n8) {
+  v8d acc = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < n8; i += 8) {
+    const v8d cv = ld8(col + i);
+    acc += cv * ld8(x + i);
+    st8(p + i, ld8(p + i) + cv * vc);
+  }
+  return ((acc[0] + acc[4]) + (acc[1] + acc[5])) + ((acc[2] + acc[6]) + (acc[3] + acc[7]));
+}
+inline void rank2_update8(double* __restrict col, const double* __restrict vp, const double* __restrict wp, double vc, double wc,
+                          int n8) {
+  for (int i = 0; i < n8; i += 8) st8(col + i, ld8(col + i) - (ld8(vp + i) * wc + ld8(wp + i) * vc));
 }
 // y -= a * x (the two never overlap: said so, or the compiler keeps the loop scalar)
 inline void axpy_neg(double* __restrict y, const double* __restrict x, double a, int n) {
   for (int i = 0; i < n; ++i) y[i] -= a * x[i];
-}
-// acc = sum_r col[r] * x[r]  and  p[r] += col[r] * vc  in one sweep over col (one column of the symmetric rank-2 step)
-inline double dot_axpy_lanes(const double* __restrict col, const double* __restrict x, double* __restrict p, double vc, int n) {
-  double l[DL] = {0.0};
-  int i = 0;
-  for (; i + DL <= n; i += DL)
-    for (int j = 0; j < DL; ++j) {
-      const double cv = col[i + j];
-      l[j] += cv * x[i + j];
-      p[i + j] += cv * vc;
-    }
-  for (int j = 0; i + j < n; ++j) {
-    const double cv = col[i + j];
-    l[j] += cv * x[i + j];
-    p[i + j] += cv * vc;
-  }
-  return lanes_sum(l);
 }
 
 // Householder tridiagonalisation.  On exit `a` holds the accumulated orthogonal matrix Q (columns), d the
@@ -217,10 +246,12 @@ void tridiagonalize_factored(int n, double* a, double* d, double* e, double* tau
   // One sweep over the trailing block per step instead of two: the symmetric rank-2 update of step i-1 (A -= v w' + w v') is
   // applied to a column in the same pass that accumulates step i's product A v' from it -- half the passes over the matrix and
   // half the short column loops (at K = 100 .. 700 those loops, not the arithmetic, are what the reduction costs).
-  double* pvec = work;            // [n]  p = tau A v, then w
-  double* vprev = work + n;       // [n]  reflector of the previous step (v[0] = 1 explicit), indexed from its first row
-  double* wprev = work + 2 * n;   // [n]  its w
-  double* vcur = work + 3 * n;    // [n]  reflector of this step, v[0] = 1 explicit
+  const int np = n + 16;          // every work vector has 16 spare elements: the 8-lane loops run past the logical length
+  double* pvec = work;            // [np]  p = tau A v, then w
+  double* vprev = work + np;      // [np]  reflector of the previous step (v[0] = 1 explicit), indexed from its first row
+  double* wprev = work + 2 * np;  // [np]  its w
+  double* vcur = work + 3 * np;   // [np]  reflector of this step, v[0] = 1 explicit
+  for (int k = 0; k < 4 * np; ++k) work[k] = 0.0;
   bool pending = false;           // (vprev, wprev) of length n - i still to be applied to A[i.., i..]
   for (int i = 0; i < n - 1; ++i) {
     const int s = n - i - 1;            // length of the column below the diagonal
@@ -245,9 +276,10 @@ void tridiagonalize_factored(int n, double* a, double* d, double* e, double* tau
     x[0] = beta;                        // T's sub-diagonal in place of v[0] (v[0] = 1 is implicit in the stored reflector)
     vcur[0] = 1.0;
     for (int k = 1; k < s; ++k) vcur[k] = x[k];
+    for (int k = s; k < s + 8; ++k) vcur[k] = 0.0;   // zeros past the end (the previous, longer reflector lived here)
     const bool symv = t != 0.0;
     if (symv)
-      for (int r = 0; r < s; ++r) pvec[r] = 0.0;
+      for (int r = 0; r < s + 8; ++r) pvec[r] = 0.0;
     if (pending || symv) {
       // trailing block A[i+1.., i+1..], lower triangle by columns: update with (vprev, wprev)[1 + .], product with vcur
       const double* vp = vprev + 1;
@@ -255,13 +287,10 @@ void tridiagonalize_factored(int n, double* a, double* d, double* e, double* tau
       for (int c = 0; c < s; ++c) {
         double* col = &at(a, n, i + 1 + c, i + 1 + c);  // col[0] = diagonal, col[r - c] for r > c
         const int len = s - c;
-        if (pending) {
-          const double vc = vp[c], wc = wp[c];
-          for (int r = 0; r < len; ++r) col[r] -= vp[c + r] * wc + wp[c + r] * vc;
-        }
+        if (pending) rank2_update8(col, vp + c, wp + c, vp[c], wp[c], (len + 7) & ~7);
         if (symv) {
           const double vc = vcur[c];
-          pvec[c] += col[0] * vc + dot_axpy_lanes(col + 1, vcur + c + 1, pvec + c + 1, vc, len - 1);
+          pvec[c] += col[0] * vc + dot_axpy8(col + 1, vcur + c + 1, pvec + c + 1, vc, (len - 1 + 7) & ~7);
         }
       }
     }
@@ -274,6 +303,7 @@ void tridiagonalize_factored(int n, double* a, double* d, double* e, double* tau
         wprev[r] = pvec[r] - half * vcur[r];   // w = p - (tau/2)(p'v) v
         vprev[r] = vcur[r];
       }
+      for (int r = s; r < s + 8; ++r) wprev[r] = vprev[r] = 0.0;   // zeros past the end for the 8-lane update of the next step
     }
   }
   if (pending) at(a, n, n - 1, n - 1) -= 2.0 * vprev[0] * wprev[0];
@@ -392,7 +422,7 @@ void tridiag_shift_solve(int n, const double* u0inv, const double* u1, const dou
 // top-m eigenpairs of the symmetric n x n matrix `a` (column-major, destroyed): w_top[0..m) descending, V n x m.
 // Returns 0 = done (unverified: see sym_eig_top), 1 = inverse iteration broke down.
 int sym_eig_top_unverified(int n, double* a, int m, double* w_top, double* V) {
-  std::vector<double> d(n), e(n), tau(n), work(6 * (size_t)n);
+  std::vector<double> d(n), e(n), tau(n), work(6 * ((size_t)n + 16));
   std::vector<int> sw(n);
   tridiagonalize_factored(n, a, d.data(), e.data(), tau.data(), work.data());
   std::vector<double> wtop_t((size_t)m), bwork(5 * ((size_t)m + 8));
@@ -488,7 +518,8 @@ int sym_eig(int n, double* a, double* w) {
 int sym_eig_top(int n, const double* g, int m, double* w_top, double* V) {
   if (n <= 0 || m <= 0 || m > n) return 1;
   if (n < 8 || 3 * m > n) return 1;  // no advantage over the full solver
-  std::vector<double> a(g, g + (size_t)n * n);
+  std::vector<double> a((size_t)n * n + 16, 0.0);   // + padding: the reduction's 8-lane loops run past a column's end
+  std::copy(g, g + (size_t)n * n, a.begin());
   if (sym_eig_top_unverified(n, a.data(), m, w_top, V) != 0) return 1;
   double fro = 0.0;
   for (int j = 0; j < n; ++j) fro += dot_lanes(g + (size_t)j * n, g + (size_t)j * n, n);
