@@ -284,6 +284,10 @@ int32_t si_reconstruct(si_ctx* ctx, const double* Z /* M x C */, int64_t C, doub
 int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, const float* w0 /* N */,
                        const double* X, const double* Y, int32_t in_dim, int32_t out_dim, int64_t B_total,
                        int64_t batch_max, int32_t opt_kind, double eta, double p1, double p2);
+/* With loss_out = NULL the call QUEUES the step and returns: idx (caller-owned, may be reused at once) is copied into a pinned
+ * staging buffer and shipped asynchronously, a batch that is 0 .. nb-1 in order is used in place; nothing waits for the
+ * previous step, so the caller's work between two steps overlaps the GPU's.  Errors of queued work surface at the next
+ * synchronising call (a step with loss_out, si_train_get_weights, si_construct_finish, si_synchronize).              */
 int32_t si_train_step(si_ctx* ctx, const int64_t* idx /* nb observation indices, 0-based */, int64_t nb,
                       double* loss_out /* mse of the batch before the update; may be NULL (no host sync) */);
 /* :45-52 with W taken in place from the device-resident Float32 weights (no extract_params, no PCIe) */
