@@ -68,6 +68,7 @@ int main(int argc, char** argv) {
     V(96, 128, 1, 4, 3, 3), V(192, 128, 2, 4, 3, 2), V(192, 256, 2, 8, 3, 4),
     VK(192, 128, 2, 4, 2, 4, 32), VK(128, 128, 2, 4, 2, 4, 32), VK(192, 128, 2, 4, 2, 4, 16), VK(192, 128, 2, 4, 3, 2, 32),
     VK(192, 128, 2, 4, 2, 6, 16), VK(128, 128, 2, 4, 2, 6, 16), VK(128, 128, 2, 4, 2, 4, 16), V(192, 128, 2, 4, 3, 4),
+    VK(192, 256, 2, 4, 2, 4, 16), VK(192, 256, 2, 4, 2, 2, 16), VK(192, 128, 2, 4, 2, 4, 16),
   };
 
 
