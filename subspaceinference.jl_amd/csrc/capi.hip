@@ -122,6 +122,9 @@ static void free_infer(Ctx* c) {
   dev_free(c->d_act[1]);
   dev_free(c->d_ssepart);
   dev_free(c->d_part);
+  dev_free(c->d_outZ);
+  dev_free(c->d_outlp);
+  c->outZ_cap = c->outlp_cap = 0;
   dev_free(c->d_yhat);
   dev_free(c->d_X32);
   dev_free(c->d_w32);
@@ -1824,12 +1827,24 @@ static int32_t sample_rwmh_impl(si_ctx* ctx, const char* who, int64_t itr, doubl
   int32_t rc = ensure_chains(ctx, C);
   if (rc != SI_OK) return rc;
   if (W_out && (rc = ensure_wstream(ctx, C)) != SI_OK) return rc;
-  double *dZ = nullptr, *dlp = nullptr;
-  if (dev_alloc(&dZ, (size_t)M * itr * C) != hipSuccess || dev_alloc(&dlp, (size_t)itr * C) != hipSuccess) {
-    dev_free(dZ);
-    dev_free(dlp);
-    return fail(ctx, SI_ERR_NOMEM, std::string(who) + ": output allocation failed");
+  // the device-side output arrays stay with the ctx (grown on demand, released with the inference set-up)
+  {
+    const size_t needZ = (size_t)M * itr * C, needlp = (size_t)itr * C;
+    if (ctx->outZ_cap < needZ) {
+      dev_free(ctx->d_outZ);
+      ctx->outZ_cap = 0;
+      if (dev_alloc(&ctx->d_outZ, needZ) != hipSuccess) return fail(ctx, SI_ERR_NOMEM, std::string(who) + ": output allocation failed");
+      ctx->outZ_cap = needZ;
+    }
+    if (ctx->outlp_cap < needlp) {
+      dev_free(ctx->d_outlp);
+      ctx->outlp_cap = 0;
+      if (dev_alloc(&ctx->d_outlp, needlp) != hipSuccess) return fail(ctx, SI_ERR_NOMEM, std::string(who) + ": output allocation failed");
+      ctx->outlp_cap = needlp;
+    }
   }
+  double* const dZ = ctx->d_outZ;
+  double* const dlp = ctx->d_outlp;
   const double d = (double)ctx->out_dim * (double)ctx->B;
   const double c0 = mvnormal_c0(d, ctx->sigma_m), s2 = ctx->sigma_m * ctx->sigma_m;
   // ---- K6 as a device-resident loop (kernels_chain.hip): small Dense chains whose weights, data and activations fit one
@@ -1874,8 +1889,6 @@ static int32_t sample_rwmh_impl(si_ctx* ctx, const char* who, int64_t itr, doubl
       }
       const hipError_t e2 = hipStreamSynchronize(ctx->stream);
       dev_free(dW);
-      dev_free(dZ);
-      dev_free(dlp);
       if (e != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
       if (e2 != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e2));
       if (accept_rate_out)
@@ -1954,8 +1967,6 @@ static int32_t sample_rwmh_impl(si_ctx* ctx, const char* who, int64_t itr, doubl
   if (W_out) (void)hipStreamSynchronize(ctx->stream2);
   if (rc != SI_OK || e != hipSuccess) {
     (void)hipStreamSynchronize(ctx->stream);
-    dev_free(dZ);
-    dev_free(dlp);
     if (rc != SI_OK) return rc;
     return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
   }
@@ -1968,8 +1979,6 @@ static int32_t sample_rwmh_impl(si_ctx* ctx, const char* who, int64_t itr, doubl
   if (e == hipSuccess)
     e = hipMemcpyAsync(nacc.data(), ctx->d_nacc, (size_t)C * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
   hipError_t e2 = hipStreamSynchronize(ctx->stream);
-  dev_free(dZ);
-  dev_free(dlp);
   if (e != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
   if (e2 != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e2));
   if (accept_rate_out)

@@ -236,6 +236,8 @@ struct Ctx {
   uint64_t sw_seed = 0;
   int32_t sw_chain0 = 0, sw_C = 0;
   bool sw_evaluated = false;
+  double *d_outZ = nullptr, *d_outlp = nullptr;   // device-side sample / lp arrays of si_sample_rwmh*, kept between calls
+  size_t outZ_cap = 0, outlp_cap = 0;             // (a hipMalloc / hipFree pair per call was 0.4 ms of a 20-transition call)
   bool defer_sse_final = false;   // eval_density leaves the SSE block partials in d_ssepart (sample_rwmh_impl's fused tail sums them)
   bool chain_loop_enabled = true;   // si_set_chain_loop: 0 forces the launch-per-step loop (the parity tests compare the two)
 };
