@@ -266,10 +266,18 @@ int32_t si_rwmh_end(si_ctx* ctx, double* Z_out, double* lp_out, double* accept_r
 /* drop an open session.  While a session is open, si_logdensity / _grad / si_forward / si_predict / si_sample_rwmh
  * return SI_ERR_STATE (they share the session's proposal and SSE buffers); si_rwmh_begin restarts it.              */
 int32_t si_rwmh_abort(si_ctx* ctx);
-/* K6 as a DEVICE-RESIDENT loop: for small Dense chains (weights, data and activations of a chain fit one
- * workgroup's LDS, 2*N*B <= 3 MFLOP -- the reference's own README / docs sizes) si_sample_rwmh runs all `itr` transitions of
- * all chains in ONE launch, one workgroup per chain, instead of ~8 launches per transition; results are bit-identical to the
- * launch-per-step loop.  on = 0 forces the launch-per-step loop (the parity tests compare the two); default on.           */
+/* K6 as a DEVICE-RESIDENT loop and K5 as ONE launch for narrow Dense chains -- the sizes the reference itself
+ * documents.  Automatic (on = 1, the default):
+ *   - weights, data and activations of a chain fit one workgroup's LDS and 2*N*B <= 3 MFLOP (README.md:52-79): si_sample_rwmh
+ *     runs all `itr` transitions of all chains in ONE launch, one workgroup per chain;
+ *   - fp64 Dense chains with hidden widths <= 256 (docs/src/nn_example.md:112-118, 2-200-50-50-50-1 on 1000 observations): the
+ *     density runs EVERY layer in one launch, a workgroup per batch tile with the activations in LDS; si_sample_rwmh runs all
+ *     transitions in one PERSISTENT launch when ceil(B / tile) * nchains workgroups are resident together (one per CU), with
+ *     two bounded grid barriers per transition -- a barrier that times out (the GPU is shared and the workgroups were not
+ *     all resident) ends the call with SI_ERR_HIP, never a hang; more chains than that stack in the grid of the one-launch
+ *     density, one pass of launches per transition.
+ * Every form gives the SAME BITS as the launch-per-step loop with one launch per layer (on = 0: what the parity tests
+ * compare against).  on = 2: the one-launch density, but no device-resident loop.                                          */
 int32_t si_set_chain_loop(si_ctx* ctx, int32_t on);
 /* :91 / :125  W_out[:, c] = W_swa + P * Z[:, c]   (N x C col-major).  Pipelined: K4 -> pinned staging (second stream) ->
  * host threads (SI_HOST_COPY_THREADS, default min(8, cpus / 2)) copy into W_out, which may be pageable and untouched.  */

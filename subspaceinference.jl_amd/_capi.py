@@ -590,8 +590,9 @@ class Context:
         return z, lp, acc, w
 
     def set_chain_loop(self, on):
-        """False: si_sample_rwmh always takes the launch-per-step loop (default: small Dense chains run device-resident)."""
-        self._check(self.lib.si_set_chain_loop(self.h, 1 if on else 0))
+        """False / 0: one launch per layer and per step of si_sample_rwmh; True / 1 (default): small and narrow Dense chains run
+        fused and device-resident; 2: the one-launch density for narrow chains, but no device-resident loop."""
+        self._check(self.lib.si_set_chain_loop(self.h, int(on)))
 
     def rwmh_begin(self, itr, sigma_z, seed, chain_id0=0, nchains=1, d_total=0):
         self._check(self.lib.si_rwmh_begin(self.h, int(itr), float(sigma_z), int(seed), int(chain_id0), int(nchains),

@@ -21,6 +21,9 @@ SOURCES = [
     ("host_copy.cpp", []),
     ("kernels_stream.hip", ["-ffp-contract=off"]),
     ("kernels_chain.hip", ["-ffp-contract=off"]),
+    # (-amdgpu-mfma-vgpr-form: accumulators stay in VGPRs; the default moved them between the two register files at every
+    #  block boundary of the layer loops, 32 copies + a pipeline drain per 16 MFMAs)
+    ("kernels_chain_grid.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("kernels_gemm.hip", []),
     ("kernels_gemm_small.hip", []),
     ("kernels_gemm_f32.hip", []),
@@ -37,7 +40,7 @@ SOURCES = [
     ("eig.cpp", ["-DSI_EIG_NS=avx512", "-mavx512f", "-mavx512vl", "-mavx512dq", "-mfma"], "eig_avx512"),
     ("eig_dispatch.cpp", []),
 ]
-HEADERS = ["si_internal.h", "philox.h", "kernels_gemm.h", "gemm_pipeline.h", os.path.join("..", "..", "include", "subspace_hip.h")]
+HEADERS = ["si_internal.h", "philox.h", "kernels_gemm.h", "gemm_pipeline.h", "chain_common.h", os.path.join("..", "..", "include", "subspace_hip.h")]
 
 
 def _hipcc():

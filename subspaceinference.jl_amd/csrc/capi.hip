@@ -125,6 +125,10 @@ static void free_infer(Ctx* c) {
   dev_free(c->d_outZ);
   dev_free(c->d_outlp);
   c->outZ_cap = c->outlp_cap = 0;
+  dev_free(c->d_gridsync);
+  c->gridsync_chains = 0;
+  dev_free(c->d_cgprog);
+  c->fused_ok = false;
   dev_free(c->d_yhat);
   dev_free(c->d_X32);
   dev_free(c->d_w32);
@@ -1044,6 +1048,52 @@ int32_t si_construct_get_A(si_ctx* ctx, int64_t k0, int64_t nk, double* A_out) {
 // =================================================================================================
 // density + sampling
 // =================================================================================================
+// ---- narrow Dense chains: every layer in one launch (kernels_chain_grid.hip) ---------------------------------------
+// The class: fp64 Dense chains with the four MFMA-epilogue activations, hidden widths <= 256 (the weights of a layer stream
+// from L2 per workgroup: wide layers belong on the big-tile kernel, which shares W between 128 observations), an LDS plan that
+// fits at 16 observations per workgroup, and one squared error per thread in the SSE kernels (the order the fused loop
+// reproduces).  docs/src/nn_example.md:112-118 is the model this is for.
+static constexpr int SI_FUSED_MAX_WIDTH = 256;
+static bool fused_chain_class(const si_ctx* ctx) {
+  if (ctx->f32 || ctx->plan.has_conv) return false;
+  const int L = (int)ctx->layers.size();
+  if (L < 1 || L > SI_CHAIN_MAX_LAYERS) return false;
+  for (int l = 0; l + 1 < L; ++l)
+    if (ctx->layers[(size_t)l].out > SI_FUSED_MAX_WIDTH) return false;
+  if (!ctx->fuse_tail && ctx->layers[(size_t)L - 1].out > SI_FUSED_MAX_WIDTH) return false;
+  if ((int64_t)ctx->out_dim * ctx->B > (int64_t)256 * ctx->sse_blocks) return false;
+  ChainFusedPlan fp;
+  return chain_fused_plan(fp, ctx->layers.data(), L, ctx->B, 1, ctx->fuse_tail,
+                          ctx->fuse_tail ? dense_fused_slot_feats(ctx->layers[(size_t)L - 2].out) : 0, ctx->fuse_slots) != 0;
+}
+// batch tile of the stacked launch (16 NB observations per workgroup; the 16-feature tiles of a layer dealt over its four
+// waves).  Measured on docs/src/nn_example.md's model at 512 chains (profiles/r05_chain_grid_knockouts.log): 32 observations
+// per workgroup 730 us, 16 per workgroup 780 us, one WAVE per 16-observation tile without any barrier (launch_chain_fused's
+// wave_tiles form, kept for the harness) 1430 us -- a single wave's stream of small dependent steps leaves the SIMD idle.
+static void fused_fill_program(const si_ctx* ctx, ChainFusedPlan& fp) {
+  fp.prog = ctx->d_cgprog;
+  for (int i = 0; i < 5; ++i) {
+    fp.prog_start[i] = ctx->cg_start[i];
+    fp.prog_count[i] = ctx->cg_count[i];
+    fp.prog_chunks[i] = ctx->cg_chunks[i];
+  }
+}
+static size_t fused_plan_for(const si_ctx* ctx, int nchains, ChainFusedPlan& fp, int* nb_out, bool* wave_tiles) {
+  fused_fill_program(ctx, fp);
+  const int L = (int)ctx->layers.size();
+  const int sf = ctx->fuse_tail ? dense_fused_slot_feats(ctx->layers[(size_t)L - 2].out) : 0;
+  *wave_tiles = false;
+  for (int nb : {2, 1}) {
+    const size_t lds = chain_fused_plan(fp, ctx->layers.data(), L, ctx->B, nb, ctx->fuse_tail, sf, ctx->fuse_slots);
+    const int64_t wgs = (ctx->B + 16 * nb - 1) / (16 * nb) * nchains;
+    if (lds != 0 && (nb == 1 || (lds <= (size_t)80 * 1024 && wgs >= (int64_t)2 * ctx->num_cu))) {
+      *nb_out = nb;
+      return lds;
+    }
+  }
+  return 0;
+}
+
 // forward workspace for `slots` chains evaluated in one launch (grid.y = chain slot)
 static bool alloc_forward(si_ctx* ctx, int slots) {
   dev_free(ctx->d_w); dev_free(ctx->d_act[0]); dev_free(ctx->d_act[1]); dev_free(ctx->d_ssepart); dev_free(ctx->d_part);
@@ -1061,7 +1111,7 @@ static bool alloc_forward(si_ctx* ctx, int slots) {
                     dev_alloc(&ctx->d_act32[1], S * (size_t)ctx->act_elems) != hipSuccess)) ||
       dev_alloc(&ctx->d_ssepart, S * (size_t)ctx->sse_blocks) != hipSuccess ||
       (ctx->fuse_tail && dev_alloc(&ctx->d_part, S * pslots * dB) != hipSuccess) ||
-      ((ctx->fuse_tail || ctx->f32) && dev_alloc(&ctx->d_yhat, S * dB) != hipSuccess))
+      ((ctx->fuse_tail || ctx->f32 || ctx->fused_ok) && dev_alloc(&ctx->d_yhat, S * dB) != hipSuccess))
     return false;
   dev_free(ctx->d_wsqpart);
   ctx->wsq_blocks = sse_num_blocks(ctx->iN, ctx->num_cu);
@@ -1159,6 +1209,16 @@ static int32_t infer_setup_common(si_ctx* ctx, const si_layer* layers, int32_t L
   ctx->max_stored = maxstored;
   ctx->act_elems = pad_ld(maxstored * B);
   ctx->sse_blocks = sse_num_blocks((int64_t)out_dim * B, ctx->num_cu);
+  ctx->fused_ok = fused_chain_class(ctx);
+  if (ctx->fused_ok) {   // the chain's tile program (64 bytes per 16-feature tile), uploaded once
+    std::vector<CgTileD> prog;
+    chain_fused_program(ctx->layers.data(), L, ctx->fuse_tail, prog, ctx->cg_start, ctx->cg_count, ctx->cg_chunks);
+    if (dev_alloc(&ctx->d_cgprog, prog.size()) != hipSuccess) {
+      free_infer(ctx);
+      return fail(ctx, SI_ERR_NOMEM, "si_infer_setup: device allocation failed");
+    }
+    SI_HIP(ctx, hipMemcpy(ctx->d_cgprog, prog.data(), prog.size() * sizeof(CgTileD), hipMemcpyHostToDevice));
+  }
   if (dev_alloc(&ctx->d_X, (size_t)in_dim * B) != hipSuccess || dev_alloc(&ctx->d_Y, (size_t)out_dim * B) != hipSuccess ||
       (ctx->f32 && dev_alloc(&ctx->d_X32, (size_t)pad_ld((int64_t)in_dim * B)) != hipSuccess) ||
       !alloc_forward(ctx, 1) ||
@@ -1402,6 +1462,30 @@ static int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out
   }
 #endif  // SI_DEV_KNOBS
   if (ctx->f32) return eval_density_f32(ctx, c0, nc, yhat_out);
+  if (ctx->fused_ok && ctx->chain_mode != 0 && !yhat_out) {
+    // narrow chain: every layer of all nc chains in ONE launch, activations in LDS; the model outputs go through the plain
+    // SSE kernels (one squared error per thread: the same partial sums as tail_sse_kernel's)
+    ChainFusedPlan fp;
+    int nb = 1;
+    bool wave_tiles = false;
+    const size_t lds = fused_plan_for(ctx, nc, fp, &nb, &wave_tiles);
+    if (lds != 0) {
+      const int64_t d = (int64_t)ctx->out_dim * B;
+      {
+        const double fl = 2.0 * (double)N * (double)B * dn;
+        const double by = ((double)N * dn + (double)ctx->in_dim * (double)B + (double)d * dn) * 8.0;
+        ProfScope ps(ctx, SI_K_DENSE, fl, by);
+        ProfScope pm(ctx, SI_K_DENSE_MAIN, fl, by);
+        launch_chain_fused(ctx->stream, fp, nb, wave_tiles, lds, ctx->d_w, ldw, ctx->d_X, ctx->d_yhat, d, nc);
+      }
+      {
+        ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d * dn, 16.0 * (double)d * dn);
+        launch_sse(ctx->stream, ctx->d_yhat, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, nc, d, !ctx->defer_sse_final);
+      }
+      SI_HIP(ctx, hipGetLastError());
+      return SI_OK;
+    }
+  }
   ChainBatch cb;
   cb.n = nc;
   cb.w = ldw;
@@ -1714,7 +1798,7 @@ int32_t si_predict(si_ctx* ctx, const double* Z, int32_t C, const double* Xnew, 
   //  weights are what K4 writes in either mode -- the fp32 option covers the density / the RWMH samplers)
   const bool f32_saved = ctx->f32;
   ctx->f32 = false;
-  const int64_t act_elems = pad_ld(ctx->max_stored * Bn);
+  const int64_t act_elems = pad_ld(ctx->max_stored * Bn);   // (eval_density with yhat_out set never takes the fused launch)
   const int sse_blocks = sse_num_blocks((int64_t)ctx->out_dim * Bn, ctx->num_cu);
   const size_t dB = (size_t)ctx->out_dim * (size_t)Bn;
   const double per = 8.0 * (2.0 * (double)act_elems + ((double)ctx->fuse_slots + 1.0) * (double)dB + (double)sse_blocks);
@@ -1853,7 +1937,7 @@ static int32_t sample_rwmh_impl(si_ctx* ctx, const char* who, int64_t itr, doubl
   // (with the output map requested -- what the drop-in sub_inference call does -- the weight samples of the finished chains
   //  come from ONE K4 pass over all itr * C samples, the kernel si_reconstruct runs: same bits, no streaming needed at this size)
   const size_t wall_elems = (size_t)ldw * (size_t)itr * (size_t)C;
-  if ((!W_out || wall_elems <= ((size_t)512 << 20) / sizeof(double)) && chain_loop_applies(ctx) && ctx->chain_loop_enabled) {
+  if ((!W_out || wall_elems <= ((size_t)512 << 20) / sizeof(double)) && chain_loop_applies(ctx) && ctx->chain_mode == 1) {
     ChainLoopArgs a{};
     const int L = (int)ctx->layers.size();
     for (int l = 0; l < L; ++l) a.lay[l] = ctx->layers[(size_t)l];
@@ -1891,6 +1975,80 @@ static int32_t sample_rwmh_impl(si_ctx* ctx, const char* who, int64_t itr, doubl
       dev_free(dW);
       if (e != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
       if (e2 != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e2));
+      if (accept_rate_out)
+        for (int c = 0; c < C; ++c) accept_rate_out[c] = itr > 1 ? (double)nacc[(size_t)c] / (double)(itr - 1) : 0.0;
+      return SI_OK;
+    }
+  }
+  // ---- K6 as a persistent loop over a GRID of workgroups (kernels_chain_grid.hip): a narrow chain too large for one
+  // workgroup (docs/src/nn_example.md's MLP) runs all transitions in one launch, G = ceil(B / tile) resident workgroups per
+  // chain, two bounded grid barriers per transition.  Same bits as the loop below (tests/test_gpu_chain_grid.py).
+  if ((!W_out || wall_elems <= ((size_t)512 << 20) / sizeof(double)) && ctx->fused_ok && ctx->chain_mode == 1 && !(ctx->sigma_p > 0.0) &&
+      C <= ctx->fw_slots && itr < ((int64_t)1 << 24)) {
+    ChainGridArgs a{};
+    const int L = (int)ctx->layers.size();
+    const int sf = ctx->fuse_tail ? dense_fused_slot_feats(ctx->layers[(size_t)L - 2].out) : 0;
+    int nb = 0;
+    size_t lds = 0;
+    for (int cand : {1, 2, 4}) {   // the smallest tile whose grid is resident: one workgroup per CU
+      const int64_t G = (ctx->B + 16 * cand - 1) / (16 * cand);
+      if (G * C > ctx->num_cu) continue;
+      const size_t lf = chain_fused_plan(a.p, ctx->layers.data(), L, ctx->B, cand, ctx->fuse_tail, sf, ctx->fuse_slots);
+      fused_fill_program(ctx, a.p);
+      a.M = M;
+      a.nblocks = ctx->sse_blocks;
+      a.G = (int)G;
+      lds = chain_grid_plan(a, lf);
+      if (lds != 0) {
+        nb = cand;
+        break;
+      }
+    }
+    if (nb != 0) {
+      if (ctx->gridsync_chains < C) {
+        dev_free(ctx->d_gridsync);
+        ctx->gridsync_chains = 0;
+        if (dev_alloc(&ctx->d_gridsync, (size_t)32 * ((size_t)C + 1)) != hipSuccess) return fail(ctx, SI_ERR_NOMEM, std::string(who) + ": allocation failed");
+        ctx->gridsync_chains = C;
+      }
+      a.swa = ctx->i_swa; a.P = ctx->i_P; a.X = ctx->d_X; a.Y = ctx->d_Y;
+      a.wbuf = ctx->d_w; a.w_stride = ldw;
+      a.ybuf = ctx->d_yhat; a.y_stride = (int64_t)ctx->out_dim * ctx->B;
+      a.cnt = ctx->d_gridsync; a.status = ctx->d_gridsync + (size_t)32 * (size_t)C;
+      a.Z_out = dZ; a.lp_out = dlp; a.nacc_out = ctx->d_nacc;
+      a.ldP = ctx->ldP; a.itr = itr; a.seed = seed; a.sigma_z = sigma_z; a.c0 = c0; a.sigma2 = s2;
+      a.N = (int)N; a.chain_id0 = chain_id0;
+      hipError_t e = hipMemsetAsync(ctx->d_gridsync, 0, (size_t)32 * ((size_t)C + 1) * sizeof(unsigned), ctx->stream);
+      if (e == hipSuccess) {
+        const double fl = 2.0 * (double)N * (double)ctx->B * (double)itr * C;
+        ProfScope ps(ctx, SI_K_RWMH, fl, 0.0);
+        e = launch_chain_grid(ctx->stream, a, nb, C, lds);
+      }
+      std::vector<int64_t> nacc((size_t)C);
+      unsigned status = 0;
+      if (e == hipSuccess) e = hipMemcpyAsync(&status, a.status, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess && Z_out) e = hipMemcpyAsync(Z_out, dZ, (size_t)M * itr * C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess && lp_out) e = hipMemcpyAsync(lp_out, dlp, (size_t)itr * C * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(nacc.data(), ctx->d_nacc, (size_t)C * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+      double* dW = nullptr;
+      if (e == hipSuccess && W_out) {   // src/space_inference.jl:125 for every sample of every chain (one K4 pass, as above)
+        if (dev_alloc(&dW, wall_elems) != hipSuccess) e = hipErrorOutOfMemory;
+        if (e == hipSuccess) {
+          ProfScope ps(ctx, SI_K_RECON, 2.0 * (double)N * M * (double)itr * C, (double)N * (M + 1 + (double)itr * C) * 8.0);
+          launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, dZ, (int32_t)(itr * C), dW, ldw, ctx->num_cu);
+          e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+          e = hipMemcpy2DAsync(W_out, (size_t)N * sizeof(double), dW, (size_t)ldw * sizeof(double), (size_t)N * sizeof(double),
+                               (size_t)itr * C, hipMemcpyDeviceToHost, ctx->stream);
+      }
+      const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+      dev_free(dW);
+      if (e != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
+      if (e2 != hipSuccess) return fail(ctx, SI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e2));
+      if (status != 0)
+        return fail(ctx, SI_ERR_HIP, std::string(who) + ": the grid barrier of the device-resident loop timed out (its workgroups were not all resident: "
+                                     "is another process holding compute units of this GPU?); si_set_chain_loop(ctx, 2) runs the launch-per-step loop");
       if (accept_rate_out)
         for (int c = 0; c < C; ++c) accept_rate_out[c] = itr > 1 ? (double)nacc[(size_t)c] / (double)(itr - 1) : 0.0;
       return SI_OK;
@@ -2003,6 +2161,8 @@ int32_t si_sample_rwmh_weights(si_ctx* ctx, int64_t itr, double sigma_z, uint64_
 // stream (same seed / chain ids), so all ranks take identical accept decisions and keep identical chains.
 int32_t si_set_chain_loop(si_ctx* ctx, int32_t on) {
   CHECK_CTX(ctx);
+  if (on < 0 || on > 2) return fail(ctx, SI_ERR_INVALID, "si_set_chain_loop: 0 (one launch per layer and step), 1 (automatic) or 2 (fused launches, no device-resident loop)");
+  ctx->chain_mode = on;
   ctx->chain_loop_enabled = on != 0;
   return SI_OK;
 }

@@ -214,6 +214,12 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(const double* __restri
   // fp32 forward multiplies with; the fp64 copy keeps feeding the output map, the prior term and the gradient path
   const int64_t npair = (N + 1) >> 1;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (blockIdx.y != 0) {   // chain groups of CB stacked in grid.y: one launch for all of them
+    const int64_t cg = (int64_t)blockIdx.y * CB;
+    Z += cg * M;
+    w += cg * ldw;
+    if (w32 != nullptr) w32 += cg * ldw32;
+  }
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npair; p += stride) {
     const int64_t r = p << 1;
     double2 acc[CB];
@@ -257,6 +263,11 @@ void launch_reconstruct(hipStream_t st, const double* swa, const double* P, int6
                         int32_t M, const double* Z, int32_t C, double* w, int64_t ldw, int num_cu, float* w32, int64_t ldw32) {
   const int grid = stream_grid((N + 1) >> 1, num_cu);
   int c0 = 0;
+  if (C >= 8) {   // many stacked chains: every group of four in one launch (512 chains were 128 dependent launches)
+    const int n4 = C / 4;
+    hipLaunchKernelGGL((reconstruct_kernel<4>), dim3(grid, n4), dim3(256), 0, st, swa, P, ldP, N, M, Z, w, ldw, w32, ldw32);
+    c0 = 4 * n4;
+  }
   while (c0 < C) {
     const int rem = C - c0;
     const double* Zc = Z + (int64_t)c0 * M;

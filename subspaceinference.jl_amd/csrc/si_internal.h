@@ -16,6 +16,17 @@ namespace si {
 constexpr int64_t LD_ALIGN = 64;
 inline int64_t pad_ld(int64_t n) { return (n + LD_ALIGN - 1) / LD_ALIGN * LD_ALIGN; }
 
+// one 16-feature tile of a layer as a wave runs it (64 bytes: one scalar load); chain_fused_program builds the lists
+enum { SI_CG_SYNC = 1, SI_CG_GLOBAL = 2, SI_CG_MARKER = 4 };
+struct CgTileD {
+  int64_t woff, boff;      // elements into the weight vector: the layer's W and bias
+  int32_t out, row0;       // rows of W (its pitch); first feature of the tile
+  int32_t in, pad2;        // columns of W
+  int32_t flags;           // SI_CG_SYNC: the wave's last tile of a layer; _GLOBAL: outputs go to yhat; _MARKER: no tile, barrier only
+  int32_t img_in, ldi;     // input image (0 X tile, 1 / 2 the two activation images) and its pitch
+  int32_t img_out, ldo;    // output image and its pitch
+  int32_t act, pad0, pad1;  // act: SI_ACT_* | layer index << 8
+};
 struct EventPair {
   hipEvent_t a, b;
   int cls;
@@ -240,6 +251,13 @@ struct Ctx {
   size_t outZ_cap = 0, outlp_cap = 0;             // (a hipMalloc / hipFree pair per call was 0.4 ms of a 20-transition call)
   bool defer_sse_final = false;   // eval_density leaves the SSE block partials in d_ssepart (sample_rwmh_impl's fused tail sums them)
   bool chain_loop_enabled = true;   // si_set_chain_loop: 0 forces the launch-per-step loop (the parity tests compare the two)
+  // narrow Dense chains (kernels_chain_grid.hip): every layer of the density in ONE launch, and K6 as a persistent grid loop
+  int chain_mode = 1;               // si_set_chain_loop: 0 per-layer launches, 1 automatic, 2 the fused forward without the persistent loops
+  bool fused_ok = false;            // the chain set up is of that class (infer_setup_common)
+  unsigned* d_gridsync = nullptr;   // grid loop: one 128-byte counter line per chain + the status line
+  int gridsync_chains = 0;
+  CgTileD* d_cgprog = nullptr;      // the chain's tile program (chain_fused_program)
+  int cg_start[5] = {0}, cg_count[5] = {0}, cg_chunks[5] = {0};
 };
 
 void free_train(Ctx* c);
@@ -471,6 +489,42 @@ struct ChainLoopArgs {
 };
 size_t chain_loop_plan(ChainLoopArgs& a, size_t lds_limit);   // LDS bytes, 0 = the model does not fit / does not apply
 void launch_chain_loop(hipStream_t st, const ChainLoopArgs& a, int nchains, size_t lds);
+// K5 fused over all layers + K6 as a persistent grid loop for narrow Dense chains (kernels_chain_grid.hip)
+struct ChainFusedPlan {
+  si_layer lay[SI_CHAIN_MAX_LAYERS];
+  int L, B;
+  int fuse_tail, slot_feats, fuse_slots;   // narrow head on the image of layer L-2 (slots of dense_f64_kernel<FUSE>)
+  int ld[SI_CHAIN_MAX_LAYERS + 1];         // pitch of the input image of layer l; ld[l + 1] = of its output image
+  int o_x, o_buf[2], o_part;               // LDS offsets (doubles)
+  int lds_doubles;
+  const CgTileD* prog;                     // device: the tile lists (0: a wave owns the batch tile; 1 .. 4: wave 0 .. 3 of a workgroup that shares it)
+  int prog_start[5], prog_count[5], prog_chunks[5];
+};
+void chain_fused_program(const si_layer* layers, int L, bool fuse_tail, std::vector<CgTileD>& prog, int start[5], int count[5],
+                         int chunks[5]);
+size_t chain_fused_plan(ChainFusedPlan& p, const si_layer* layers, int L, int64_t B, int NB, bool fuse_tail, int slot_feats,
+                        int fuse_slots);   // LDS bytes for batch tiles of 16 NB observations; 0 = not a chain of this class
+// yhat[chain][o + out_last * b] for `nchains` weight vectors w + chain * w_stride (grid.y), every layer in one launch
+// (wave_tiles: one WAVE per batch tile, four regions of `lds` bytes per workgroup, no workgroup barrier; else one workgroup per tile)
+void launch_chain_fused(hipStream_t st, const ChainFusedPlan& p, int NB, bool wave_tiles, size_t lds, const double* w, int64_t w_stride,
+                        const double* X, double* yhat, int64_t y_stride, int nchains);
+struct ChainGridArgs {
+  ChainFusedPlan p;
+  const double *swa, *P, *X, *Y;
+  double *wbuf, *ybuf;        // per chain: W_swa + P z' (w_stride apart) and the model outputs (y_stride apart); handed between workgroups
+  int64_t w_stride, y_stride;
+  unsigned* cnt;              // 32 words (one 128-byte line) per chain, zeroed before the launch
+  unsigned* status;           // raised by a workgroup whose barrier wait timed out
+  double *Z_out, *lp_out;
+  int64_t* nacc_out;
+  int64_t ldP, itr;
+  uint64_t seed;
+  double sigma_z, c0, sigma2;
+  int N, M, G, chain_id0, nblocks;
+  int y_in_lds, o_y, o_blk, o_z, o_red, o_flag;   // LDS offsets behind the images (chain_grid_plan)
+};
+size_t chain_grid_plan(ChainGridArgs& a, size_t lds_fused);
+hipError_t launch_chain_grid(hipStream_t st, const ChainGridArgs& a, int NB, int nchains, size_t lds);
 int dense_fused_slot_feats(int32_t out);   // features per head slot of the fused fp64 layer (kernels_gemm.hip: BM / WM)
 // K6
 void launch_rwmh_init(hipStream_t st, double* zcur, double* lpcur, int64_t* nacc, uint64_t* steps, int32_t M, int32_t C);
