@@ -539,7 +539,7 @@ def run_chains(args, rk, real_stdout):
     phase("construct: end to end through api.subspace_construction")
     # end to end through the drop-in call itself: subspace_construction(model, mse, data, ADAM; T = 100, M = 20) with the
     # training step on the device (src/subspace_construction.jl:37-59 as a whole: 100 x [gradient + update! + push] + psvd)
-    e2e = None
+    e2e = e2e_f32 = None
     if rank == 0:
         wr = np.random.default_rng(1)
         mdl = flux.Chain(*[flux.Dense(i, o, a, rng=wr) for i, o, a in zip(DIMS[:-1], DIMS[1:], ACTS)])
@@ -550,6 +550,18 @@ def run_chains(args, rk, real_stdout):
                                      device_training=True, keep_on_device=True, data_parallel=False)
             solo.synchronize()
             e2e = (time.perf_counter() - t0) * 1e3
+        # the same call on Float32 data: the device step then computes in fp32, as the reference's Zygote pass would
+        # (src/subspace_construction.jl:39-43 with a Float32 model and Float32 X, Y)
+        wr = np.random.default_rng(1)
+        mdl32 = flux.Chain(*[flux.Dense(i, o, a, rng=wr) for i, o, a in zip(DIMS[:-1], DIMS[1:], ACTS)])
+        data32 = flux.DataLoader(x.astype(np.float32), y.astype(np.float32), batchsize=B)
+        with si.Context(rk.local_rank) as solo:
+            t0 = time.perf_counter()
+            si.subspace_construction(mdl32, flux.mse, data32, flux.ADAM(1e-3), T=K_SNAP, c=1, M=M, ctx=solo, verbose=False,
+                                     device_training=True, keep_on_device=True, data_parallel=False)
+            solo.synchronize()
+            e2e_f32 = (time.perf_counter() - t0) * 1e3
+        del data32, mdl32
     construct("per_push")   # the subspace the chains below sample in (rank 0's is broadcast when there are more ranks)
     if rk.ctx is not None:
         ctx.bcast_subspace(0, n_par, M)   # cfg3: (W_swa, P) device to device over RCCL inside the library, once
@@ -644,6 +656,22 @@ def run_chains(args, rk, real_stdout):
         extras["train_step_full_batch_ms"] = (time.perf_counter() - t0) / 5 * 1e3
         bs = ctx.stats()["backward"]
         extras["backward_sweep_tflops"] = bs["flops"] / max(bs["ms"], 1e-9) / 1e9
+        # the step in the caller's precision: Float32 data => fp32 forward and reverse sweep (si_train_setup_ex)
+        x32, y32 = x.astype(np.float32), y.astype(np.float32)
+        ctx.reset_stats()
+        ctx.train_setup(table, n_par, glorot_flat(1), x32, y32, B, 2, 1e-3, 0.9, 0.999)
+        ctx.train_step(ids)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ctx.train_step(ids, want_loss=False)
+        ctx.synchronize()
+        extras["train_step_full_batch_ms_f32"] = (time.perf_counter() - t0) / 5 * 1e3
+        bs32 = ctx.stats()["backward"]
+        extras["backward_sweep_tflops_f32"] = bs32["flops"] / max(bs32["ms"], 1e-9) / 1e9
+        extras["train_step_f32_note"] = ("Float32 (X, Y) with the Float32 model: the reference's own arithmetic for such data; fp32 operands on "
+                                         "v_mfma_f32_32x32x2_f32 forward and reverse, loss / head partials / batch sums in fp64; the fp64 "
+                                         "numbers beside it are what Float64 data get (unchanged)")
+        del x32, y32
         ctx.set_profiling(False)
 
     if rank == 0:
@@ -703,6 +731,10 @@ def run_chains(args, rk, real_stdout):
                                  "device_ms": {k: round(cst32[k]["ms"], 4) for k in ("push", "gram", "gram_reduce", "project")}},
             "construct_host_push": host_push,
             "construct_end_to_end_ms": e2e,
+            "construct_end_to_end_ms_f32": e2e_f32,
+            "construct_end_to_end_who_gets_it": "the Python mirror's default (device_training = \"auto\" recognises flux.mse).  The Julia wrapper trains "
+                                                "on the HOST unless called with device_training = true (a Julia closure cannot be recognised as "
+                                                "mse): INTEGRATION.md shows the one-line opt-in.  _f32: the same call on Float32 (X, Y)",
             "construct_end_to_end_note": "subspace_construction(model, mse, DataLoader(batchsize = B), ADAM; T = 100, M = 20) through "
                                          "api.py with the training step on the device: 100 x [forward + reverse sweep + ADAM + K1] + psvd, "
                                          "incl. the one-off upload of X, Y and the weights",

@@ -101,7 +101,7 @@ typedef struct {
   double bytes[SI_K_COUNT];     /* accumulated ALGORITHMIC HBM bytes per class                 */
 } si_stats;
 
-int32_t si_version(void); /* 400: + compute_dtype = SI_F32 (300: RCCL communicator, streamed output map, pipelined host push) */
+int32_t si_version(void); /* 500: + narrow-chain fused density / grid loop, si_train_setup_ex; 400: + compute_dtype = SI_F32 (300: RCCL communicator, streamed output map, pipelined host push) */
 
 /* ---- context ------------------------------------------------------------------------------- */
 int32_t si_create(si_ctx** out, int32_t device_id);
@@ -292,6 +292,25 @@ int32_t si_reconstruct(si_ctx* ctx, const double* Z /* M x C */, int64_t C, doub
 int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, const float* w0 /* N */,
                        const double* X, const double* Y, int32_t in_dim, int32_t out_dim, int64_t B_total,
                        int64_t batch_max, int32_t opt_kind, double eta, double p1, double p2);
+/* The same with the data in the caller's element type and the arithmetic of the step chosen by it -- WHICH PRECISION A STEP
+ * COMPUTES IN.  In the reference the step is `gradient(ps) do cost(model, x, y) end` on Flux arrays (:39-43): with a Float32
+ * model (Flux's default) and Float64 data (`rand(10, 100)`, every example of the reference) Julia promotes and the pass is
+ * Float64; with Float32 data (ordinary Flux practice) the whole pass -- sgemm forward and reverse, the loss -- is Float32.
+ *   data_dtype     SI_F32 / SI_F64: element type of X and Y as the caller holds them
+ *   compute_dtype  SI_DTYPE_OF_DATA (the reference's own arithmetic for that data), or SI_F32 / SI_F64 to override
+ *                  (Float64 data + SI_F32 rounds X once; Float32 data + SI_F64 widens it: what si_train_setup's callers
+ *                  had to do before round 5, wider than the reference and twice the matrix time)
+ * SI_F32 (Dense chains; Conv chains: SI_ERR_INVALID, they train in SI_F64): fp32 operands and activations on
+ * v_mfma_f32_32x32x2_f32 forward and reverse; the loss, the narrow head's partial sums and every sum over the batch (dW, db)
+ * in fp64, rounded once into the Float32 gradient; the optimiser as Flux runs it (Float64 scalars on Float32 arrays, rounded on
+ * the store).  Not bit-equal to a BLAS sgemm pass (the sums are blocked differently): measured against the oracle's Float32
+ * path (tests/test_gpu_train_f32.py) the weights after 12 ADAM steps agree to 2e-6 of their scale, the loss to 1e-6.
+ * si_train_grad_ptr / _get / _set keep exchanging N doubles (holding the Float32 values) in either mode.                  */
+enum { SI_DTYPE_OF_DATA = -1 };
+int32_t si_train_setup_ex(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, const float* w0 /* N */, const void* X,
+                          const void* Y, int32_t data_dtype, int32_t in_dim, int32_t out_dim, int64_t B_total, int64_t batch_max,
+                          int32_t opt_kind, double eta, double p1, double p2, int32_t compute_dtype);
+int32_t si_train_compute_dtype(si_ctx* ctx, int32_t* out /* SI_F32 / SI_F64: what the steps of this set-up compute in */);
 /* With loss_out = NULL the call QUEUES the step and returns: idx (caller-owned, may be reused at once) is copied into a pinned
  * staging buffer and shipped asynchronously, a batch that is 0 .. nb-1 in order is used in place; nothing waits for the
  * previous step, so the caller's work between two steps overlaps the GPU's.  Errors of queued work surface at the next

@@ -361,7 +361,11 @@ def mse_value_and_grad(table, w64, x, y):
         gs = gradient(ps) do training_loss = cost(model, d...) end
     [upstream Flux 0.11.2 `mse(ŷ, y; agg = mean) = agg((ŷ .- y).^2)`; Zygote 0.5.17 reverse mode].  The Float32
     parameters meet Float64 data, so every product promotes to Float64 and the gradient comes back as Float64 arrays
-    (Zygote 0.5 does not project it onto the parameter's eltype).  Returns (loss, flat gradient in extract_params order)."""
+    (Zygote 0.5 does not project it onto the parameter's eltype).  Returns (loss, flat gradient in extract_params order).
+
+    With Float32 weights AND Float32 data (pass float32 arrays for all three) nothing promotes: the whole pass is Float32 --
+    `W * x` is sgemm, the loss a Float32 mean, the gradient Float32 arrays (NumPy keeps float32 through every line below
+    exactly as Julia does; the summation ORDER inside sgemm / mean is the BLAS's and the runtime's, not pinned)."""
     hs = [x]
     for row in table:
         hs.append(_layer_forward(row, w64, hs[-1]))
@@ -400,6 +404,11 @@ def apply_update(w32, state, g64, opt):
     ("adam", η, β1, β2).  Updates w32 / state in place."""
     kind = opt[0]
     eta = np.float64(opt[1])
+    # A Float32 gradient (the all-Float32 pass) changes two roundings: `apply!` writes its step back INTO the Float32 array Δ
+    # (`Δ .*= η`, `@. Δ = -v`, `@. Δ = mt / ...`: computed in Float64, rounded on the store) and `x .-= Δ` subtracts two
+    # Float32 arrays in Float32.  With a Float64 gradient Δ stays Float64 and x - Δ is rounded once on the store into x.
+    g32 = g64.dtype == np.float32
+    g64 = g64.astype(np.float64)
     if kind == "descent":
         step = g64 * eta
     elif kind == "momentum":
@@ -415,15 +424,23 @@ def apply_update(w32, state, g64, opt):
         state["bp"] = [bp[0] * float(b1), bp[1] * float(b2)]
     else:
         raise ValueError(kind)
-    w32[...] = (w32.astype(np.float64) - step).astype(np.float32)
+    if g32:
+        w32[...] = w32 - step.astype(np.float32)
+    else:
+        w32[...] = (w32.astype(np.float64) - step).astype(np.float32)
 
 
 def train_step(table, w32, state, x, y, opt):
     """One pass of the reference's loop body, src/subspace_construction.jl:39-43: Zygote gradient of the mse cost on the
-    batch (x, y), then Flux.update!.  Returns the loss BEFORE the update (Zygote's forward value, `training_loss`)."""
-    loss, g = mse_value_and_grad(table, w32.astype(np.float64), x, y)
+    batch (x, y), then Flux.update!.  Returns the loss BEFORE the update (Zygote's forward value, `training_loss`).
+    The arithmetic follows the DATA: Float64 (x, y) promote the Float32 weights (a Float64 pass, a Float64 gradient);
+    Float32 (x, y) give the all-Float32 pass."""
+    if x.dtype == np.float32 and y.dtype == np.float32:
+        loss, g = mse_value_and_grad(table, w32, x, y)
+    else:
+        loss, g = mse_value_and_grad(table, w32.astype(np.float64), x.astype(np.float64), y.astype(np.float64))
     apply_update(w32, state, g, opt)
-    return loss
+    return float(loss)
 
 
 # --------------------------------------------------------------------------- sampler

@@ -18,6 +18,7 @@ SI_OK, SI_ERR_INVALID, SI_ERR_STATE, SI_ERR_HIP, SI_ERR_NOMEM, SI_ERR_BOUNDS, SI
 SI_ERR_COMM = -7
 SI_COMM_ID_BYTES, SI_COMM_SUM, SI_COMM_MAX = 128, 0, 1
 SI_F32, SI_F64 = 0, 1
+SI_DTYPE_OF_DATA = -1
 ACT_IDENTITY, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 ACT_LEAKYRELU, ACT_ELU, ACT_SOFTPLUS, ACT_SELU = 4, 5, 6, 7
 K_NAMES = ["push", "gram", "gram_reduce", "project", "reconstruct", "dense", "sse", "rwmh", "dense_main", "eig_host", "backward",
@@ -101,6 +102,9 @@ SIGNATURES = {
     "si_reconstruct": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "si_train_setup": (c_int32, [c_void_p, POINTER(SiLayer), c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_int32,
                                  c_int32, c_int64, c_int64, c_int32, c_double, c_double, c_double]),
+    "si_train_setup_ex": (c_int32, [c_void_p, POINTER(SiLayer), c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                    c_int32, c_int64, c_int64, c_int32, c_double, c_double, c_double, c_int32]),
+    "si_train_compute_dtype": (c_int32, [c_void_p, c_void_p]),
     "si_train_step": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "si_train_push": (c_int32, [c_void_p, c_double]),
     "si_train_get_weights": (c_int32, [c_void_p, c_void_p]),
@@ -430,17 +434,28 @@ class Context:
         return a
 
     # -- on-device training (f1)
-    def train_setup(self, table, n, w0, x, y, batch_max, opt_kind, eta, p1=0.0, p2=0.0):
+    def train_setup(self, table, n, w0, x, y, batch_max, opt_kind, eta, p1=0.0, p2=0.0, compute_dtype=None):
+        """si_train_setup_ex.  compute_dtype None: the reference's own arithmetic for the data handed in -- Float32 (x, y) give
+        the all-Float32 pass (SI_F32), anything else is promoted to Float64 as Julia would; SI_F32 / SI_F64 override."""
         arr = _layer_array(table)
-        x, y = _f64(x), _f64(y)
+        x, y = np.asarray(x), np.asarray(y)
+        data_f32 = x.dtype == np.float32 and y.dtype == np.float32
+        dt = np.float32 if data_f32 else np.float64
+        x, y = np.asfortranarray(x, dtype=dt), np.asfortranarray(y, dtype=dt)
         w0 = np.ascontiguousarray(w0, dtype=np.float32)
         if w0.size != n or x.ndim != 2 or y.ndim != 2 or x.shape[1] != y.shape[1]:
             raise SubspaceError("DimensionMismatch: w0 %s, X %s, Y %s" % (w0.shape, x.shape, y.shape))
-        self._check(self.lib.si_train_setup(self.h, arr, len(table), int(n), _ptr(w0), _ptr(x), _ptr(y), x.shape[0],
-                                            y.shape[0], x.shape[1], int(batch_max), int(opt_kind), float(eta), float(p1),
-                                            float(p2)))
+        self._check(self.lib.si_train_setup_ex(self.h, arr, len(table), int(n), _ptr(w0), _ptr(x), _ptr(y),
+                                               SI_F32 if data_f32 else SI_F64, x.shape[0], y.shape[0], x.shape[1], int(batch_max),
+                                               int(opt_kind), float(eta), float(p1), float(p2),
+                                               SI_DTYPE_OF_DATA if compute_dtype is None else int(compute_dtype)))
         self._tn = int(n)
         self._tout = int(y.shape[0])
+
+    def train_compute_dtype(self):
+        out = np.zeros(1, dtype=np.int32)
+        self._check(self.lib.si_train_compute_dtype(self.h, _ptr(out)))
+        return int(out[0])
 
     def train_step(self, idx, want_loss=True):
         idx = np.ascontiguousarray(idx, dtype=np.int64)

@@ -29,7 +29,7 @@ def _alg_name(alg):
 
 def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, *, device=0, ctx=None,
                           max_cols=0, verbose=True, keep_on_device=False, device_training="auto", init="zeros",
-                          data_parallel=False, a_storage="f64"):
+                          data_parallel=False, a_storage="f64", compute_dtype="auto"):
     """src/subspace_construction.jl:26-67.
 
     Per batch the host does `gradient` + `update!` (:39-43, caller side) and hands the flattened weights
@@ -44,6 +44,11 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
 
     init ("zeros" | "pretrained"): "zeros" is what the reference's CODE does (W_swa = zeros, :31 -- quirk Q1, the default);
     "pretrained" starts the running mean at the model's weights, as the reference's docs describe (nn_example.md:44).
+
+    compute_dtype ("auto" | "f32" | "f64") of the DEVICE training step: "auto" is the reference's own arithmetic for the data
+    handed in -- a Float32 model on Float32 (X, Y) is a Float32 Zygote pass (:39-43), Float64 data (every example of the
+    reference: `rand(10, 100)`) promote the pass to Float64; "f32" / "f64" override (Float64 data are then rounded once /
+    Float32 data widened).  The host step (device_training=False) follows NumPy's promotion, which is Julia's.
 
     a_storage ("f64" | "f32"): "f64" keeps the deviation matrix in Float64 like the reference (:33,51-52); "f32" (opt-in,
     SURVEY section 0 Q6) stores every column rounded once to Float32 -- half the memory and half the bytes of the Gram /
@@ -93,7 +98,10 @@ def subspace_construction(model, cost, data, opt, T=10, c=1, M=3, print_freq=1, 
             xm, ym, in_size = flux.data_matrices(data)
             table, _ = flux.layer_table(model, in_size)
             bmax = min(data.batchsize, data.nobs)
-            ctx.train_setup(table, n_par, flux.extract_params(ps), xm, ym, bmax, *dev_opt)
+            if compute_dtype not in ("auto", "f32", "f64"):
+                raise SubspaceError("compute_dtype must be \"auto\" (the data's element type, as in the reference), \"f32\" or \"f64\"")
+            ctx.train_setup(table, n_par, flux.extract_params(ps), xm, ym, bmax, *dev_opt,
+                            compute_dtype={"auto": None, "f32": _capi.SI_F32, "f64": _capi.SI_F64}[compute_dtype])
         for i in range(1, T + 1):
             if use_dev:
                 last = (i % print_freq == 0) or (i == T)

@@ -33,6 +33,7 @@ SOURCES = [
     ("kernels_gram_wave.hip", ["-DSI_GW_PART=2"], "kernels_gram_wave2"),
     ("kernels_project.hip", []),
     ("kernels_bwd.hip", []),
+    ("kernels_bwd_f32.hip", []),
     ("kernels_conv.hip", []),
     ("capi_net.hip", []),
     ("eig.cpp", ["-DSI_EIG_NS=base"]),

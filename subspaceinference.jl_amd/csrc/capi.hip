@@ -107,6 +107,8 @@ static void free_construct(Ctx* c) {
   c->a_cols_alloc = 0;
   c->a_bytes = 0;
   c->a_zero_dtype = -1;
+  c->a_zero_cols = 0;
+  c->a_pending = false;
   c->a_dtype = SI_F64;
   c->npush = 0;
   c->M_built = 0;
@@ -248,7 +250,7 @@ static void free_wstream(si_ctx* ctx);
 
 extern "C" {
 
-int32_t si_version(void) { return 400; }
+int32_t si_version(void) { return 500; }
 
 const char* si_last_error(si_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -376,10 +378,14 @@ int32_t si_device_name(si_ctx* ctx, char* buf, int32_t buflen) {
 // =================================================================================================
 // construction
 // =================================================================================================
-// The deviation matrix: ldA x Kcap elements of a_dtype behind d_A.  (Re)allocated when too small; the padding rows [N, ldA) of
-// every column must be zero (the Gram kernels read whole slabs): zeroed whenever the buffer is new or was last used with
-// another element size -- pushes only ever write rows < N, stale columns beyond K are never read.
+// The deviation matrix: ldA x Kcap elements of a_dtype behind d_A.  Allocated by the FIRST use after si_construct_begin -- a
+// push, or si_construct_set_storage -- so that it is sized for the storage type the construction really uses (a construction
+// that fits the device only with fp32 columns must not fail at begin on the fp64 size); (re)allocated when too
+// small.  The padding rows [N, ldA) of every column must be zero (the Gram kernels read whole slabs): zeroed whenever the
+// buffer is new, was last used with another element size, or has more columns in use than were zeroed for this element size
+// -- pushes only ever write rows < N, but a push of the OTHER element size writes over this size's padding rows.
 static int32_t ensure_A(si_ctx* ctx) {
+  ctx->a_pending = false;
   const size_t esz = ctx->a_dtype == SI_F32 ? 4 : 8;
   const size_t need = (size_t)ctx->ldA * (size_t)ctx->Kcap * esz;
   if (ctx->d_A == nullptr || ctx->a_bytes < need) {
@@ -392,13 +398,15 @@ static int32_t ensure_A(si_ctx* ctx) {
     }
     ctx->a_bytes = need;
     ctx->a_zero_dtype = -1;
+    ctx->a_zero_cols = 0;
   }
-  if (ctx->a_zero_dtype != ctx->a_dtype) {
+  if (ctx->a_zero_dtype != ctx->a_dtype || ctx->a_zero_cols < ctx->Kcap) {
     // only the padding rows [N, ldA) of every column (a strided fill of < 64 elements per column, not the whole matrix)
     if (ctx->ldA > ctx->N)
       SI_HIP(ctx, hipMemset2DAsync(reinterpret_cast<char*>(ctx->d_A) + (size_t)ctx->N * esz, (size_t)ctx->ldA * esz, 0,
                                    (size_t)(ctx->ldA - ctx->N) * esz, (size_t)ctx->Kcap, ctx->stream));
     ctx->a_zero_dtype = ctx->a_dtype;
+    ctx->a_zero_cols = ctx->Kcap;
   }
   return SI_OK;
 }
@@ -428,10 +436,7 @@ int32_t si_construct_begin(si_ctx* ctx, int64_t N, int64_t K_capacity, int32_t m
   ctx->max_cols = max_cols;
   ctx->Kcap = kcap;
   ctx->a_dtype = SI_F64;   // the reference's storage (A = Array{Float64}); si_construct_set_storage changes it before the first push
-  {
-    const int32_t arc = ensure_A(ctx);   // allocated here (not at the first push) so that an out-of-memory shows at begin
-    if (arc != SI_OK) return arc;
-  }
+  ctx->a_pending = true;   // ensure_A runs at the first push / at si_construct_set_storage: sized for the storage type in use
   // W_swa = zeros(N)  (reference :31, quirk Q1: NOT the pretrained weights)
   SI_HIP(ctx, hipMemsetAsync(ctx->d_swa, 0, (size_t)ctx->ldA * sizeof(double), ctx->stream));
   ctx->c_active = true;
@@ -486,6 +491,10 @@ static int32_t push_common(si_ctx* ctx, const void* w_dev, int32_t w_dtype, doub
     if (ctx->K >= ctx->Kcap) return fail(ctx, SI_ERR_STATE, "si_construct_push: more pushes than K_capacity");
     slot = ctx->K;
   }
+  if (ctx->a_pending) {
+    const int32_t arc = ensure_A(ctx);
+    if (arc != SI_OK) return arc;
+  }
   const size_t wsz = w_dtype == SI_F32 ? 4 : 8, asz = ctx->a_dtype == SI_F32 ? 4 : 8;
   {
     ProfScope ps(ctx, SI_K_PUSH, 4.0 * (double)ctx->N, (double)ctx->N * (double)(wsz + 16 + asz));
@@ -518,6 +527,10 @@ int32_t si_construct_push_batch_dev(si_ctx* ctx, const void* w_dev, int32_t w_dt
   if (ctx->max_cols == 0 && ctx->K + count > ctx->Kcap)
     return fail(ctx, SI_ERR_STATE, "si_construct_push: more pushes than K_capacity");
   BIND(ctx);
+  if (ctx->a_pending) {
+    const int32_t arc = ensure_A(ctx);
+    if (arc != SI_OK) return arc;
+  }
   if (ctx->nvals_cap < count) {
     SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     dev_free(ctx->d_nvals);
@@ -1893,6 +1906,7 @@ static constexpr size_t SI_CHAIN_LDS_LIMIT = 160 * 1024 - 256;
 static bool chain_loop_applies(const si_ctx* ctx) {
   if (ctx->f32 || ctx->plan.has_conv || !ctx->fuse_tail || ctx->sigma_p > 0.0) return false;
   if (ctx->layers.size() > (size_t)SI_CHAIN_MAX_LAYERS || ctx->iN > (1 << 20) || ctx->B > (1 << 20)) return false;
+  if (ctx->iM > 1024) return false;   // (rwmh_chain_kernel keeps z one element per thread of its 1024-thread workgroup)
   for (const auto& ly : ctx->layers)
     if (ly.kind != SI_LAYER_DENSE || ly.act >= SI_ACT_LEAKYRELU) return false;
   return 2.0 * (double)ctx->iN * (double)ctx->B <= 3.0e6;

@@ -38,10 +38,28 @@ __global__ __launch_bounds__(256) void widen_kernel(const float* __restrict__ w3
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) w64[i] = (double)w32[i];
 }
 
+__global__ __launch_bounds__(256) void gather_cols_f32_kernel(const float* __restrict__ src, int rows, const int64_t* __restrict__ idx,
+                                                              int64_t nb, float* __restrict__ dst) {
+  const int64_t total = (int64_t)rows * nb;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t j = e / rows;
+    const int r = (int)(e - j * rows);
+    dst[e] = src[r + (int64_t)rows * idx[j]];
+  }
+}
+__global__ __launch_bounds__(256) void narrow_kernel(const double* __restrict__ src, int64_t n, float* __restrict__ dst) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (float)src[i];
+}
+
 // Flux 0.11.2 apply! + update!:  x .-= apply!(opt, x, g), state zero(x) (Float32), arithmetic in Float64
+// g32: the gradient arrays are Float32 (compute_dtype = SI_F32: g holds Float32 values) -- then `apply!` writes its step back
+// into the Float32 array `delta` (rounded) and `x .-= delta` is a Float32 subtraction; with a Float64 gradient the step stays
+// Float64 and x - step is rounded once on the store into x
 __global__ __launch_bounds__(256) void optimiser_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                         const double* __restrict__ g, int64_t n, int kind, double eta,
-                                                        double p1, double p2, double bp1, double bp2) {
+                                                        double p1, double p2, double bp1, double bp2, int g32) {
 #pragma clang fp contract(off)
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -60,7 +78,10 @@ __global__ __launch_bounds__(256) void optimiser_kernel(float* __restrict__ w, f
       v[i] = vt;
       step = (double)mt / (1.0 - bp1) / (sqrt((double)vt / (1.0 - bp2)) + 1e-8) * eta;
     }
-    w[i] = (float)((double)w[i] - step);
+    if (g32)
+      w[i] = w[i] - (float)step;
+    else
+      w[i] = (float)((double)w[i] - step);
   }
 }
 
@@ -89,6 +110,9 @@ void free_train(Ctx* c) {
   release(t->rspart); release(t->ssepart); release(t->sse); release(t->part); release(t->Xc); release(t->wpack);
   release(t->scratch.bwpart); release(t->scratch.rspart); release(t->scratch.wt); release(t->scratch.dbtmp);
   for (auto& h : t->hs) release(h);
+  for (auto& h : t->hs32) release(h);
+  release(t->X32); release(t->Xb32); release(t->delta32[0]); release(t->delta32[1]); release(t->gw32); release(t->wt32);
+  release(t->zero32); release(t->part32); release(t->rspart64); release(t->tailpart64); release(t->yhat64);
   for (auto& h : t->pidx) release(h);
   for (int b = 0; b < 2; ++b) {
     if (t->idx_pin[b]) (void)hipHostFree(t->idx_pin[b]);
@@ -104,13 +128,16 @@ using namespace si;
 
 extern "C" {
 
-int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, const float* w0, const double* X,
-                       const double* Y, int32_t in_dim, int32_t out_dim, int64_t B_total, int64_t batch_max,
-                       int32_t opt_kind, double eta, double p1, double p2) {
+static int32_t train_setup_impl(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, const float* w0, const void* Xv,
+                                const void* Yv, int32_t data_dtype, int32_t in_dim, int32_t out_dim, int64_t B_total, int64_t batch_max,
+                                int32_t opt_kind, double eta, double p1, double p2, int32_t compute_dtype) {
   if (!ctx) return SI_ERR_INVALID;
-  if (!layers || L <= 0 || N <= 0 || !w0 || !X || !Y || in_dim <= 0 || out_dim <= 0 || B_total <= 0 || batch_max <= 0 ||
+  if (!layers || L <= 0 || N <= 0 || !w0 || !Xv || !Yv || in_dim <= 0 || out_dim <= 0 || B_total <= 0 || batch_max <= 0 ||
       batch_max > B_total || opt_kind < 0 || opt_kind > 2)
     return fail(ctx, SI_ERR_INVALID, "si_train_setup: bad argument");
+  if ((data_dtype != SI_F32 && data_dtype != SI_F64) || (compute_dtype != SI_F32 && compute_dtype != SI_F64 && compute_dtype != SI_DTYPE_OF_DATA))
+    return fail(ctx, SI_ERR_INVALID, "si_train_setup_ex: data_dtype is SI_F32 / SI_F64, compute_dtype SI_F32 / SI_F64 / SI_DTYPE_OF_DATA");
+  const bool f32 = (compute_dtype == SI_DTYPE_OF_DATA ? data_dtype : compute_dtype) == SI_F32;
   NetPlan plan;
   {
     const int32_t prc = net_plan(ctx, "si_train_setup", layers, L, N, in_dim, out_dim, plan);
@@ -129,6 +156,8 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
   const bool fuse_tail = !plan.has_conv && (L >= 2) && layers[L - 1].out <= SI_FUSE_MAX_OUT &&
                          layers[L - 1].act < SI_ACT_LEAKYRELU && layers[L - 2].act < SI_ACT_LEAKYRELU;
   if (fuse_tail) maxpart = std::max(maxpart, tail_bwd_part_elems(layers[L - 1].out, layers[L - 1].in));
+  if (f32 && plan.has_conv)
+    return fail(ctx, SI_ERR_INVALID, "si_train_setup_ex: compute_dtype = SI_F32 is implemented for Dense chains; Conv / MaxPool / flatten chains train in SI_F64");
   SI_HIP(ctx, hipSetDevice(ctx->device));
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   free_train(ctx);
@@ -140,15 +169,19 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
   t->sse_blocks = sse_num_blocks((int64_t)out_dim * batch_max, ctx->num_cu);
   t->fuse_tail = fuse_tail;
   t->fuse_slots = fuse_tail ? dense_fused_slots(layers[L - 2].out) : 0;
+  t->f32 = f32;
+  if (f32 && fuse_tail)   // (w32 is 256-byte aligned: a layer's W is 16-byte aligned iff w_off % 4 == 0)
+    t->fuse_slots = std::max(t->fuse_slots, dense_f32_fused_slots(layers[L - 2].out, layers[L - 2].in, layers[L - 2].w_off % 4 == 0));
   t->hs.assign((size_t)L, nullptr);
+  t->hs32.assign((size_t)L, nullptr);
   t->plan = plan;
   size_t nb = 1, nr = 1, nw = 1, nd = 1;
   if (plan.has_conv) net_scratch_sizes(plan, batch_max, ctx->num_cu, &nb, &nr, &nw, &nd);
   bool ok = (!plan.has_conv || (alloc(&t->wpack, plan.wpack_elems) && alloc(&t->scratch.bwpart, nb) && alloc(&t->scratch.rspart, nr) &&
                                 alloc(&t->scratch.wt, nw) && alloc(&t->scratch.dbtmp, nd))) &&
             (!plan.input_spatial || alloc(&t->Xc, (size_t)plan.in_elems * batch_max)) &&
-            alloc(&t->X, (size_t)in_dim * B_total) && alloc(&t->Y, (size_t)out_dim * B_total) &&
-            alloc(&t->Xb, (size_t)in_dim * batch_max) && alloc(&t->Yb, (size_t)out_dim * batch_max) &&
+            (f32 || (alloc(&t->X, (size_t)in_dim * B_total) && alloc(&t->Xb, (size_t)in_dim * batch_max))) &&
+            alloc(&t->Y, (size_t)out_dim * B_total) && alloc(&t->Yb, (size_t)out_dim * batch_max) &&
             alloc(&t->idx, (size_t)batch_max) &&
             hipHostMalloc((void**)&t->idx_pin[0], (size_t)batch_max * sizeof(int64_t), hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc((void**)&t->idx_pin[1], (size_t)batch_max * sizeof(int64_t), hipHostMallocDefault) == hipSuccess &&
@@ -156,12 +189,29 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
             hipEventCreateWithFlags(&t->idx_ev[1], hipEventDisableTiming) == hipSuccess &&
             alloc(&t->w32, (size_t)N) && alloc(&t->m32, (size_t)N) &&
             alloc(&t->v32, (size_t)N) && alloc(&t->w64, (size_t)pad_ld(N)) && alloc(&t->gw, (size_t)pad_ld(N)) &&
-            alloc(&t->delta[0], (size_t)maxw * batch_max) && alloc(&t->delta[1], (size_t)maxw * batch_max) &&
-            alloc(&t->bwpart, maxpart) && alloc(&t->rspart, (size_t)rowsum_chunks() * maxw) &&
+            (f32 || (alloc(&t->delta[0], (size_t)maxw * batch_max) && alloc(&t->delta[1], (size_t)maxw * batch_max) &&
+                     alloc(&t->bwpart, maxpart) && alloc(&t->rspart, (size_t)rowsum_chunks() * maxw))) &&
             alloc(&t->ssepart, (size_t)t->sse_blocks) && alloc(&t->sse, 1) &&
             (!fuse_tail || alloc(&t->part, (size_t)t->fuse_slots * out_dim * batch_max));
   t->pidx.assign((size_t)L, nullptr);
-  for (int l = 0; l < L && ok; ++l) {
+  if (f32 && ok) {
+    size_t maxpart32 = 1, maxwt = 1, maxin = (size_t)in_dim;
+    for (int l = 0; l < L; ++l) {
+      maxpart32 = std::max(maxpart32, backward_weight_f32_part_elems(layers[l].out, layers[l].in, batch_max, ctx->num_cu));
+      maxwt = std::max(maxwt, (size_t)layers[l].out * (size_t)layers[l].in);
+      maxin = std::max(maxin, (size_t)layers[l].in);
+    }
+    ok = alloc(&t->X32, (size_t)in_dim * B_total) && alloc(&t->Xb32, (size_t)in_dim * batch_max) &&
+         alloc(&t->delta32[0], (size_t)maxw * batch_max) && alloc(&t->delta32[1], (size_t)maxw * batch_max) &&
+         alloc(&t->gw32, (size_t)pad_ld(N)) && alloc(&t->wt32, maxwt) && alloc(&t->zero32, std::max(maxin, (size_t)maxw)) &&
+         alloc(&t->part32, maxpart32) && alloc(&t->rspart64, rowsum_f32_part_elems((int)std::max<size_t>(maxin, (size_t)maxw))) &&
+         alloc(&t->yhat64, (size_t)out_dim * batch_max) &&
+         (!fuse_tail || alloc(&t->tailpart64, tail_bwd_f32_part_elems(layers[L - 1].out, layers[L - 1].in)));
+    for (int l = 0; l < L && ok; ++l)   // (the head's own output lives in yhat64)
+      if (!(fuse_tail && l == L - 1)) ok = alloc(&t->hs32[(size_t)l], (size_t)layers[l].out * batch_max);
+    if (ok) SI_HIP(ctx, hipMemsetAsync(t->zero32, 0, std::max(maxin, (size_t)maxw) * sizeof(float), ctx->stream));
+  }
+  for (int l = 0; l < L && ok && !f32; ++l) {
     if (plan.has_conv && net_grad_fused(plan, (size_t)l))   // Conv + MaxPool as one kernel: a byte index instead of the activation
       ok = alloc(&t->pidx[(size_t)l], net_pidx_bytes(plan, (size_t)l, batch_max));
     else
@@ -172,13 +222,69 @@ int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N
     free_train(ctx);
     return fail(ctx, SI_ERR_NOMEM, "si_train_setup: device allocation failed");
   }
-  SI_HIP(ctx, hipMemcpyAsync(t->X, X, (size_t)in_dim * B_total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  SI_HIP(ctx, hipMemcpyAsync(t->Y, Y, (size_t)out_dim * B_total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  {
+    // the data in the element type the step computes in (X) / sums the loss in (Y: fp64 always); one conversion at set-up where
+    // the caller's type differs (Float32 -> Float64 is exact; Float64 -> Float32 rounds once, as `Float32.(X)` would)
+    const size_t nx = (size_t)in_dim * B_total, ny = (size_t)out_dim * B_total;
+    const size_t esz = data_dtype == SI_F32 ? 4 : 8;
+    void* stage = nullptr;
+    const bool x_conv = (data_dtype == SI_F32) != f32, y_conv = data_dtype == SI_F32;
+    if ((x_conv || y_conv) && hipMalloc(&stage, std::max(nx, ny) * esz) != hipSuccess) {
+      free_train(ctx);
+      return fail(ctx, SI_ERR_NOMEM, "si_train_setup: device allocation failed");
+    }
+    hipError_t e = hipSuccess;
+    const int gx = grid_for((int64_t)nx, ctx->num_cu), gy = grid_for((int64_t)ny, ctx->num_cu);
+    if (!x_conv) {
+      e = hipMemcpyAsync(f32 ? (void*)t->X32 : (void*)t->X, Xv, nx * esz, hipMemcpyHostToDevice, ctx->stream);
+    } else {
+      e = hipMemcpyAsync(stage, Xv, nx * esz, hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) {
+        if (f32) hipLaunchKernelGGL(narrow_kernel, dim3(gx), dim3(256), 0, ctx->stream, static_cast<const double*>(stage), (int64_t)nx, t->X32);
+        else hipLaunchKernelGGL(widen_kernel, dim3(gx), dim3(256), 0, ctx->stream, static_cast<const float*>(stage), (int64_t)nx, t->X);
+      }
+    }
+    if (e == hipSuccess) {
+      if (!y_conv) {
+        e = hipMemcpyAsync(t->Y, Yv, ny * 8, hipMemcpyHostToDevice, ctx->stream);
+      } else {
+        e = hipStreamSynchronize(ctx->stream);   // (the staging buffer is reused)
+        if (e == hipSuccess) e = hipMemcpyAsync(stage, Yv, ny * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) hipLaunchKernelGGL(widen_kernel, dim3(gy), dim3(256), 0, ctx->stream, static_cast<const float*>(stage), (int64_t)ny, t->Y);
+      }
+    }
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (stage) (void)hipFree(stage);
+    if (e != hipSuccess || e2 != hipSuccess) {
+      free_train(ctx);
+      return fail(ctx, SI_ERR_HIP, std::string("si_train_setup: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    }
+  }
   SI_HIP(ctx, hipMemcpyAsync(t->w32, w0, (size_t)N * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   SI_HIP(ctx, hipMemsetAsync(t->m32, 0, (size_t)N * sizeof(float), ctx->stream));
   SI_HIP(ctx, hipMemsetAsync(t->v32, 0, (size_t)N * sizeof(float), ctx->stream));
   SI_HIP(ctx, hipMemsetAsync(t->w64, 0, (size_t)pad_ld(N) * sizeof(double), ctx->stream));
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SI_OK;
+}
+
+int32_t si_train_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, const float* w0, const double* X,
+                       const double* Y, int32_t in_dim, int32_t out_dim, int64_t B_total, int64_t batch_max,
+                       int32_t opt_kind, double eta, double p1, double p2) {
+  return train_setup_impl(ctx, layers, L, N, w0, X, Y, SI_F64, in_dim, out_dim, B_total, batch_max, opt_kind, eta, p1, p2, SI_F64);
+}
+
+int32_t si_train_setup_ex(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, const float* w0, const void* X, const void* Y,
+                          int32_t data_dtype, int32_t in_dim, int32_t out_dim, int64_t B_total, int64_t batch_max, int32_t opt_kind,
+                          double eta, double p1, double p2, int32_t compute_dtype) {
+  return train_setup_impl(ctx, layers, L, N, w0, X, Y, data_dtype, in_dim, out_dim, B_total, batch_max, opt_kind, eta, p1, p2,
+                          compute_dtype);
+}
+
+int32_t si_train_compute_dtype(si_ctx* ctx, int32_t* out) {
+  if (!ctx) return SI_ERR_INVALID;
+  if (!ctx->train || !out) return fail(ctx, SI_ERR_STATE, "si_train_compute_dtype: no training state / NULL output");
+  *out = ctx->train->f32 ? SI_F32 : SI_F64;
   return SI_OK;
 }
 
@@ -200,6 +306,7 @@ static int32_t train_gradient(si_ctx* ctx, const char* who, const int64_t* idx, 
   const int64_t N = t->N;
   const size_t nl = t->layers.size();
   const double *Xb = t->X, *Yb = t->Y;
+  const float* Xb32 = t->X32;
   if (!in_order) {
     // idx is caller-owned: copied into a pinned buffer, shipped asynchronously; the buffer is free again once its event has
     // passed (two steps later at the earliest) -- no synchronisation of the stream, the call returns while the GPU works
@@ -210,14 +317,91 @@ static int32_t train_gradient(si_ctx* ctx, const char* who, const int64_t* idx, 
     SI_HIP(ctx, hipMemcpyAsync(t->idx, t->idx_pin[b], (size_t)nb * sizeof(int64_t), hipMemcpyHostToDevice, st));
     SI_HIP(ctx, hipEventRecord(t->idx_ev[b], st));
     t->idx_busy[b] = true;
-    hipLaunchKernelGGL(gather_cols_kernel, dim3(grid_for((int64_t)t->in_dim * nb, ctx->num_cu)), dim3(256), 0, st, t->X,
-                       t->in_dim, t->idx, nb, t->Xb);
+    if (t->f32) {
+      hipLaunchKernelGGL(gather_cols_f32_kernel, dim3(grid_for((int64_t)t->in_dim * nb, ctx->num_cu)), dim3(256), 0, st, t->X32,
+                         t->in_dim, t->idx, nb, t->Xb32);
+      Xb32 = t->Xb32;
+    } else {
+      hipLaunchKernelGGL(gather_cols_kernel, dim3(grid_for((int64_t)t->in_dim * nb, ctx->num_cu)), dim3(256), 0, st, t->X,
+                         t->in_dim, t->idx, nb, t->Xb);
+    }
     hipLaunchKernelGGL(gather_cols_kernel, dim3(grid_for((int64_t)t->out_dim * nb, ctx->num_cu)), dim3(256), 0, st, t->Y,
                        t->out_dim, t->idx, nb, t->Yb);
     Xb = t->Xb;
     Yb = t->Yb;
   }
   hipLaunchKernelGGL(widen_kernel, dim3(grid_for(N, ctx->num_cu)), dim3(256), 0, st, t->w32, N, t->w64);
+  if (t->f32) {
+    // ---- the step in the caller's precision: a Float32 model on Float32 data is a Float32 Zygote pass in the reference
+    // (src/subspace_construction.jl:39-43).  fp32 operands and activations on v_mfma_f32_32x32x2_f32; fp64 for the head's
+    // partial sums, the loss and every sum over the batch (rounded once into the Float32 gradient).
+    const float* w = t->w32;
+    const float* h = Xb32;
+    const size_t nplain = t->fuse_tail ? nl - 2 : nl;
+    for (size_t l = 0; l < nplain; ++l) {
+      const si_layer& ly = t->layers[l];
+      ProfScope ps(ctx, SI_K_DENSE, 2.0 * (double)ly.in * ly.out * (double)nb, 0.0);
+      launch_dense_f32(st, w + ly.w_off, w + ly.b_off, h, t->hs32[l], ly.out, ly.in, nb, ly.act);
+      h = t->hs32[l];
+    }
+    const int64_t d = (int64_t)t->out_dim * nb;
+    const int sse_blocks = sse_num_blocks(d, ctx->num_cu);
+    const si_layer& ll = t->layers[nl - 1];
+    if (t->fuse_tail) {
+      const si_layer& ly = t->layers[nl - 2];
+      const int slots = dense_f32_fused_slots(ly.out, ly.in, ly.w_off % 4 == 0);
+      {
+        ProfScope ps(ctx, SI_K_DENSE, 2.0 * ((double)ly.in * ly.out + (double)ll.in * ll.out) * (double)nb, 0.0);
+        launch_dense_f32_fused(st, w + ly.w_off, w + ly.b_off, h, ly.out, ly.in, nb, ly.act, w + ll.w_off, ll.out, t->part, ChainBatch(),
+                               t->hs32[nl - 2]);
+      }
+      launch_tail_sse(st, t->part, slots, ll.out, nb, t->w64 + ll.b_off, ll.act, Yb, t->yhat64, t->ssepart, sse_blocks);
+      launch_sse_final(st, t->ssepart, sse_blocks, t->sse);
+    } else {
+      launch_sse_f32(st, h, Yb, d, t->ssepart, sse_blocks, t->sse);
+    }
+    double bflops = 0.0;
+    for (const auto& ly : t->layers) bflops += 4.0 * (double)ly.in * ly.out * (double)nb;
+    ProfScope ps(ctx, SI_K_BACKWARD, bflops, 0.0);
+    SI_HIP(ctx, hipMemsetAsync(t->gw32, 0, (size_t)pad_ld(N) * sizeof(float), st));
+    int cur = 0;
+    // d mse / d yhat = 2 (yhat - y) / d, times act_L'
+    launch_delta_out_f32(st, Yb, t->fuse_tail ? t->yhat64 : nullptr, t->fuse_tail ? nullptr : h, d, -2.0 / d_total, ll.act, t->delta32[cur]);
+    size_t top = nl;
+    bool have_db = false;   // db of layer top-1 already produced (by the pass that formed its Delta)
+    if (t->fuse_tail) {
+      const si_layer& lp = t->layers[nl - 2];
+      launch_mul_dact_rowsum_f32(st, t->delta32[cur], nullptr, ll.out, nb, SI_ACT_IDENTITY, nullptr, t->rspart64, t->gw32 + ll.b_off);
+      launch_tail_bwd_f32(st, w + ll.w_off, t->delta32[cur], t->hs32[nl - 2], ll.out, ll.in, nb, lp.act, t->delta32[cur ^ 1], t->tailpart64,
+                          t->gw32 + ll.w_off, t->gw32 + lp.b_off);
+      cur ^= 1;
+      top = nl - 1;
+      have_db = true;
+    }
+    for (size_t li = top; li-- > 0;) {
+      const si_layer& ly = t->layers[li];
+      const float* hprev = li > 0 ? t->hs32[li - 1] : Xb32;
+      launch_backward_weight_f32(st, t->delta32[cur], hprev, t->part32, ly.out, ly.in, nb, ctx->num_cu, t->gw32 + ly.w_off);
+      if (!have_db)
+        launch_mul_dact_rowsum_f32(st, t->delta32[cur], nullptr, ly.out, nb, SI_ACT_IDENTITY, nullptr, t->rspart64, t->gw32 + ly.b_off);
+      if (li > 0) {
+        // Delta_{l-1} = (W_l' Delta_l) .* act'(H_{l-1}): the forward kernel on W_l' (out' = in, in' = out, zero bias), then one
+        // elementwise pass that also sums the rows (db of layer l-1)
+        const si_layer& lq = t->layers[li - 1];
+        launch_transpose_f32(st, w + ly.w_off, ly.out, ly.in, t->wt32);
+        launch_dense_f32(st, t->wt32, t->zero32, t->delta32[cur], t->delta32[cur ^ 1], ly.in, ly.out, nb, SI_ACT_IDENTITY);
+        launch_mul_dact_rowsum_f32(st, t->delta32[cur ^ 1], t->hs32[li - 1], ly.in, nb, lq.act, t->delta32[cur ^ 1], t->rspart64,
+                                   t->gw32 + lq.b_off);
+        cur ^= 1;
+        have_db = true;
+      }
+    }
+    // the gradient as the optimiser and the data-parallel all-reduce see it: fp64 words holding the Float32 values
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(N, ctx->num_cu)), dim3(256), 0, st, t->gw32, N, t->gw);
+    SI_HIP(ctx, hipGetLastError());
+    t->grad_ready = true;
+    return SI_OK;
+  }
   if (t->plan.has_conv) {
     // chains with Conv / MaxPool / flatten layers: the generic forward / reverse sweep of capi_net.hip
     const NetPlan& p = t->plan;
@@ -286,7 +470,7 @@ static int32_t train_gradient(si_ctx* ctx, const char* who, const int64_t* idx, 
 static int32_t train_apply(si_ctx* ctx) {
   TrainState* t = ctx->train;
   hipLaunchKernelGGL(optimiser_kernel, dim3(grid_for(t->N, ctx->num_cu)), dim3(256), 0, ctx->stream, t->w32, t->m32, t->v32,
-                     t->gw, t->N, t->opt, t->eta, t->p1, t->p2, t->bp1, t->bp2);
+                     t->gw, t->N, t->opt, t->eta, t->p1, t->p2, t->bp1, t->bp2, t->f32 ? 1 : 0);
   SI_HIP(ctx, hipGetLastError());
   if (t->opt == 2) {
     t->bp1 *= t->p1;

@@ -212,10 +212,13 @@ static int32_t comm_agree(si_ctx* ctx, int32_t local_rc, const char* who) {
   double flag = local_rc == SI_OK ? 0.0 : 1.0;
   double* slot = ctx->d_commtmp + COMM_TMP_ELEMS;
   const std::string own = ctx->err;
+  // A local HIP failure in front of the all-reduce must NOT make this rank skip it (its peers would wait inside theirs for
+  // good -- ADVICE r4): the all-reduce is entered regardless, on whatever the slot holds; the failing rank reports its HIP
+  // error below, and if its flag never reached the device its peers learn of the failure from the next collective's own
+  // error handling rather than from a hang here.
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMemcpyAsync(slot, &flag, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-  ncclResult_t nr = ncclSuccess;
-  if (e == hipSuccess) nr = rccl().AllReduce(slot, slot, 1, ncclFloat64, ncclMax, comm_of(ctx), ctx->stream);
+  const ncclResult_t nr = rccl().AllReduce(slot, slot, 1, ncclFloat64, ncclMax, comm_of(ctx), ctx->stream);
   if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(&flag, slot, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
   const hipError_t e2 = hipStreamSynchronize(ctx->stream);
   if (local_rc != SI_OK) {   // this rank's own failure is what it reports

@@ -182,12 +182,17 @@ class CopyPool {
       }
       Slice s;
       {
-        std::lock_guard<std::mutex> lk(m_);   // orders the read of the slice after the writer's update
+        // The slice is read AND claimed inside the critical section in which copy() publishes a generation (slices, claim
+        // words, pending count): a worker descheduled between the two could otherwise claim the NEXT copy's slice with the
+        // previous copy's (stale, possibly freed) pointers in hand and take one off the next copy's pending count.
+        // A claim taken here belongs to generation `seen`; its copy() cannot return -- and no later generation begin --
+        // before this worker has taken its slice off pending_.
+        std::lock_guard<std::mutex> lk(m_);
         seen = gen_.load(std::memory_order_acquire);
         if (stop_) return;
         s = slices_[(size_t)i];
+        if (claimed_[(size_t)i].exchange(1, std::memory_order_acq_rel) != 0) continue;   // not part of this copy, or taken over by the caller
       }
-      if (claimed_[(size_t)i].exchange(1, std::memory_order_acq_rel) != 0) continue;   // not part of this copy, or taken over by the caller
       if (s.bytes) std::memcpy(s.dst, s.src, s.bytes);
       pending_.fetch_sub(1, std::memory_order_release);
     }

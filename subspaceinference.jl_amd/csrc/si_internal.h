@@ -95,6 +95,14 @@ struct TrainState {
   bool fuse_tail = false;   // narrow head: folded into the epilogue of the layer in front of it (forward and reverse)
   int fuse_slots = 0;
   double* part = nullptr;   // [fuse_slots][out_last][Bmax] partial head products
+  // compute_dtype = SI_F32 (Dense chains; reference src/subspace_construction.jl:39-43 with a Float32 model AND Float32 data):
+  // fp32 data, activations, deltas and gradient; fp64 only for the loss, the head's partial sums and the sums over the batch
+  bool f32 = false;
+  float *X32 = nullptr, *Xb32 = nullptr;
+  std::vector<float*> hs32;          // kept outputs of the stored layers
+  float* delta32[2] = {nullptr, nullptr};
+  float *gw32 = nullptr, *wt32 = nullptr, *zero32 = nullptr, *part32 = nullptr;   // gradient, a layer's W transposed, a zero bias, dW split partials
+  double *rspart64 = nullptr, *tailpart64 = nullptr, *yhat64 = nullptr;
   // chains with Conv / MaxPool / flatten layers (generic path, capi_net.hip)
   NetPlan plan;
   double *Xc = nullptr, *wpack = nullptr;
@@ -152,6 +160,8 @@ struct Ctx {
   int32_t a_dtype = SI_F64;   // storage of the deviation matrix (si_construct_set_storage)
   size_t a_bytes = 0;         // bytes allocated behind d_A
   int32_t a_zero_dtype = -1;  // element type for which the padding rows of d_A are known to be zero (-1: unknown)
+  int64_t a_zero_cols = 0;    // ... in the first a_zero_cols columns
+  bool a_pending = false;     // si_construct_begin ran, the matrix is allocated / checked by the first push or si_construct_set_storage
   void* d_wstage = nullptr;   // staging of si_construct_set_mean
   // pipelined host pushes (si_construct_push): two pinned host buffers -> two device buffers, events mark the H2D of each
   void* h_wpin[2] = {nullptr, nullptr};
@@ -410,6 +420,19 @@ size_t tail_bwd_part_elems(int32_t out_last, int32_t F);
 void launch_tail_bwd(hipStream_t st, const double* W, const double* Delta, const double* H, int32_t out_last, int32_t F,
                      int64_t B, int32_t act_prev, double* DeltaPrev, double* part, double* dW, double* dbprev);
 int rowsum_chunks();
+// the reverse sweep in fp32 (kernels_bwd_f32.hip): compute_dtype = SI_F32 of the on-device training step
+size_t backward_weight_f32_part_elems(int32_t out, int32_t in, int64_t B, int num_cu);
+void launch_backward_weight_f32(hipStream_t st, const float* Delta, const float* Hprev, float* part, int32_t out, int32_t in, int64_t B,
+                                int num_cu, float* dW);
+void launch_transpose_f32(hipStream_t st, const float* W, int32_t out, int32_t in, float* Wt);
+size_t rowsum_f32_part_elems(int max_rows);
+void launch_mul_dact_rowsum_f32(hipStream_t st, const float* G, const float* H, int rows, int64_t B, int act, float* D, double* part,
+                                float* db);   // D = G .* act'(H) (H == nullptr: G itself; D == nullptr: nothing stored), db = rowsum(D)
+void launch_delta_out_f32(hipStream_t st, const double* Y, const double* Yhat64, const float* Yhat32, int64_t d, double scale, int act,
+                          float* delta);
+size_t tail_bwd_f32_part_elems(int32_t out_last, int32_t F);
+void launch_tail_bwd_f32(hipStream_t st, const float* W, const float* Delta, const float* H, int32_t out_last, int32_t F, int64_t B,
+                         int32_t act_prev, float* DeltaPrev, double* part, float* dW, float* dbprev);
 void launch_ptg(hipStream_t st, const double* P, int64_t ldP, int64_t N, int M, const double* g, double* part, double* gz);
 int ptg_blocks();
 // ---- Conv / MaxPool / flatten (kernels_conv.hip; host side capi_net.hip) ---------------------------------------------

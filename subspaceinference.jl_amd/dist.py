@@ -110,12 +110,16 @@ def comm_init(ctx, rank=None, world=None, id_file=None, timeout_s=120.0):
         uid = _capi.comm_unique_id()
     else:
         raise _capi.SubspaceError("comm_init: %d ranks need a way to share the RCCL id (a torch process group or id_file)" % world)
-    ctx.comm_init_rank(world, rank, uid)
-    if id_file is not None and rank == 0:   # every rank has read the id once ncclCommInitRank returns anywhere
-        try:
-            os.unlink(id_file)
-        except OSError:
-            pass
+    try:
+        ctx.comm_init_rank(world, rank, uid)
+    finally:
+        # every rank has read the id once ncclCommInitRank returns anywhere; a bring-up that RAISES must not leave the file
+        # behind either (the next run would find a stale id there)
+        if id_file is not None and rank == 0:
+            try:
+                os.unlink(id_file)
+            except OSError:
+                pass
     return rank, world
 
 

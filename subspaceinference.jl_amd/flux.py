@@ -371,6 +371,13 @@ def store_device_state(opt, model, m_flat, v_flat, beta_pows):
 
 
 def update(opt, ps, gs):
-    """Flux.update!(opt, ps, gs): `x .-= apply!(opt, x, g)` -- Float32 x minus Float64 step, rounded once to Float32."""
+    """Flux.update!(opt, ps, gs): `x .-= apply!(opt, x, g)`.  With a Float64 gradient (Float64 data) the step stays Float64 and
+    x - step is rounded once on the store into the Float32 x; with a Float32 gradient (the all-Float32 pass of Float32 data)
+    `apply!` writes the step back into the Float32 gradient array (rounded) and the subtraction is Float32."""
     for p, g in zip(ps, gs):
-        p[...] = (p.astype(np.float64) - opt.apply(p, np.asarray(g, dtype=np.float64))).astype(p.dtype)
+        g = np.asarray(g)
+        step = opt.apply(p, g.astype(np.float64))
+        if g.dtype == np.float32 and p.dtype == np.float32:
+            p[...] = p - step.astype(np.float32)
+        else:
+            p[...] = (p.astype(np.float64) - step).astype(p.dtype)

@@ -141,6 +141,18 @@ function data_matrices(data)
     insize = ndims(X) == 4 ? size(X)[1:3] : nothing
     return Float64.(reshape(X, :, size(X)[end])), Float64.(reshape(Y, :, size(Y)[end])), insize
 end
+# the same for the training step, in the element type that decides its arithmetic: Float32 (X, Y) stay Float32 -- with a
+# Float32 model that is an all-Float32 Zygote pass in the reference (src/subspace_construction.jl:39-43) -- anything else is
+# promoted to Float64, as `W * x` would promote it
+function train_matrices(data)
+    X, Y = data.data[1], data.data[2]
+    insize = ndims(X) == 4 ? size(X)[1:3] : nothing
+    T = (eltype(X) == Float32 && eltype(Y) == Float32) ? Float32 : Float64
+    return Array{T}(reshape(X, :, size(X)[end])), Array{T}(reshape(Y, :, size(Y)[end])), insize
+end
+const SI_DTYPE_OF_DATA = Int32(-1)
+si_dtype(::Type{Float32}) = Int32(0)
+si_dtype(::Type{Float64}) = Int32(1)
 
 # ---- on-device training step (SURVEY 8 f1): src/subspace_construction.jl:39-43 for cost = mse ----------------------
 # (kind, η, p1, p2) of a fresh Flux 0.11.2 optimiser [upstream field names: Descent.eta; Momentum.eta/.rho; ADAM.eta/.beta]
@@ -168,17 +180,19 @@ end
 # data_parallel = true (opt-in): every rank of the ctx's communicator makes this call with the same model / data / DataLoader
 # seed and takes its share of every batch.  The default keeps the step local whatever the ctx carries: a construction on one
 # rank followed by bcast_subspace! (the cfg3 flow) must not wait alone inside a gradient all-reduce.
-function train_on_device!(ctx::Ctx, model, data, opt, T, c, print_freq; data_parallel = false)
-    X, Y, insize = data_matrices(data)
+# compute_dtype: SI_DTYPE_OF_DATA (default: Float32 data => the Float32 pass, Float64 data => the Float64 pass, as in the
+# reference), or si_dtype(Float32) / si_dtype(Float64) to override
+function train_on_device!(ctx::Ctx, model, data, opt, T, c, print_freq; data_parallel = false, compute_dtype = SI_DTYPE_OF_DATA)
+    X, Y, insize = train_matrices(data)
     tbl, N = layer_table(model, insize)
     kind, η, p1, p2 = device_optimiser(opt)
     ps = Flux.params(model)
     w0 = Float32.(extract_params(ps))
-    GC.@preserve tbl w0 X Y check(ctx, ccall((:si_train_setup, LIB), Int32,
-        (Ptr{Cvoid}, Ptr{SiLayer}, Int32, Int64, Ptr{Float32}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Int64, Int64,
-         Int32, Float64, Float64, Float64),
-        ctx.h, tbl, length(tbl), N, w0, X, Y, size(X, 1), size(Y, 1), size(X, 2), min(data.batchsize, data.nobs),
-        kind, η, p1, p2))
+    GC.@preserve tbl w0 X Y check(ctx, ccall((:si_train_setup_ex, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{SiLayer}, Int32, Int64, Ptr{Float32}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Int32, Int64, Int64,
+         Int32, Float64, Float64, Float64, Int32),
+        ctx.h, tbl, length(tbl), N, w0, X, Y, si_dtype(eltype(X)), size(X, 1), size(Y, 1), size(X, 2),
+        min(data.batchsize, data.nobs), kind, η, p1, p2, Int32(compute_dtype)))
     loss = Ref{Float64}(0.0)
     world, rank = comm_info(ctx)
     for i in 1:T
@@ -225,7 +239,7 @@ end
 # init = :zeros is what the reference's code does (W_swa = zeros, :31); :pretrained is what its docs describe (nn_example.md:44)
 function subspace_construction(model, cost, data, opt; T = 10, c = 1, M = 3, print_freq = 1, device = 0,
                                ctx = Ctx(device), max_cols = 0, keep_on_device = false, device_training = false,
-                               init = :zeros, data_parallel = false, a_storage = :f64)
+                               init = :zeros, data_parallel = false, a_storage = :f64, compute_dtype = :auto)
     training_loss = 0.0
     ps = Flux.params(model)
     N = sum(length, ps)
@@ -239,7 +253,10 @@ function subspace_construction(model, cost, data, opt; T = 10, c = 1, M = 3, pri
                                          ctx.h, pointer(W0), eltype(W0) == Float32 ? SI_F32 : SI_F64))
     end
     if device_training
-        train_on_device!(ctx, model, data, opt, T, c, print_freq; data_parallel = data_parallel)
+        # compute_dtype = :auto: the device step computes in the DATA's element type, as the reference's Zygote pass does
+        # (Float32 model + Float32 data: Float32 throughout; Float64 data: Float64); :f32 / :f64 override
+        cd = compute_dtype == :auto ? SI_DTYPE_OF_DATA : compute_dtype == :f32 ? SI_F32 : SI_F64
+        train_on_device!(ctx, model, data, opt, T, c, print_freq; data_parallel = data_parallel, compute_dtype = cd)
     else
         for i in 1:T
             for d in data

@@ -101,6 +101,17 @@ def main():
         out.update({name + "_w": w, name + "_loss": np.array(losses), name + "_m": st["m"], name + "_v": st["v"],
                     name + "_bp": np.array(st["bp"] if st["bp"] else [0.0, 0.0])})
     np.savez_compressed(os.path.join(HERE, "toy_train_steps.npz"), **out)
+    # ---- the same 12 steps with Float32 DATA: a Float32 model on Float32 (X, Y) is an all-Float32 Zygote pass in the reference
+    # (nothing promotes), and Flux's optimisers then round their step into the Float32 gradient array before `x .-= step`
+    tx32, ty32 = tx.astype(np.float32), ty.astype(np.float32)
+    out32 = dict(X=tx32, Y=ty32, w0=tw0, batches=out["batches"])
+    for name, opt in opts.items():
+        w, st, losses = tw0.copy(), so.optimiser_state(tn, opt), []
+        for ids in batches:
+            losses.append(so.train_step(ttab, w, st, tx32[:, ids], ty32[:, ids], opt))
+        out32.update({name + "_w": w, name + "_loss": np.array(losses), name + "_m": st["m"], name + "_v": st["v"],
+                      name + "_bp": np.array(st["bp"] if st["bp"] else [0.0, 0.0])})
+    np.savez_compressed(os.path.join(HERE, "toy_train_steps_f32.npz"), **out32)
     print("wrote golden fixtures to", HERE)
 
 

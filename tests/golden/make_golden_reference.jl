@@ -90,4 +90,29 @@ for (name, mk) in (("descent", () -> Descent(0.1)), ("momentum", () -> Momentum(
     out[name * "_loss"] = losses
 end
 npzwrite(joinpath(here, "toy_train_steps_reference.npz"), out)
+
+# ---- the same with Float32 DATA (toy_train_steps_f32.npz): nothing promotes, the Zygote pass and `update!` are Float32 ------
+trn32 = npzread(joinpath(here, "toy_train_steps_f32.npz"))
+tx32, ty32 = Float32.(trn32["X"]), Float32.(trn32["Y"])
+out32 = Dict{String,Any}()
+for (name, mk) in (("descent", () -> Descent(0.1)), ("momentum", () -> Momentum(0.01, 0.9)), ("adam", () -> ADAM(0.001, (0.9, 0.999))))
+    m = Chain(Dense(10, 20, tanh), Dense(20, 20, relu), Dense(20, 2))
+    θ, re = Flux.destructure(m)
+    m = re(Float32.(trn32["w0"]))
+    ps, opt = Flux.params(m), mk()
+    losses = Float64[]
+    for b in 1:size(batches, 1)
+        ids = filter(i -> i >= 0, batches[b, :]) .+ 1
+        local training_loss
+        gs = gradient(ps) do
+            training_loss = Flux.Losses.mse(m(tx32[:, ids]), ty32[:, ids])
+            return training_loss
+        end
+        Flux.update!(opt, ps, gs)
+        push!(losses, Float64(training_loss))
+    end
+    out32[name * "_w"] = SubspaceInference.extract_params(ps)
+    out32[name * "_loss"] = losses
+end
+npzwrite(joinpath(here, "toy_train_steps_f32_reference.npz"), out32)
 println("wrote *_reference.npz next to the oracle fixtures")

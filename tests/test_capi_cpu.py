@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(si):
         assert hasattr(lib, s), "libsubspace_hip.so does not export %s" % s
     # and the ctypes table binds exactly the declared ABI
     assert sorted(si._capi.SIGNATURES) == syms
-    assert lib.si_version() == 400
+    assert lib.si_version() == 500
 
 
 def test_no_cpu_fallback(si):

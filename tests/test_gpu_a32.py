@@ -95,3 +95,58 @@ def test_fp32_storage_through_the_api(si, gpu_ctx):
     assert np.array_equal(res["f64"][0], res["f32"][0])
     p64, p32 = res["f64"][1], res["f32"][1]
     assert np.max(np.abs(_align(p32, p64) - p64)) <= 1e-5 * np.abs(p64).max()
+
+
+def test_padding_rows_stay_zero_across_storage_types_and_capacities(si, gpu_ctx):
+    """N % 32 != 0; an fp32 construction at K = 100 writes over the fp64 padding rows of columns 0 .. 49; a small
+    fp64 construction then re-zeroes 20 columns only; the next fp64 construction at K = 100 must not read dirty padding
+    (the Gram kernels read whole 32-row slabs)."""
+    from subspaceinference_jl_amd import _capi
+    n, m = 1003, 5
+    ctx = gpu_ctx
+    s32 = _snaps(n, 100, seed=1)
+    ctx.construct_begin(n, 100)
+    ctx.construct_set_storage(_capi.SI_F32)
+    for i, w in enumerate(s32):
+        ctx.construct_push(w, float(1 + i // 7))
+    ctx.construct_finish(m)
+    small = _snaps(n, 20, seed=2)
+    ctx.construct_begin(n, 20)
+    for i, w in enumerate(small):
+        ctx.construct_push(w, float(1 + i // 7))
+    ctx.construct_finish(m)
+    big = _snaps(n, 100, seed=3)
+    ns = [float(1 + i // 7) for i in range(100)]
+    ctx.construct_begin(n, 100)
+    for w, nn in zip(big, ns):
+        ctx.construct_push(w, nn)
+    w_swa, p, s, k = ctx.construct_finish(m)
+    w_ref, a_ref = so.construct_stream(big, ns)
+    p_ref, s_ref = so.projection_from_A(a_ref, m)
+    assert np.array_equal(w_swa, w_ref)
+    assert np.allclose(s, np.asarray(s_ref)[:m], rtol=1e-10)
+    assert np.allclose(_align(p, p_ref), p_ref, rtol=1e-7, atol=1e-9 * float(np.abs(p_ref).max()))
+
+
+def test_fp32_storage_allocates_the_fp32_size(si, gpu_ctx):
+    """the deviation matrix is allocated by its first use, at the size of the storage type in use -- a fresh
+    context's fp32 construction takes half the device memory of the fp64 one"""
+    import torch
+    from subspaceinference_jl_amd import _capi
+    n, k = 2_000_003, 64   # fp64: 1.02 GB, fp32: 0.51 GB
+    w = np.zeros(n, dtype=np.float32)
+
+    def grown(storage):
+        with si.Context(0) as c:
+            torch.cuda.synchronize()
+            free0 = torch.cuda.mem_get_info()[0]
+            c.construct_begin(n, k)
+            if storage is not None:
+                c.construct_set_storage(storage)
+            c.construct_push(w, 1.0)
+            c.synchronize()
+            return free0 - torch.cuda.mem_get_info()[0]
+
+    g64, g32 = grown(None), grown(_capi.SI_F32)
+    a64 = 8 * k * ((n + 63) // 64 * 64)
+    assert g64 >= a64 and g32 < g64 - 0.4 * a64, (g64, g32, a64)

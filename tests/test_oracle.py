@@ -368,13 +368,39 @@ def test_maxpool_gradient_goes_to_one_element_per_window():
     assert np.array_equal(gx[0::2, 0::2, 0, 0], g4[:, :, 0, 0]) and gx[1::2, :, 0, 0].sum() == 0.0   # constant channel: first element
 
 
+def test_training_step_float32_data():
+    """Float32 (X, Y) with the Float32 model: the oracle's pass stays Float32 line by line (as Julia's would), reproduces the
+    committed fixture, lands within Float32 rounding of the Float64 pass, and the optimisers round their step into the
+    Float32 gradient array before the Float32 subtraction."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "toy_train_steps_f32.npz"))
+    d64, batches = _train_fixture()
+    table, n = so.layer_table(TRAIN_DIMS, TRAIN_ACTS)
+    x, y = d["X"], d["Y"]
+    assert x.dtype == np.float32 and y.dtype == np.float32 and np.array_equal(d["batches"], d64["batches"])
+    loss, g = so.mse_value_and_grad(table, d["w0"], x[:, batches[0]], y[:, batches[0]])
+    assert g.dtype == np.float32 and isinstance(loss, float)
+    _, g64 = so.mse_value_and_grad(table, d["w0"].astype(np.float64), x[:, batches[0]].astype(np.float64), y[:, batches[0]].astype(np.float64))
+    assert np.allclose(g, g64, rtol=0, atol=2e-6 * np.abs(g64).max())
+    for name, opt in TRAIN_OPTS.items():
+        w, st = d["w0"].copy(), so.optimiser_state(n, opt)
+        losses = [so.train_step(table, w, st, x[:, ids], y[:, ids], opt) for ids in batches]
+        assert np.array_equal(w, d[name + "_w"]) and np.array_equal(np.array(losses), d[name + "_loss"])
+        # the two precisions train the same model: 12 steps apart by Float32 rounding only
+        assert np.allclose(w, d64[name + "_w"], rtol=0, atol=2e-5) and np.allclose(losses, d64[name + "_loss"], rtol=1e-5)
+    # the rounding rule of `x .-= apply!(...)` with a Float32 gradient: one Descent step by hand
+    w = d["w0"].copy()
+    _, g = so.mse_value_and_grad(table, w, x[:, batches[0]], y[:, batches[0]])
+    so.apply_update(w, so.optimiser_state(n, ("descent", 0.1)), g, ("descent", 0.1))
+    assert np.array_equal(w, d["w0"] - (g.astype(np.float64) * 0.1).astype(np.float32))
+
+
 def test_reference_fixtures_when_present():
     """`tests/golden/make_golden_reference.jl` (UNEXECUTED here: no Julia) writes `*_reference.npz` from the REAL package.
     When a maintainer has run it and committed the files, this test holds the oracle against them -- the moment the parity
     of this repository stops being 'unpinned'.  Without the files it is skipped."""
     gold = os.path.join(os.path.dirname(__file__), "golden")
     names = ["toy_construct_k12_reference.npz", "toy_density_rwmh_reference.npz", "toy_train_steps_reference.npz",
-             "toy_construct_k1000_reference.npz"]
+             "toy_construct_k1000_reference.npz", "toy_train_steps_f32_reference.npz"]
     present = [n for n in names if os.path.exists(os.path.join(gold, n))]
     if not present:
         pytest.skip("no *_reference.npz committed (the reference cannot be run in this environment)")
@@ -395,6 +421,11 @@ def test_reference_fixtures_when_present():
         assert np.array_equal(ref["W_swa"], mine["W_swa"]) and np.allclose(ref["s"], mine["s"][:3], rtol=1e-8)
         sign = np.sign(np.sum(ref["P"] * mine["P"], axis=0))
         assert np.allclose(ref["P"] * sign, mine["P"], rtol=1e-4, atol=1e-10)
+    if names[4] in present:   # the all-Float32 pass: sgemm / mean sum in the BLAS's and Julia's order, not NumPy's
+        ref, mine = np.load(os.path.join(gold, names[4])), np.load(os.path.join(gold, "toy_train_steps_f32.npz"))
+        for name in ("descent", "momentum", "adam"):
+            assert np.allclose(ref[name + "_loss"], mine[name + "_loss"], rtol=1e-5)
+            assert np.allclose(ref[name + "_w"], mine[name + "_w"], rtol=0, atol=5e-6)
     if names[2] in present:
         ref, mine = np.load(os.path.join(gold, names[2])), np.load(os.path.join(gold, "toy_train_steps.npz"))
         for name in ("descent", "momentum", "adam"):
