@@ -201,8 +201,10 @@ int32_t si_construct_get_A(si_ctx* ctx, int64_t k0, int64_t nk, double* A_out);
  * SI_F32 (Dense chains; Conv chains are refused) = the measured fp32 option of SURVEY section 0 Q6 / 8(b),(d): X is rounded to
  *   fp32 once, W_swa + P*z is formed in fp64 and rounded to fp32 once per evaluation, every Dense layer multiplies and
  *   accumulates in fp32 (v_mfma_f32_32x32x2_f32) with fp32 activations; a narrow last layer (out <= 4), its bias /
- *   activation and the sum of squared errors are fp64.  It applies to si_logdensity, si_forward and the RWMH samplers
- *   (si_sample_rwmh*, si_rwmh_*); si_logdensity_grad and si_predict keep computing in fp64, and the output map
+ *   activation and the sum of squared errors are fp64.  It applies to si_logdensity, si_forward, the RWMH samplers
+ *   (si_sample_rwmh*, si_rwmh_*) and -- since round 5 -- si_logdensity_grad (the fp32 forward with kept activations and the
+ *   fp32 reverse sweep of the training step; the pull-back P' g and the optional prior term in fp64: grad rtol 2e-5 of its
+ *   scale against the fp64 oracle, tests/test_gpu_f32.py); si_predict keeps computing in fp64, and the output map
  *   (si_sample_rwmh_weights, si_reconstruct) delivers the fp64 W_swa + P*z.  Stated tolerance (tests/test_gpu_f32.py,
  *   against the fp64 oracle): model outputs 2e-5 of their scale, lp rtol 1e-5 (north_star: 1e-4); at BASELINE cfg2 the
  *   measured lp difference is rtol 2e-8 or better and none of 1000 accept decisions changes.                                       */

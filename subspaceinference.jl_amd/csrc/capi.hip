@@ -150,6 +150,11 @@ static void free_infer(Ctx* c) {
   dev_free(c->d_rspart);
   dev_free(c->d_ptgpart);
   dev_free(c->d_gz);
+  if (c->g_ws32) {
+    sweep_f32_free(*c->g_ws32);
+    delete c->g_ws32;
+    c->g_ws32 = nullptr;
+  }
   c->g_ready = false;
   c->fuse_tail = false;
   dev_free(c->d_Xc);
@@ -1638,6 +1643,22 @@ static int32_t ensure_grad(si_ctx* ctx) {
     ctx->g_ready = true;
     return SI_OK;
   }
+  if (ctx->f32) {   // compute_dtype = SI_F32: the fp32 forward + reverse sweep (kernels_bwd_f32.hip), P' g in fp64
+    ctx->g_ws32 = new SweepF32Ws();
+    const bool ok32 = sweep_f32_alloc(ctx, *ctx->g_ws32, ctx->layers.data(), (int)ctx->layers.size(), ctx->fuse_tail, ctx->iN, ctx->in_dim,
+                                      ctx->out_dim, B) &&
+                      dev_alloc(&ctx->d_gw, (size_t)pad_ld(ctx->iN)) == hipSuccess &&
+                      dev_alloc(&ctx->d_ptgpart, (size_t)ptg_blocks() * ctx->iM) == hipSuccess && dev_alloc(&ctx->d_gz, (size_t)ctx->iM) == hipSuccess;
+    if (!ok32) {
+      sweep_f32_free(*ctx->g_ws32);
+      delete ctx->g_ws32;
+      ctx->g_ws32 = nullptr;
+      dev_free(ctx->d_gw); dev_free(ctx->d_ptgpart); dev_free(ctx->d_gz);
+      return fail(ctx, SI_ERR_NOMEM, "si_logdensity_grad: workspace allocation failed");
+    }
+    ctx->g_ready = true;
+    return SI_OK;
+  }
   int64_t maxw = 1;
   size_t maxpart = 1;
   ctx->d_hs.assign(ctx->layers.size(), nullptr);
@@ -1681,10 +1702,31 @@ int32_t si_logdensity_grad(si_ctx* ctx, const double* z, double* lp_out, double*
   SI_HIP(ctx, hipMemcpyAsync(ctx->d_zprop, z, (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   {
     ProfScope ps(ctx, SI_K_RECON, 2.0 * (double)N * M, (double)N * (M + 2) * 8.0);
-    launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, ctx->d_zprop, 1, ctx->d_w, pad_ld(N), ctx->num_cu);
+    launch_reconstruct(ctx->stream, ctx->i_swa, ctx->i_P, ctx->ldP, N, M, ctx->d_zprop, 1, ctx->d_w, pad_ld(N), ctx->num_cu,
+                       ctx->f32 ? ctx->d_w32 : nullptr, pad_ld(N));
   }
   const bool prior = ctx->sigma_p > 0.0;
   if (prior) launch_sse(ctx->stream, ctx->d_w, nullptr, N, ctx->d_wsqpart, ctx->wsq_blocks, ctx->d_wsq, 1, pad_ld(N));
+  if (ctx->f32) {
+    // compute_dtype = SI_F32: value and gradient on the fp32 density's own arithmetic (fp32 operands and activations, fp64 head
+    // partials / SSE / batch sums; W_swa + P z rounded once), the pull-back P' g and the optional prior term in fp64
+    const int64_t d = (int64_t)ctx->out_dim * B;
+    DenseSweepF32 sw{ctx->layers.data(), nl, ctx->fuse_tail, ctx->d_w32, ctx->d_w, ctx->d_X32, ctx->d_Y, ctx->g_ws32, ctx->d_part,
+                     ctx->d_ssepart, ctx->d_sse, ctx->sse_blocks, B, N, 1.0 / s2};   // d lp / d yhat = (y - yhat) / sigma^2
+    if ((rc = dense_value_and_grad_f32(ctx, ctx->stream, sw)) != SI_OK) return rc;
+    launch_widen_f32_to_f64(ctx->stream, ctx->g_ws32->gw32, N, ctx->d_gw, ctx->num_cu);
+    if (prior) launch_prior_grad(ctx->stream, ctx->d_gw, ctx->d_w, N, 1.0 / (ctx->sigma_p * ctx->sigma_p), ctx->num_cu);
+    launch_ptg(ctx->stream, ctx->i_P, ctx->ldP, N, M, ctx->d_gw, ctx->d_ptgpart, ctx->d_gz);
+    SI_HIP(ctx, hipGetLastError());
+    double sse = 0.0, wsq = 0.0;
+    SI_HIP(ctx, hipMemcpyAsync(&sse, ctx->d_sse, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SI_HIP(ctx, hipMemcpyAsync(grad_out, ctx->d_gz, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (prior) SI_HIP(ctx, hipMemcpyAsync(&wsq, ctx->d_wsq, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *lp_out = mvnormal_c0((double)d, ctx->sigma_m) - (sse / s2) / 2.0;
+    if (prior) *lp_out += prior_c0(ctx) - (wsq / (ctx->sigma_p * ctx->sigma_p)) / 2.0;
+    return SI_OK;
+  }
   if (ctx->plan.has_conv) {
     // generic path: forward with every output kept, d lp / d yhat = (y - yhat) / sigma^2, reverse sweep, P' g_w
     const NetPlan& p = ctx->plan;

@@ -110,9 +110,12 @@ void free_train(Ctx* c) {
   release(t->rspart); release(t->ssepart); release(t->sse); release(t->part); release(t->Xc); release(t->wpack);
   release(t->scratch.bwpart); release(t->scratch.rspart); release(t->scratch.wt); release(t->scratch.dbtmp);
   for (auto& h : t->hs) release(h);
-  for (auto& h : t->hs32) release(h);
-  release(t->X32); release(t->Xb32); release(t->delta32[0]); release(t->delta32[1]); release(t->gw32); release(t->wt32);
-  release(t->zero32); release(t->part32); release(t->rspart64); release(t->tailpart64); release(t->yhat64);
+  release(t->X32); release(t->Xb32);
+  if (t->ws32) {
+    sweep_f32_free(*t->ws32);
+    delete t->ws32;
+    t->ws32 = nullptr;
+  }
   for (auto& h : t->pidx) release(h);
   for (int b = 0; b < 2; ++b) {
     if (t->idx_pin[b]) (void)hipHostFree(t->idx_pin[b]);
@@ -120,6 +123,106 @@ void free_train(Ctx* c) {
   }
   delete t;
   c->train = nullptr;
+}
+
+// ---- the fp32 forward + reverse sweep shared by the training step and si_logdensity_grad (compute_dtype = SI_F32) --------------
+void sweep_f32_free(SweepF32Ws& ws) {
+  for (auto& h : ws.hs32) release(h);
+  ws.hs32.clear();
+  release(ws.delta32[0]); release(ws.delta32[1]); release(ws.gw32); release(ws.wt32); release(ws.zero32); release(ws.part32);
+  release(ws.rspart64); release(ws.tailpart64); release(ws.yhat64);
+}
+bool sweep_f32_alloc(Ctx* ctx, SweepF32Ws& ws, const si_layer* layers, int L, bool fuse_tail, int64_t N, int32_t in_dim, int32_t out_dim,
+                     int64_t Bmax) {
+  size_t maxpart32 = 1, maxwt = 1, maxin = (size_t)in_dim, maxw = 1;
+  for (int l = 0; l < L; ++l) {
+    maxpart32 = std::max(maxpart32, backward_weight_f32_part_elems(layers[l].out, layers[l].in, Bmax, ctx->num_cu));
+    maxwt = std::max(maxwt, (size_t)layers[l].out * (size_t)layers[l].in);
+    maxin = std::max(maxin, (size_t)layers[l].in);
+    maxw = std::max(maxw, (size_t)layers[l].out);
+  }
+  const size_t wide = std::max(maxin, maxw);
+  ws.hs32.assign((size_t)L, nullptr);
+  bool ok = alloc(&ws.delta32[0], maxw * (size_t)Bmax) && alloc(&ws.delta32[1], maxw * (size_t)Bmax) && alloc(&ws.gw32, (size_t)pad_ld(N)) &&
+            alloc(&ws.wt32, maxwt) && alloc(&ws.zero32, wide) && alloc(&ws.part32, maxpart32) &&
+            alloc(&ws.rspart64, rowsum_f32_part_elems((int)wide)) && alloc(&ws.yhat64, (size_t)out_dim * (size_t)Bmax) &&
+            (!fuse_tail || alloc(&ws.tailpart64, tail_bwd_f32_part_elems(layers[L - 1].out, layers[L - 1].in)));
+  for (int l = 0; l < L && ok; ++l)   // (a fused head's own output lives in yhat64)
+    if (!(fuse_tail && l == L - 1)) ok = alloc(&ws.hs32[(size_t)l], (size_t)layers[l].out * (size_t)Bmax);
+  if (ok) ok = hipMemsetAsync(ws.zero32, 0, wide * sizeof(float), ctx->stream) == hipSuccess;
+  if (!ok) sweep_f32_free(ws);
+  return ok;
+}
+
+int32_t dense_value_and_grad_f32(Ctx* ctx, hipStream_t st, const DenseSweepF32& s) {
+  SweepF32Ws& ws = *s.ws;
+  const size_t nl = s.nl;
+  const int64_t nb = s.B;
+  const float* w = s.w32;
+  const float* h = s.X32;
+  const size_t nplain = s.fuse_tail ? nl - 2 : nl;
+  for (size_t l = 0; l < nplain; ++l) {
+    const si_layer& ly = s.layers[l];
+    ProfScope ps(ctx, SI_K_DENSE, 2.0 * (double)ly.in * ly.out * (double)nb, 0.0);
+    launch_dense_f32(st, w + ly.w_off, w + ly.b_off, h, ws.hs32[l], ly.out, ly.in, nb, ly.act);
+    h = ws.hs32[l];
+  }
+  const si_layer& ll = s.layers[nl - 1];
+  const int64_t d = (int64_t)ll.out * nb;
+  if (s.fuse_tail) {
+    const si_layer& ly = s.layers[nl - 2];
+    const int slots = dense_f32_fused_slots(ly.out, ly.in, ly.w_off % 4 == 0);
+    {
+      ProfScope ps(ctx, SI_K_DENSE, 2.0 * ((double)ly.in * ly.out + (double)ll.in * ll.out) * (double)nb, 0.0);
+      launch_dense_f32_fused(st, w + ly.w_off, w + ly.b_off, h, ly.out, ly.in, nb, ly.act, w + ll.w_off, ll.out, s.part, ChainBatch(),
+                             ws.hs32[nl - 2]);
+    }
+    launch_tail_sse(st, s.part, slots, ll.out, nb, s.w64 + ll.b_off, ll.act, s.Y, ws.yhat64, s.ssepart, s.sse_blocks);
+    launch_sse_final(st, s.ssepart, s.sse_blocks, s.sse);
+  } else {
+    launch_sse_f32(st, h, s.Y, d, s.ssepart, s.sse_blocks, s.sse);
+  }
+  double bflops = 0.0;
+  for (size_t l = 0; l < nl; ++l) bflops += 4.0 * (double)s.layers[l].in * s.layers[l].out * (double)nb;
+  ProfScope ps(ctx, SI_K_BACKWARD, bflops, 0.0);
+  SI_HIP(ctx, hipMemsetAsync(ws.gw32, 0, (size_t)pad_ld(s.N) * sizeof(float), st));
+  int cur = 0;
+  launch_delta_out_f32(st, s.Y, s.fuse_tail ? ws.yhat64 : nullptr, s.fuse_tail ? nullptr : h, d, s.scale, ll.act, ws.delta32[cur]);
+  size_t top = nl;
+  bool have_db = false;   // db of layer top-1 already produced (by the pass that formed its Delta)
+  if (s.fuse_tail) {
+    const si_layer& lp = s.layers[nl - 2];
+    launch_mul_dact_rowsum_f32(st, ws.delta32[cur], nullptr, ll.out, nb, SI_ACT_IDENTITY, nullptr, ws.rspart64, ws.gw32 + ll.b_off);
+    launch_tail_bwd_f32(st, w + ll.w_off, ws.delta32[cur], ws.hs32[nl - 2], ll.out, ll.in, nb, lp.act, ws.delta32[cur ^ 1], ws.tailpart64,
+                        ws.gw32 + ll.w_off, ws.gw32 + lp.b_off);
+    cur ^= 1;
+    top = nl - 1;
+    have_db = true;
+  }
+  for (size_t li = top; li-- > 0;) {
+    const si_layer& ly = s.layers[li];
+    const float* hprev = li > 0 ? ws.hs32[li - 1] : s.X32;
+    launch_backward_weight_f32(st, ws.delta32[cur], hprev, ws.part32, ly.out, ly.in, nb, ctx->num_cu, ws.gw32 + ly.w_off);
+    if (!have_db)
+      launch_mul_dact_rowsum_f32(st, ws.delta32[cur], nullptr, ly.out, nb, SI_ACT_IDENTITY, nullptr, ws.rspart64, ws.gw32 + ly.b_off);
+    if (li > 0) {
+      // Delta_{l-1} = (W_l' Delta_l) .* act'(H_{l-1}): the forward kernel on W_l' (out' = in, in' = out, zero bias), then one
+      // elementwise pass that also sums the rows (db of layer l-1)
+      const si_layer& lq = s.layers[li - 1];
+      launch_transpose_f32(st, w + ly.w_off, ly.out, ly.in, ws.wt32);
+      launch_dense_f32(st, ws.wt32, ws.zero32, ws.delta32[cur], ws.delta32[cur ^ 1], ly.in, ly.out, nb, SI_ACT_IDENTITY);
+      launch_mul_dact_rowsum_f32(st, ws.delta32[cur ^ 1], ws.hs32[li - 1], ly.in, nb, lq.act, ws.delta32[cur ^ 1], ws.rspart64,
+                                 ws.gw32 + lq.b_off);
+      cur ^= 1;
+      have_db = true;
+    }
+  }
+  SI_HIP(ctx, hipGetLastError());
+  return SI_OK;
+}
+
+void launch_widen_f32_to_f64(hipStream_t st, const float* src, int64_t n, double* dst, int num_cu) {
+  hipLaunchKernelGGL(widen_kernel, dim3(grid_for(n, num_cu)), dim3(256), 0, st, src, n, dst);
 }
 
 }  // namespace si
@@ -173,7 +276,6 @@ static int32_t train_setup_impl(si_ctx* ctx, const si_layer* layers, int32_t L, 
   if (f32 && fuse_tail)   // (w32 is 256-byte aligned: a layer's W is 16-byte aligned iff w_off % 4 == 0)
     t->fuse_slots = std::max(t->fuse_slots, dense_f32_fused_slots(layers[L - 2].out, layers[L - 2].in, layers[L - 2].w_off % 4 == 0));
   t->hs.assign((size_t)L, nullptr);
-  t->hs32.assign((size_t)L, nullptr);
   t->plan = plan;
   size_t nb = 1, nr = 1, nw = 1, nd = 1;
   if (plan.has_conv) net_scratch_sizes(plan, batch_max, ctx->num_cu, &nb, &nr, &nw, &nd);
@@ -195,21 +297,9 @@ static int32_t train_setup_impl(si_ctx* ctx, const si_layer* layers, int32_t L, 
             (!fuse_tail || alloc(&t->part, (size_t)t->fuse_slots * out_dim * batch_max));
   t->pidx.assign((size_t)L, nullptr);
   if (f32 && ok) {
-    size_t maxpart32 = 1, maxwt = 1, maxin = (size_t)in_dim;
-    for (int l = 0; l < L; ++l) {
-      maxpart32 = std::max(maxpart32, backward_weight_f32_part_elems(layers[l].out, layers[l].in, batch_max, ctx->num_cu));
-      maxwt = std::max(maxwt, (size_t)layers[l].out * (size_t)layers[l].in);
-      maxin = std::max(maxin, (size_t)layers[l].in);
-    }
+    t->ws32 = new SweepF32Ws();
     ok = alloc(&t->X32, (size_t)in_dim * B_total) && alloc(&t->Xb32, (size_t)in_dim * batch_max) &&
-         alloc(&t->delta32[0], (size_t)maxw * batch_max) && alloc(&t->delta32[1], (size_t)maxw * batch_max) &&
-         alloc(&t->gw32, (size_t)pad_ld(N)) && alloc(&t->wt32, maxwt) && alloc(&t->zero32, std::max(maxin, (size_t)maxw)) &&
-         alloc(&t->part32, maxpart32) && alloc(&t->rspart64, rowsum_f32_part_elems((int)std::max<size_t>(maxin, (size_t)maxw))) &&
-         alloc(&t->yhat64, (size_t)out_dim * batch_max) &&
-         (!fuse_tail || alloc(&t->tailpart64, tail_bwd_f32_part_elems(layers[L - 1].out, layers[L - 1].in)));
-    for (int l = 0; l < L && ok; ++l)   // (the head's own output lives in yhat64)
-      if (!(fuse_tail && l == L - 1)) ok = alloc(&t->hs32[(size_t)l], (size_t)layers[l].out * batch_max);
-    if (ok) SI_HIP(ctx, hipMemsetAsync(t->zero32, 0, std::max(maxin, (size_t)maxw) * sizeof(float), ctx->stream));
+         sweep_f32_alloc(ctx, *t->ws32, layers, L, fuse_tail, N, in_dim, out_dim, batch_max);
   }
   for (int l = 0; l < L && ok && !f32; ++l) {
     if (plan.has_conv && net_grad_fused(plan, (size_t)l))   // Conv + MaxPool as one kernel: a byte index instead of the activation
@@ -335,69 +425,13 @@ static int32_t train_gradient(si_ctx* ctx, const char* who, const int64_t* idx, 
     // ---- the step in the caller's precision: a Float32 model on Float32 data is a Float32 Zygote pass in the reference
     // (src/subspace_construction.jl:39-43).  fp32 operands and activations on v_mfma_f32_32x32x2_f32; fp64 for the head's
     // partial sums, the loss and every sum over the batch (rounded once into the Float32 gradient).
-    const float* w = t->w32;
-    const float* h = Xb32;
-    const size_t nplain = t->fuse_tail ? nl - 2 : nl;
-    for (size_t l = 0; l < nplain; ++l) {
-      const si_layer& ly = t->layers[l];
-      ProfScope ps(ctx, SI_K_DENSE, 2.0 * (double)ly.in * ly.out * (double)nb, 0.0);
-      launch_dense_f32(st, w + ly.w_off, w + ly.b_off, h, t->hs32[l], ly.out, ly.in, nb, ly.act);
-      h = t->hs32[l];
-    }
     const int64_t d = (int64_t)t->out_dim * nb;
-    const int sse_blocks = sse_num_blocks(d, ctx->num_cu);
-    const si_layer& ll = t->layers[nl - 1];
-    if (t->fuse_tail) {
-      const si_layer& ly = t->layers[nl - 2];
-      const int slots = dense_f32_fused_slots(ly.out, ly.in, ly.w_off % 4 == 0);
-      {
-        ProfScope ps(ctx, SI_K_DENSE, 2.0 * ((double)ly.in * ly.out + (double)ll.in * ll.out) * (double)nb, 0.0);
-        launch_dense_f32_fused(st, w + ly.w_off, w + ly.b_off, h, ly.out, ly.in, nb, ly.act, w + ll.w_off, ll.out, t->part, ChainBatch(),
-                               t->hs32[nl - 2]);
-      }
-      launch_tail_sse(st, t->part, slots, ll.out, nb, t->w64 + ll.b_off, ll.act, Yb, t->yhat64, t->ssepart, sse_blocks);
-      launch_sse_final(st, t->ssepart, sse_blocks, t->sse);
-    } else {
-      launch_sse_f32(st, h, Yb, d, t->ssepart, sse_blocks, t->sse);
-    }
-    double bflops = 0.0;
-    for (const auto& ly : t->layers) bflops += 4.0 * (double)ly.in * ly.out * (double)nb;
-    ProfScope ps(ctx, SI_K_BACKWARD, bflops, 0.0);
-    SI_HIP(ctx, hipMemsetAsync(t->gw32, 0, (size_t)pad_ld(N) * sizeof(float), st));
-    int cur = 0;
-    // d mse / d yhat = 2 (yhat - y) / d, times act_L'
-    launch_delta_out_f32(st, Yb, t->fuse_tail ? t->yhat64 : nullptr, t->fuse_tail ? nullptr : h, d, -2.0 / d_total, ll.act, t->delta32[cur]);
-    size_t top = nl;
-    bool have_db = false;   // db of layer top-1 already produced (by the pass that formed its Delta)
-    if (t->fuse_tail) {
-      const si_layer& lp = t->layers[nl - 2];
-      launch_mul_dact_rowsum_f32(st, t->delta32[cur], nullptr, ll.out, nb, SI_ACT_IDENTITY, nullptr, t->rspart64, t->gw32 + ll.b_off);
-      launch_tail_bwd_f32(st, w + ll.w_off, t->delta32[cur], t->hs32[nl - 2], ll.out, ll.in, nb, lp.act, t->delta32[cur ^ 1], t->tailpart64,
-                          t->gw32 + ll.w_off, t->gw32 + lp.b_off);
-      cur ^= 1;
-      top = nl - 1;
-      have_db = true;
-    }
-    for (size_t li = top; li-- > 0;) {
-      const si_layer& ly = t->layers[li];
-      const float* hprev = li > 0 ? t->hs32[li - 1] : Xb32;
-      launch_backward_weight_f32(st, t->delta32[cur], hprev, t->part32, ly.out, ly.in, nb, ctx->num_cu, t->gw32 + ly.w_off);
-      if (!have_db)
-        launch_mul_dact_rowsum_f32(st, t->delta32[cur], nullptr, ly.out, nb, SI_ACT_IDENTITY, nullptr, t->rspart64, t->gw32 + ly.b_off);
-      if (li > 0) {
-        // Delta_{l-1} = (W_l' Delta_l) .* act'(H_{l-1}): the forward kernel on W_l' (out' = in, in' = out, zero bias), then one
-        // elementwise pass that also sums the rows (db of layer l-1)
-        const si_layer& lq = t->layers[li - 1];
-        launch_transpose_f32(st, w + ly.w_off, ly.out, ly.in, t->wt32);
-        launch_dense_f32(st, t->wt32, t->zero32, t->delta32[cur], t->delta32[cur ^ 1], ly.in, ly.out, nb, SI_ACT_IDENTITY);
-        launch_mul_dact_rowsum_f32(st, t->delta32[cur ^ 1], t->hs32[li - 1], ly.in, nb, lq.act, t->delta32[cur ^ 1], t->rspart64,
-                                   t->gw32 + lq.b_off);
-        cur ^= 1;
-        have_db = true;
-      }
-    }
+    DenseSweepF32 sw{t->layers.data(), nl, t->fuse_tail, t->w32, t->w64, Xb32, Yb, t->ws32, t->part, t->ssepart, t->sse,
+                     sse_num_blocks(d, ctx->num_cu), nb, N, -2.0 / d_total};   // d mse / d yhat = 2 (yhat - y) / d
+    const int32_t rcs = dense_value_and_grad_f32(ctx, st, sw);
+    if (rcs != SI_OK) return rcs;
     // the gradient as the optimiser and the data-parallel all-reduce see it: fp64 words holding the Float32 values
-    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(N, ctx->num_cu)), dim3(256), 0, st, t->gw32, N, t->gw);
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(N, ctx->num_cu)), dim3(256), 0, st, t->ws32->gw32, N, t->gw);
     SI_HIP(ctx, hipGetLastError());
     t->grad_ready = true;
     return SI_OK;

@@ -99,10 +99,7 @@ struct TrainState {
   // fp32 data, activations, deltas and gradient; fp64 only for the loss, the head's partial sums and the sums over the batch
   bool f32 = false;
   float *X32 = nullptr, *Xb32 = nullptr;
-  std::vector<float*> hs32;          // kept outputs of the stored layers
-  float* delta32[2] = {nullptr, nullptr};
-  float *gw32 = nullptr, *wt32 = nullptr, *zero32 = nullptr, *part32 = nullptr;   // gradient, a layer's W transposed, a zero bias, dW split partials
-  double *rspart64 = nullptr, *tailpart64 = nullptr, *yhat64 = nullptr;
+  struct SweepF32Ws* ws32 = nullptr;   // kept outputs, deltas, gradient, scratch of the fp32 sweep
   // chains with Conv / MaxPool / flatten layers (generic path, capi_net.hip)
   NetPlan plan;
   double *Xc = nullptr, *wpack = nullptr;
@@ -235,6 +232,7 @@ struct Ctx {
   double* d_rspart = nullptr;  // row-sum partials
   double* d_ptgpart = nullptr;
   double* d_gz = nullptr;
+  struct SweepF32Ws* g_ws32 = nullptr;   // compute_dtype = SI_F32: the fp32 sweep's workspace (si_logdensity_grad)
   // chains with Conv / MaxPool / flatten layers (generic path, capi_net.hip)
   NetPlan plan;
   double* d_Xc = nullptr;      // X re-laid channel-fastest (input_spatial)
@@ -406,6 +404,36 @@ struct DenseSweep {
   int64_t B;
 };
 int32_t dense_reverse_sweep(Ctx* ctx, hipStream_t st, const DenseSweep& s);
+// The same in fp32 together with the forward pass (capi_train.hip; kernels_gemm_f32.hip + kernels_bwd_f32.hip): forward with every
+// layer's output kept, the SSE (fp64), Delta_L = scale * (y - yhat) * act_L'(yhat), reverse sweep; on return gw32 holds
+// d (scale/2 * -SSE) / dw rounded to fp32 and *sse the sum of squared errors.  Shared by the training step and si_logdensity_grad
+// with compute_dtype = SI_F32.
+struct SweepF32Ws {   // workspace of one sweep at up to Bmax observations (sweep_f32_alloc / _free)
+  std::vector<float*> hs32;
+  float* delta32[2] = {nullptr, nullptr};
+  float *gw32 = nullptr, *wt32 = nullptr, *zero32 = nullptr, *part32 = nullptr;
+  double *rspart64 = nullptr, *tailpart64 = nullptr, *yhat64 = nullptr;
+};
+bool sweep_f32_alloc(Ctx* ctx, SweepF32Ws& ws, const si_layer* layers, int L, bool fuse_tail, int64_t N, int32_t in_dim, int32_t out_dim,
+                     int64_t Bmax);
+void sweep_f32_free(SweepF32Ws& ws);
+struct DenseSweepF32 {
+  const si_layer* layers;
+  size_t nl;
+  bool fuse_tail;
+  const float* w32;     // flat fp32 weights
+  const double* w64;    // the same in fp64 (the head's bias is added in fp64)
+  const float* X32;     // input of layer 0, in_0 x B
+  const double* Y;
+  SweepF32Ws* ws;
+  double* part;         // head partials [slots][out_last][B]
+  double *ssepart, *sse;
+  int sse_blocks;
+  int64_t B, N;
+  double scale;         // of Delta_L: -2 / d for the mse loss, 1 / sigma^2 for the log-density
+};
+int32_t dense_value_and_grad_f32(Ctx* ctx, hipStream_t st, const DenseSweepF32& s);
+void launch_widen_f32_to_f64(hipStream_t st, const float* src, int64_t n, double* dst, int num_cu);
 // dW[out x in] = Delta * Hprev' into dW, through `part` (backward_weight_part_elems doubles): split-K GEMM + fixed-order reduction;
 // db != nullptr: db[out] = rowsum(Delta) as well (inside the GEMM where the LDS-DMA kernel runs, else by launch_rowsum)
 size_t backward_weight_part_elems(int32_t out, int32_t in, int64_t B, int num_cu);

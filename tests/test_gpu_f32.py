@@ -56,10 +56,15 @@ def test_f32_forward_and_lp_vs_fp64_oracle(si, gpu_ctx, dims, acts, b):
     # chain-batched evaluation (grid.y) == one at a time, bit for bit
     one = np.array([gpu_ctx.logdensity(z[:, c:c + 1])[0] for c in range(3)])
     assert np.array_equal(one, lp)
-    # the gradient and the predictive forward stay in fp64 in this mode (documented): they match the fp64 oracle tightly
+    # the gradient runs on the same fp32 arithmetic since round 5 (fp32 forward with kept activations + the fp32 reverse sweep of
+    # the training step, P' g in fp64): its lp IS the fp32 density's, the gradient within fp32 rounding of the fp64 oracle's
+    # (measured <= 4e-6 of its scale over these cases); the predictive forward stays fp64 (documented)
     lpg, g = gpu_ctx.logdensity_grad(z[:, 0])
     lp_ref, g_ref, _ = so.logdensity_grad(table, w, p, x, y, 0.7, z[:, 0])
-    assert abs(lpg - lp_ref) <= 1e-10 * abs(lp_ref) and np.allclose(g, g_ref, rtol=1e-7, atol=1e-9 * np.max(np.abs(g_ref)))
+    gerr = np.max(np.abs(g - g_ref)) / np.max(np.abs(g_ref))
+    print("f32 gradient %s B=%d: max |g - g_ref| / max |g_ref| = %.2e, lp rel %.2e" % (dims, b, gerr, abs(lpg - lp_ref) / abs(lp_ref)))
+    assert abs(lpg - lp_ref) <= 1e-5 * abs(lp_ref) and gerr <= 2e-5
+    assert abs(lpg - lp[0]) <= 1e-9 * abs(lp[0])
     xn = np.random.default_rng(2).standard_normal((dims[0], 37))
     yp = gpu_ctx.predict(z[:, :2], xn)
     assert np.allclose(yp[:, :, 1], so.forward(table, w + p @ z[:, 1], xn), rtol=1e-9, atol=1e-12)
