@@ -16,6 +16,8 @@ ARCH = "gfx950"
 # three rounded operations.
 SOURCES = [
     ("capi.hip", []),
+    ("capi_infer.hip", []),
+    ("capi_sample.hip", []),
     ("capi_train.hip", []),
     ("comm.hip", []),
     ("host_copy.cpp", []),
@@ -41,7 +43,7 @@ SOURCES = [
     ("eig.cpp", ["-DSI_EIG_NS=avx512", "-mavx512f", "-mavx512vl", "-mavx512dq", "-mfma"], "eig_avx512"),
     ("eig_dispatch.cpp", []),
 ]
-HEADERS = ["si_internal.h", "philox.h", "kernels_gemm.h", "gemm_pipeline.h", "chain_common.h", os.path.join("..", "..", "include", "subspace_hip.h")]
+HEADERS = ["si_internal.h", "philox.h", "kernels_gemm.h", "gemm_pipeline.h", "chain_common.h", "capi_common.h", os.path.join("..", "..", "include", "subspace_hip.h")]
 
 
 def _hipcc():

@@ -1,7 +1,7 @@
 // Host side of chains that contain Conv / MaxPool / flatten layers: validation of the caller's layer
 // table, the geometry every kernel launch needs, and the generic forward pass / reverse sweep over such a chain.
 // The reference's `model_re` restructures ANY Flux Chain (src/libs.jl:55-57) and `density` evaluates it on the full data
-// (src/space_inference.jl:94); pure Dense chains keep their tuned path in capi.hip / capi_train.hip (fused narrow tail,
+// (src/space_inference.jl:94); pure Dense chains keep their tuned path in capi_infer.hip / capi_train.hip (fused narrow tail,
 // chain batching) and only pass through net_plan() for validation.  No arithmetic happens on the host.
 #include <algorithm>
 

@@ -2,7 +2,7 @@
 // all `itr` transitions of reference src/space_inference.jl:111-116 (AdvancedMH RWMH: propose -> density -> accept) in ONE
 // launch, with the reconstructed weights, the data, the activations and the head partials of its chain in LDS.
 //
-// Why: the launch-per-step path (capi.hip sample_rwmh_impl) pays ~8 dependent kernel launches per transition; for the only
+// Why: the launch-per-step path (capi_sample.hip sample_rwmh_impl) pays ~8 dependent kernel launches per transition; for the only
 // workloads the reference documents (README.md:52-79: N = 682, M = 3, B = 100) that is 25 us of launch latency around
 // ~1 us of arithmetic (profiles/r03_small_model_steps.log; a hipGraph replay did not help: the kernels are DEPENDENT).
 //

@@ -387,7 +387,7 @@ void launch_sse(hipStream_t st, const double* yhat, const double* y, int64_t d, 
 // backward pass (kernels_bwd.hip): gradient of the log-density w.r.t. the flat weights and its pull-back P' g
 void launch_backward_data(hipStream_t st, const double* W, const double* Delta, const double* Hprev, double* DeltaPrev,
                           int32_t out, int32_t in, int64_t B, int32_t act_prev);
-// Reverse sweep through a Dense chain shared by si_logdensity_grad (capi.hip) and the training step (capi_train.hip).
+// Reverse sweep through a Dense chain shared by si_logdensity_grad (capi_infer.hip) and the training step (capi_train.hip).
 // On entry delta[0] holds Delta_L (launch_delta_out) and gw is zeroed, both on `st`; on return every dW / db of the
 // chain is in gw.
 struct DenseSweep {

@@ -236,7 +236,7 @@ def test_forward_and_logdensity(gpu_ctx, dims, acts, b, m):
     ([3, 100, 97, 2], [1, 2, 3], 130, 4),                 # odd widths: scalar staging with slot strides
 ])
 def test_chain_batched_density_is_bit_identical(gpu_ctx, dims, acts, b, m):
-    """Independent chains stacked in grid.y of ONE forward pass (capi.hip eval_density, ChainBatch) give exactly the
+    """Independent chains stacked in grid.y of ONE forward pass (capi_infer.hip eval_density, ChainBatch) give exactly the
     bits of one-chain-at-a-time evaluation, and agree with the oracle."""
     table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=11 + sum(dims))
     gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, sigma_m=0.9)
@@ -262,7 +262,7 @@ def test_chain_batched_density_is_bit_identical(gpu_ctx, dims, acts, b, m):
 
 
 def test_chain_batching_respects_the_workspace_cap(gpu_ctx):
-    """A model whose forward workspace is ~0.5 GB per chain gets 4 slots under the 2 GiB cap (capi.hip batch_width):
+    """A model whose forward workspace is ~0.5 GB per chain gets 4 slots under the 2 GiB cap (capi_infer.hip batch_width):
     6 chains run as a batch of 4 and a batch of 2, with the bits of one-at-a-time evaluation."""
     dims, acts, b, m = [16, 256, 256, 1], [1, 1, 0], 120000, 3
     table, n, w_swa, p, x, y = _random_problem(dims, acts, b, m, seed=77)

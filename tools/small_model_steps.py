@@ -30,7 +30,7 @@ for name, dims, acts, b, m in (("README toy", [10, 20, 20, 2], [0, 0, 0], 100, 3
     z, lp, acc = ctx.sample_rwmh(itr, 0.1, seed=1)
     dt = time.perf_counter() - t0
     print("%-16s N=%6d B=%5d: %.1f us per step, %.0f samples/s, accept %.2f, lp[-1]=%.3f" % (name, n, b, dt / itr * 1e6, itr / dt, acc[0], lp[-1, 0]))
-    # independent chains stacked in grid.y of every launch (capi.hip eval_density / ChainBatch)
+    # independent chains stacked in grid.y of every launch (capi_infer.hip eval_density / ChainBatch)
     for nch in (8, 64, 512):
         ctx.sample_rwmh(20, 0.1, seed=1, nchains=nch)
         itc = 500
