@@ -673,6 +673,28 @@ def run_chains(args, rk, real_stdout):
                                          "numbers beside it are what Float64 data get (unchanged)")
         del x32, y32
         ctx.set_profiling(False)
+        # the reference's own worked example (docs/src/nn_example.md:112-118,188-194: 2-200-50-50-50-1 on 1000 observations):
+        # the persistent grid loop for one chain, the one-launch density stacked over 512 chains
+        nd, na, nb_obs = [2, 200, 50, 50, 50, 1], [1, 1, 1, 1, 0], 1000
+        ntab, noff = [], 0
+        for fin, fout, act in zip(nd[:-1], nd[1:], na):
+            ntab.append((fin, fout, act, noff, noff + fin * fout))
+            noff += fin * fout + fout
+        nrng = np.random.default_rng(0)
+        with si.Context(rk.local_rank) as nctx:
+            nctx.infer_setup(ntab, noff, 20, 0.3 * nrng.standard_normal(noff), 0.05 * nrng.standard_normal((noff, 20)),
+                             nrng.standard_normal((2, nb_obs)), nrng.standard_normal((1, nb_obs)), 1.0)
+            nctx.sample_rwmh(50, 0.1, seed=1)
+            t0 = time.perf_counter()
+            nctx.sample_rwmh(2000, 0.1, seed=1)
+            extras["nn_example_us_per_transition"] = (time.perf_counter() - t0) / 2000 * 1e6
+            nctx.sample_rwmh(10, 0.1, seed=1, nchains=512)
+            t0 = time.perf_counter()
+            nctx.sample_rwmh(100, 0.1, seed=1, nchains=512)
+            extras["nn_example_512_chains_samples_per_s"] = 100 * 512 / (time.perf_counter() - t0)
+        extras["nn_example_note"] = ("docs/src/nn_example.md's MLP, N = 15801, B = 1000, M = 20 (the largest M of its sweep): one chain in the "
+                                     "persistent grid loop (63 workgroups, two grid barriers per transition); 512 chains stacked in the "
+                                     "one-launch density (csrc/kernels_chain_grid.hip); round 4: 41.0 us and 0.336 M samples/s")
 
     if rank == 0:
         dm = st["dense_main"]
