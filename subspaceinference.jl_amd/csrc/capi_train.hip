@@ -206,13 +206,16 @@ int32_t dense_value_and_grad_f32(Ctx* ctx, hipStream_t st, const DenseSweepF32& 
     if (!have_db)
       launch_mul_dact_rowsum_f32(st, ws.delta32[cur], nullptr, ly.out, nb, SI_ACT_IDENTITY, nullptr, ws.rspart64, ws.gw32 + ly.b_off);
     if (li > 0) {
-      // Delta_{l-1} = (W_l' Delta_l) .* act'(H_{l-1}): the forward kernel on W_l' (out' = in, in' = out, zero bias), then one
-      // elementwise pass that also sums the rows (db of layer l-1)
+      // Delta_{l-1} = (W_l' Delta_l) .* act'(H_{l-1}): the forward kernel on W_l' (out' = in, in' = out, zero bias) with the
+      // multiply in its store, then the row sums (db of layer l-1); shapes the LDS-DMA kernel does not take: one elementwise pass
+      // behind the GEMM does both
       const si_layer& lq = s.layers[li - 1];
       launch_transpose_f32(st, w + ly.w_off, ly.out, ly.in, ws.wt32);
-      launch_dense_f32(st, ws.wt32, ws.zero32, ws.delta32[cur], ws.delta32[cur ^ 1], ly.in, ly.out, nb, SI_ACT_IDENTITY);
-      launch_mul_dact_rowsum_f32(st, ws.delta32[cur ^ 1], ws.hs32[li - 1], ly.in, nb, lq.act, ws.delta32[cur ^ 1], ws.rspart64,
-                                 ws.gw32 + lq.b_off);
+      if (launch_dense_f32_dx(st, ws.wt32, ws.zero32, ws.delta32[cur], ws.delta32[cur ^ 1], ly.in, ly.out, nb, ws.hs32[li - 1], lq.act))
+        launch_mul_dact_rowsum_f32(st, ws.delta32[cur ^ 1], nullptr, ly.in, nb, SI_ACT_IDENTITY, nullptr, ws.rspart64, ws.gw32 + lq.b_off);
+      else
+        launch_mul_dact_rowsum_f32(st, ws.delta32[cur ^ 1], ws.hs32[li - 1], ly.in, nb, lq.act, ws.delta32[cur ^ 1], ws.rspart64,
+                                   ws.gw32 + lq.b_off);
       cur ^= 1;
       have_db = true;
     }

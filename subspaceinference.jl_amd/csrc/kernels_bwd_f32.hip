@@ -19,6 +19,7 @@
 namespace si {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_void_ptr_f;
 
 template <int N, int I = 0, class F>
@@ -247,15 +248,6 @@ void launch_transpose_f32(hipStream_t st, const float* W, int32_t out, int32_t i
   hipLaunchKernelGGL(transpose_f32_kernel, dim3((out + 31) / 32, (in + 31) / 32), dim3(256), 0, st, W, (int)out, (int)in, Wt);
 }
 
-__device__ __forceinline__ float dact_f32(float h, int act) {   // act'(x) through the output h = act(x), in the layer's precision
-  switch (act) {
-    case SI_ACT_IDENTITY: return 1.0f;
-    case SI_ACT_RELU: return h > 0.0f ? 1.0f : 0.0f;
-    case SI_ACT_TANH: return 1.0f - h * h;
-    case SI_ACT_SIGMOID: return h * (1.0f - h);
-    default: return (float)dact_extra((double)h, act);
-  }
-}
 
 // D[i + rows b] = G[i + rows b] * act'(H[i + rows b]) (in place allowed) and part[chunk][i] = sum over the chunk's columns of D
 // (fp64 partial sums, chunks summed in order by rowsum_final_f32_kernel: db of the layer below)
@@ -286,19 +278,100 @@ __global__ __launch_bounds__(256) void mul_dact_rowsum_f32_kernel(const float* _
     part[(int64_t)blockIdx.y * rows + i] = t;
   }
 }
-__global__ __launch_bounds__(256) void rowsum_final_f32_kernel(const double* __restrict__ part, int rows, float* __restrict__ db) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= rows) return;
-  double s = 0.0;
-  for (int ch = 0; ch < RSF_CHUNKS; ++ch) s += part[(int64_t)ch * rows + i];
-  db[i] = (float)s;
+// db = rowsum(G) alone (the dX GEMM's epilogue has already applied act'): 16-byte loads, four features per thread, RS4_CHUNKS
+// slices of the batch so that 2048 workgroups stream the panel
+constexpr int RS4_CHUNKS = 256;
+__global__ __launch_bounds__(256) void rowsum4_f32_kernel(const float* __restrict__ G, int rows, int64_t B, double* __restrict__ part) {
+  __shared__ double red[8][32][4];
+  const int il = threadIdx.x & 31, bl = threadIdx.x >> 5;
+  const int i = (blockIdx.x * 32 + il) * 4;
+  const int64_t per = (B + RS4_CHUNKS - 1) / RS4_CHUNKS;
+  const int64_t b0 = (int64_t)blockIdx.y * per;
+  int64_t b1 = b0 + per;
+  if (b1 > B) b1 = B;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  if (i < rows) {
+    int64_t b = b0 + bl;
+    for (; b + 24 < b1; b += 32) {   // four loads in flight
+      f4v v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f4v*>(G + i + (int64_t)rows * (b + 8 * u));
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += (double)v[u][j];
+    }
+    for (; b < b1; b += 8) {
+      const f4v v = *reinterpret_cast<const f4v*>(G + i + (int64_t)rows * b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += (double)v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[bl][il][j] = s[j];
+  __syncthreads();
+  if (bl < 4 && i < rows) {   // thread (bl, il) finishes feature i + bl
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][il][bl];
+    part[(int64_t)blockIdx.y * rows + i + bl] = t;
+  }
 }
-size_t rowsum_f32_part_elems(int max_rows) { return (size_t)RSF_CHUNKS * (size_t)max_rows; }
+// ... and of a NARROW panel (rows <= 8: the head's Delta): the threads of a workgroup run along the batch
+__global__ __launch_bounds__(256) void rowsum_narrow_f32_kernel(const float* __restrict__ G, int rows, int64_t B, double* __restrict__ part) {
+  __shared__ double red[4][8];
+  const int64_t per = (B + RSF_CHUNKS - 1) / RSF_CHUNKS;
+  const int64_t b0 = (int64_t)blockIdx.x * per;
+  int64_t b1 = b0 + per;
+  if (b1 > B) b1 = B;
+  double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int64_t b = b0 + threadIdx.x; b < b1; b += 256)
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (r < rows) s[r] += (double)G[r + (int64_t)rows * b];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s[r] += __shfl_down(s[r], off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][r] = s[r];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < rows) part[(int64_t)blockIdx.x * rows + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// db[i] = (float) sum over chunks of part[chunk][i]: 32 rows per workgroup, eight threads per row each summing every eighth
+// chunk (independent loads), the eight combined in order
+__global__ __launch_bounds__(256) void rowsum_final_f32_kernel(const double* __restrict__ part, int rows, int chunks, float* __restrict__ db) {
+  __shared__ double red[8][33];
+  const int il = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + il;
+  double s = 0.0;
+  if (i < rows)
+    for (int ch = q; ch < chunks; ch += 8) s += part[(int64_t)ch * rows + i];
+  red[q][il] = s;
+  __syncthreads();
+  if (q == 0 && i < rows) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][il];
+    db[i] = (float)t;
+  }
+}
+size_t rowsum_f32_part_elems(int max_rows) { return (size_t)RS4_CHUNKS * (size_t)max_rows; }
 // D = G .* act'(H) (H == nullptr: D = G, nothing stored when D == nullptr either) and db = rowsum(D)
 void launch_mul_dact_rowsum_f32(hipStream_t st, const float* G, const float* H, int rows, int64_t B, int act, float* D, double* part,
                                 float* db) {
+  if (H == nullptr && D == nullptr && rows % 4 == 0 && (reinterpret_cast<uintptr_t>(G) & 15u) == 0) {
+    hipLaunchKernelGGL(rowsum4_f32_kernel, dim3((rows / 4 + 31) / 32, RS4_CHUNKS), dim3(256), 0, st, G, rows, B, part);
+    hipLaunchKernelGGL(rowsum_final_f32_kernel, dim3((rows + 31) / 32), dim3(256), 0, st, part, rows, RS4_CHUNKS, db);
+    return;
+  }
+  if (H == nullptr && D == nullptr && rows <= 8) {
+    hipLaunchKernelGGL(rowsum_narrow_f32_kernel, dim3(RSF_CHUNKS), dim3(256), 0, st, G, rows, B, part);
+    hipLaunchKernelGGL(rowsum_final_f32_kernel, dim3(1), dim3(256), 0, st, part, rows, RSF_CHUNKS, db);
+    return;
+  }
   hipLaunchKernelGGL(mul_dact_rowsum_f32_kernel, dim3((rows + 31) / 32, RSF_CHUNKS), dim3(256), 0, st, G, H, rows, B, act, D, part);
-  hipLaunchKernelGGL(rowsum_final_f32_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, part, rows, db);
+  hipLaunchKernelGGL(rowsum_final_f32_kernel, dim3((rows + 31) / 32), dim3(256), 0, st, part, rows, RSF_CHUNKS, db);
 }
 
 // Delta_L[e] = (float)(scale * (Y[e] - Yhat[e]) * act_L'(Yhat[e])): the seed of the reverse sweep; Yhat in fp64 (the fused

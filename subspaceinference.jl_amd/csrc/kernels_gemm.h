@@ -48,5 +48,15 @@ __device__ __forceinline__ double dact_full(double h, int act) {
     default: return dact_extra(h, act);
   }
 }
+// the same in the layer's own precision (the fp32 reverse sweep: kernels_bwd_f32.hip and the dX epilogue of kernels_gemm_f32.hip)
+__device__ __forceinline__ float dact_f32(float h, int act) {
+  switch (act) {
+    case SI_ACT_IDENTITY: return 1.0f;
+    case SI_ACT_RELU: return h > 0.0f ? 1.0f : 0.0f;
+    case SI_ACT_TANH: return 1.0f - h * h;
+    case SI_ACT_SIGMOID: return h * (1.0f - h);
+    default: return (float)dact_extra((double)h, act);
+  }
+}
 inline bool act_is_extra(int act) { return act >= SI_ACT_LEAKYRELU; }
 }

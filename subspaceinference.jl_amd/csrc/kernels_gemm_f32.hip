@@ -91,7 +91,8 @@ template <int BM, int BN, int WM, int WN, int NB, int MINW, bool FUSE, int BK>
 __device__ __forceinline__ void dense_f32_dma_body(const float* __restrict__ W, const float* __restrict__ bias,
                                                    const float* __restrict__ Hin, float* __restrict__ Hout, int out, int in,
                                                    int64_t B, int act, int nMt, int64_t nNt, const float* __restrict__ Wlast,
-                                                   int out_last, double* __restrict__ part, const ChainBatch& cb, float* smem) {
+                                                   int out_last, double* __restrict__ part, const ChainBatch& cb,
+                                                   const float* __restrict__ Dh, int dkind, float* smem) {
   constexpr int NWAVES = WM * WN;
   constexpr int KG = BK / 8;          // groups of 8 k values (one ds_read_b128 of H per half feeds four MFMA steps)
   constexpr int SPR = BK / 4;         // 16-byte slots per H row
@@ -270,10 +271,17 @@ __device__ __forceinline__ void dense_f32_dma_body(const float* __restrict__ W, 
         for (int p = 0; p < NCH; ++p) {
           const int chunk = p * 64 + lane;
           const int row = chunk / (WI / 4), col4 = chunk % (WI / 4);
-          const f4v v = *reinterpret_cast<const f4v*>(reg + row * WI + 4 * col4);
+          f4v v = *reinterpret_cast<const f4v*>(reg + row * WI + 4 * col4);
           const int gf = iw0 + 4 * col4;
           const int64_t gb = bw0 + 32 * b + 8 * g + row;
-          if (gf < out && gb < B) *reinterpret_cast<f4v*>(Hout + gf + (int64_t)out * gb) = v;   // out % 4 == 0: all four or none
+          if (gf < out && gb < B) {   // out % 4 == 0: all four or none
+            if (Dh != nullptr) {      // reverse sweep: this GEMM is W' Delta, and what is stored is (W' Delta) .* act'(H)
+              const f4v hv = *reinterpret_cast<const f4v*>(Dh + gf + (int64_t)out * gb);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] *= dact_f32(hv[j], dkind);
+            }
+            *reinterpret_cast<f4v*>(Hout + gf + (int64_t)out * gb) = v;
+          }
         }
       }
   } else if (Hout != nullptr) {   // (the gradient / training forward keeps this layer's output: plain stores)
@@ -295,20 +303,22 @@ template <int BM, int BN, int WM, int WN, int NB, int MINW, bool FUSE, int BK = 
 __global__ __launch_bounds__(64 * WM * WN, MINW) void dense_f32_dma_kernel(
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ Hin, float* __restrict__ Hout, int out,
     int in, int64_t B, int act, int nMt, int64_t nNt, const float* __restrict__ Wlast, int out_last, double* __restrict__ part,
-    ChainBatch cb) {
+    ChainBatch cb, const float* __restrict__ Dh, int dkind) {
   if (blockIdx.y != 0) {   // chain batching: every operand that differs per chain moves by its slot stride
     const int64_t ch = blockIdx.y;
     W += ch * cb.w;
     bias += ch * cb.w;
     Hin += ch * cb.hin;
     if (Hout != nullptr) Hout += ch * cb.hout;
+    if (Dh != nullptr) Dh += ch * cb.hout;
     if constexpr (FUSE) {
       Wlast += ch * cb.w;
       part += ch * cb.part;
     }
   }
   extern __shared__ float smem_f32[];
-  dense_f32_dma_body<BM, BN, WM, WN, NB, MINW, FUSE, BK>(W, bias, Hin, Hout, out, in, B, act, nMt, nNt, Wlast, out_last, part, cb, smem_f32);
+  dense_f32_dma_body<BM, BN, WM, WN, NB, MINW, FUSE, BK>(W, bias, Hin, Hout, out, in, B, act, nMt, nNt, Wlast, out_last, part, cb, Dh,
+                                                         dkind, smem_f32);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -383,6 +393,8 @@ struct FuseArgsF32 {
   int out_last = 0;
   double* part = nullptr;
   ChainBatch cb;
+  const float* dact_h = nullptr;   // !FUSE only: multiply the stored value by act'(dact_h[same element]) (the reverse sweep's dX)
+  int dact_kind = SI_ACT_IDENTITY;
 };
 
 template <int BM, int BN, int WM, int WN, int NB, int MINW, bool FUSE, int BK = 16>
@@ -397,7 +409,7 @@ static void launch_f32_dma(hipStream_t st, const float* W, const float* bias, co
   static LdsOptIn optin;
   optin.ensure(reinterpret_cast<const void*>(kern), lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)fa.cb.n), dim3(64 * WM * WN), lds, st, W, bias, Hin, Hout, (int)out, (int)in, B,
-                     (int)act, nMt, nNt, fa.Wlast, fa.out_last, fa.part, fa.cb);
+                     (int)act, nMt, nNt, fa.Wlast, fa.out_last, fa.part, fa.cb, fa.dact_h, fa.dact_kind);
 }
 
 template <bool FUSE>
@@ -457,6 +469,21 @@ void launch_dense_f32(hipStream_t st, const float* W, const float* bias, const f
     return;
   }
   launch_f32_any<false>(st, W, bias, Hin, Hout, out, in, B, act, fa);
+}
+
+// The reverse sweep's dX: Dout = (Wt Delta) .* act'(Hprev) with the multiply in the GEMM's store (one read of Hprev instead of a
+// read + write of the whole panel in a pass of its own).  Only the LDS-DMA kernel has that store: returns false when the shape
+// went to the generic kernel and Dout = Wt Delta still needs its elementwise pass.
+bool launch_dense_f32_dx(hipStream_t st, const float* Wt, const float* zero_bias, const float* Delta, float* Dout, int32_t out,
+                         int32_t in, int64_t B, const float* Hprev, int32_t act_prev) {
+  FuseArgsF32 fa;
+  const bool fused = f32_fast_ok(Wt, Delta, Dout, out, in, fa.cb) && (reinterpret_cast<uintptr_t>(Hprev) & 15u) == 0;
+  if (fused) {
+    fa.dact_h = Hprev;
+    fa.dact_kind = act_prev;
+  }
+  launch_f32_any<false>(st, Wt, zero_bias, Delta, Dout, out, in, B, SI_ACT_IDENTITY, fa);
+  return fused;
 }
 
 // number of feature slots (partials per (o, b)) the fused kernel writes for a layer; `aligned` = what f32_fast_ok will see

@@ -16,6 +16,9 @@
 
 #include "si_internal.h"
 
+#ifndef SI_GW_KNOB   // compile-time knock-outs of tools/r05_gram_conflicts.sh; 0 in every shipped build
+#define SI_GW_KNOB 0
+#endif
 #ifndef SI_GW_PART
 #error "compile with -DSI_GW_PART=0|1|2"
 #endif
@@ -184,7 +187,11 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
   }
   auto issue_one = [&](int64_t roff, double* dst, auto PC) {
     constexpr int p = decltype(PC)::value;
+#if SI_GW_KNOB & 1   // (tools/r05_gram_conflicts.sh: no staging traffic at all)
+    (void)roff; (void)dst;
+#else
     __builtin_amdgcn_global_load_lds(src[p] + roff, (lds_void_ptr)(dst + 16 * p * GR), 16, 0, 0);
+#endif
   };
   auto issue = [&](int64_t slab, int buf) {
     const int64_t roff = slab * GR;
@@ -197,6 +204,11 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
   for (int i = 0; i < H; ++i) {
     const int s = KG + KS * i;
     fb[i] = c * GR + 2 * ((2 * s + (q >> 1)) ^ c) + (q & 1);
+#if SI_GW_KNOB & 2   // operand reads of 64 consecutive doubles: conflict-free whatever the image (wrong numbers, timing only)
+    fb[i] = lane + 64 * i;
+#elif SI_GW_KNOB & 4   // operand reads of the UNSWIZZLED image: every column on the same banks (the positive control)
+    fb[i] = c * GR + 2 * (2 * s + (q >> 1)) + (q & 1);
+#endif
     asm volatile("" : "+v"(fb[i]));   // keep the reads of neighbouring steps apart (no ds_read2_b64)
   }
   // ragged last tile: B operand of the 4x4x4_4b instruction = column 16 (NT-1) + 4 jb + (c & 3), row 4s + q, the same in all
@@ -470,6 +482,11 @@ __device__ __forceinline__ void gram_spec_consumer(int64_t N, double* __restrict
   for (int i = 0; i < H; ++i) {
     const int s = KG + KS * i;
     fb[i] = c * GR + 2 * ((2 * s + (q >> 1)) ^ c) + (q & 1);
+#if SI_GW_KNOB & 2   // operand reads of 64 consecutive doubles: conflict-free whatever the image (wrong numbers, timing only)
+    fb[i] = lane + 64 * i;
+#elif SI_GW_KNOB & 4   // operand reads of the UNSWIZZLED image: every column on the same banks (the positive control)
+    fb[i] = c * GR + 2 * (2 * s + (q >> 1)) + (q & 1);
+#endif
     asm volatile("" : "+v"(fb[i]));
   }
   const int64_t nslab = (N + GR - 1) / GR;

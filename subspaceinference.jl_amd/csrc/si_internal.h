@@ -367,6 +367,8 @@ void launch_dense_small_f64_fused(hipStream_t st, const double* W, const double*
 void launch_dense_f32(hipStream_t st, const float* W, const float* bias, const float* Hin, float* Hout, int32_t out, int32_t in,
                       int64_t B, int32_t act, const ChainBatch& cb = ChainBatch());
 int dense_f32_fused_slots(int32_t out, int32_t in, bool aligned);
+bool launch_dense_f32_dx(hipStream_t st, const float* Wt, const float* zero_bias, const float* Delta, float* Dout, int32_t out,
+                         int32_t in, int64_t B, const float* Hprev, int32_t act_prev);
 void launch_dense_f32_fused(hipStream_t st, const float* W, const float* bias, const float* Hin, int32_t out, int32_t in, int64_t B,
                             int32_t act, const float* Wlast, int32_t out_last, double* part, const ChainBatch& cb = ChainBatch(),
                             float* Hkeep = nullptr);

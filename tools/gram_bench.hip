@@ -11,6 +11,7 @@ ProfScope::~ProfScope() {}
 // the wide-subspace projection lives in kernels_bwd.hip; this harness only exercises M <= 32
 void launch_project_mfma(hipStream_t, const double*, int64_t, int64_t, int64_t, const double*, int32_t, int32_t, double*, int64_t) {}
 bool launch_project_stream(hipStream_t, const double*, int64_t, int64_t, int64_t, const double*, int32_t, int32_t, double*, int64_t, int) { return false; }
+bool launch_project_stream_f32(hipStream_t, const float*, int64_t, int64_t, int64_t, const double*, int32_t, int32_t, double*, int64_t, int) { return false; }
 }
 using namespace si;
 #ifdef SI_GRAM_TS
