@@ -229,6 +229,19 @@ __device__ __forceinline__ void dense_f32_dma_body(const float* __restrict__ W, 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail fetches must land before the workgroup retires
 
+#if defined(SI_F32_KNOB) && (SI_F32_KNOB & 1)   // tools/r05_f32_ceiling.sh only: no epilogue at all (the MFMAs stay observable)
+  {
+    float t = 0.0f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[a][b][r];
+    if (t == 12345.678f) part[0] = 1.0;
+    return;
+  }
+#endif
   // ---- epilogue: bias + activation (fp32), then either the store or the fused head
   const int iw0 = i0 + wm * (BM / WM);
   const int64_t bw0 = b0 + wn * (BN / WN);

@@ -164,6 +164,20 @@ struct GWave {
 // -- the 16 columns of a 32-lane half then cover the 16 slot positions, i.e. all 64 banks exactly once.
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef __attribute__((address_space(3))) const double* lds_d_ptr;
+// (inline asm inside the nested lambdas of the body does not survive the host-side pass: helpers)
+template <int OFF>
+__device__ __forceinline__ double gw_lds_read_b64(const double* p) {
+  double v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(uintptr_t)(lds_d_ptr)p), "n"(OFF));
+  return v;
+}
+template <int NT>
+__device__ __forceinline__ void gw_lds_wait(double (&f)[NT]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(f[t]));
+}
 
 template <int NT, int KS, int KG, int G, int NB, int NQ>
 __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int64_t ldA, int64_t N, int K,
@@ -248,7 +262,14 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
       constexpr unsigned M = GW::mask();
       // (with a ragged last tile the ordinary fragment of tile NT-1 is only the A operand of its own diagonal pair)
       constexpr bool need = ((M >> T) & 1u) && !(GW::RAG && T == NT - 1 && !(GW::LO <= GW::P - 1 && GW::P - 1 < GW::HI));
+#if SI_GW_KNOB & 16   // (round 4's form, kept for tools/r05_gram_conflicts.sh: the compiler's own reads)
       if constexpr (need) f[T] = buf[b + T * 16 * GR];
+#else
+      // one ds_read_b64 per tile, by hand: left to itself the load/store optimiser pairs the reads of two tiles (same base, 4 KiB
+      // apart) into ds_read2st64_b64, which is banked mod 32 in 16-lane groups -- 2-way conflicts on this image, half of all
+      // LDS-array cycles (profiles/r05_gram_conflicts.txt; same bits of G, same time: the conflicts were free)
+      if constexpr (need) f[T] = gw_lds_read_b64<T * 16 * GR * 8>(buf + b);
+#endif
     });
     if constexpr (GW::has_rag()) {
 #pragma unroll
@@ -293,6 +314,11 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
           issue_one(roff, pdst, std::integral_constant<int, I - (FRAG_AT + 1)>{});
         }
       };
+#if !(SI_GW_KNOB & 16)
+      // the compiler does not count hand-written LDS reads: wait for this group's fragments (issued a whole group ago) and make
+      // every MFMA operand depend on the wait
+      gw_lds_wait<NT>(fc);
+#endif
       __builtin_amdgcn_s_setprio(1);
       if constexpr (first_slab && i == 0)
         GW::template mfma<0, true>(fc, rc, acc, hook);
@@ -334,7 +360,8 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
   } else {
     constexpr int PS = GW::PS;
     constexpr int CMAX = GW::cmax();
-    constexpr int R = (NB * BUF) / (256 * GW_WAVES) > 0 ? (NB * BUF) / (256 * GW_WAVES) : 1;
+    constexpr int TP = 272;   // a 16 x 16 tile at pitch 17: the 16 lanes of a ds_write_b64 group (one column each) on 16 banks
+    constexpr int R = (NB * BUF) / (TP * GW_WAVES) > 0 ? (NB * BUF) / (TP * GW_WAVES) : 1;
     constexpr int ROUNDS = (CMAX + R - 1) / R;
     __syncthreads();
 #pragma unroll
@@ -347,7 +374,10 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
             constexpr int ii = decltype(IC)::value;
             if (ii == i) {
 #pragma unroll
-              for (int r = 0; r < GW::template comps<ii>(); ++r) sA[(wave * R + j) * 256 + GW::template tile_elem<ii>(lane, r)] = acc[ii][r];
+              for (int r = 0; r < GW::template comps<ii>(); ++r) {
+                const int te = GW::template tile_elem<ii>(lane, r);
+                sA[(wave * R + j) * TP + (te & 15) + 17 * (te >> 4)] = acc[ii][r];
+              }
             }
           });
         }
@@ -361,7 +391,7 @@ __device__ __forceinline__ void gram_glds_body(const double* __restrict__ A, int
         if (i < cnt2) {
           double sum = 0.0;
 #pragma unroll
-          for (int kg2 = 0; kg2 < KS; ++kg2) sum += sA[((g2 * KS + kg2) * R + j) * 256 + el];
+          for (int kg2 = 0; kg2 < KS; ++kg2) sum += sA[((g2 * KS + kg2) * R + j) * TP + (el & 15) + 17 * (el >> 4)];
           out[(lo2 + i) * 256 + el] = sum;
         }
       }
@@ -600,7 +630,7 @@ __device__ __forceinline__ void gram_spec_consumer(int64_t N, double* __restrict
         if (i < cnt2) {
           double sum = 0.0;
 #pragma unroll
-          for (int kg2 = 0; kg2 < KS; ++kg2) sum += sA[((g2 * KS + kg2) * R + j) * 256 + el];
+          for (int kg2 = 0; kg2 < KS; ++kg2) sum += sA[((g2 * KS + kg2) * R + j) * TP + (el & 15) + 17 * (el >> 4)];
           out[(lo2 + i) * 256 + el] = sum;
         }
       }

@@ -3,6 +3,7 @@
 #include "../subspaceinference.jl_amd/csrc/kernels_gram.hip"
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 namespace si {
 int32_t fail(Ctx*, int32_t c, const std::string&) { return c; }
@@ -93,6 +94,7 @@ int main(int argc, char** argv) {
     printf("CHECK K=%d: max |G - G_naive| / sqrt(G_ii G_jj) = %.3e at (%d, %d), symmetric %d -> %s\n", K, worst, wi, wj, (int)sym,
            (worst < 1e-12 && sym) ? "OK" : "FAIL");
   }
+  { unsigned long long x = 0; for (size_t i = 0; i < g.size(); ++i) { unsigned long long u; memcpy(&u, &g[i], 8); x = (x * 1099511628211ull) ^ u; } printf("G bits hash %016llx\n", x); }
   printf("G[0,0]=%.6f G[1,0]=%.6f G[K-1,K-1]=%.6f (expect ~N/12=%.1f on the diagonal)\n", g[0], g[1], g[(size_t)K * K - 1], N / 12.0);
   return 0;
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # where do gram_glds_kernel's SQ_LDS_BANK_CONFLICT cycles come from, and do they cost time?
 # Compile-time variants of kernels_gram_wave.hip (SI_GW_KNOB; built by tools/r05_gram_conflicts_build.sh HERE, run THERE):
-#   k0 shipped kernel | k1 no LDS-DMA staging at all | k2 operand reads of 64 consecutive doubles (conflict-free by construction)
+#   k0 shipped kernel (round 5: hand-written ds_read_b64; k16 = round 4, compiler-paired reads) | k1 no LDS-DMA staging at all | k2 operand reads of 64 consecutive doubles (conflict-free by construction)
 #   k4 operand reads of the unswizzled image (16 columns on the same banks: the positive control) | k3 = k1 + k2
 # For each: event-timed runs, then ONE rocprofv3 --pmc pass (SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_BUSY_CYCLES).
 set -o pipefail
