@@ -279,8 +279,17 @@ int32_t si_rwmh_abort(si_ctx* ctx);
  *     all resident) ends the call with SI_ERR_HIP, never a hang; more chains than that stack in the grid of the one-launch
  *     density, one pass of launches per transition.
  * Every form gives the SAME BITS as the launch-per-step loop with one launch per layer (on = 0: what the parity tests
- * compare against).  on = 2: the one-launch density, but no device-resident loop.                                          */
+ * compare against).  on = 2: the one-launch density, but no device-resident loop.
+ * RUN-TIME SPECIALISATION (round 5): for chains with a narrow head whose weight fragments fit a wave's registers (the
+ * nn_example model does) the two narrow-chain kernels are compiled once per distinct chain and process by hiprtc from kernel text
+ * embedded in the library, with the layer table as compile-time constants (csrc/chain_spec.inc: same arithmetic, same bits;
+ * ~1.5 s the first time a chain shape is used; the loop then takes ONE grid barrier per transition).  When hiprtc is not usable
+ * the generic kernels run; si_chain_kernel_info says which did.  on = 3 / 4: as 1 / 2 with the generic kernels only.       */
 int32_t si_set_chain_loop(si_ctx* ctx, int32_t on);
+/* did the last density evaluation / the last si_sample_rwmh* call run the kernels specialised at run time (1) or the generic
+ * ones (0)?  si_chain_spec_message: why not (hiprtc's log, or the class limit), "" when they did.                           */
+int32_t si_chain_kernel_info(si_ctx* ctx, int32_t* density_specialised, int32_t* loop_specialised);
+const char* si_chain_spec_message(si_ctx* ctx);
 /* :91 / :125  W_out[:, c] = W_swa + P * Z[:, c]   (N x C col-major).  Pipelined: K4 -> pinned staging (second stream) ->
  * host threads (SI_HOST_COPY_THREADS, default min(8, cpus / 2)) copy into W_out, which may be pageable and untouched.  */
 int32_t si_reconstruct(si_ctx* ctx, const double* Z /* M x C */, int64_t C, double* W_out);

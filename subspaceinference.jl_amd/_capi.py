@@ -134,6 +134,8 @@ SIGNATURES = {
     "si_host_sym_eig_top": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "si_host_jacobi_eig_psd": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
     "si_set_chain_loop": (c_int32, [c_void_p, c_int32]),
+    "si_chain_kernel_info": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32)]),
+    "si_chain_spec_message": (c_char_p, [c_void_p]),
     "si_construct_set_storage": (c_int32, [c_void_p, c_int32]),
     "si_host_cpu_budget": (c_int, []),
     "si_host_parse_cpu_max": (c_double, [c_char_p]),
@@ -606,8 +608,16 @@ class Context:
 
     def set_chain_loop(self, on):
         """False / 0: one launch per layer and per step of si_sample_rwmh; True / 1 (default): small and narrow Dense chains run
-        fused and device-resident; 2: the one-launch density for narrow chains, but no device-resident loop."""
+        fused and device-resident; 2: the one-launch density for narrow chains, but no device-resident loop; 3 / 4: as 1 / 2 with
+        the generic kernels only (no run-time specialisation to the chain's shapes)."""
         self._check(self.lib.si_set_chain_loop(self.h, int(on)))
+
+    def chain_kernel_info(self):
+        """(density_specialised, loop_specialised, message): did the last density evaluation / si_sample_rwmh* call run the kernels
+        compiled for this chain's shapes at run time (hiprtc), and if not, why"""
+        d, l = c_int32(0), c_int32(0)
+        self._check(self.lib.si_chain_kernel_info(self.h, byref(d), byref(l)))
+        return bool(d.value), bool(l.value), (self.lib.si_chain_spec_message(self.h) or b"").decode()
 
     def rwmh_begin(self, itr, sigma_z, seed, chain_id0=0, nchains=1, d_total=0):
         self._check(self.lib.si_rwmh_begin(self.h, int(itr), float(sigma_z), int(seed), int(chain_id0), int(nchains),

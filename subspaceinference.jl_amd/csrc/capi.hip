@@ -112,6 +112,12 @@ void free_infer(Ctx* c) {
   c->gridsync_chains = 0;
   dev_free(c->d_cgprog);
   c->fused_ok = false;
+  dev_free(c->d_specw);
+  dev_free(c->d_specy);
+  dev_free(c->d_specperm);
+  c->specperm_for = nullptr;
+  c->spec_chains = c->spec_fo = 0;
+  c->last_density_spec = c->last_loop_spec = 0;
   dev_free(c->d_yhat);
   dev_free(c->d_X32);
   dev_free(c->d_w32);

@@ -2,6 +2,7 @@
 // (si_logdensity_grad) -- reference src/space_inference.jl:88-95,107 and src/libs.jl:55-57,75-77.  Host-side orchestration only:
 // every arithmetic step runs in the kernels of kernels_*.hip.  No CPU fallback anywhere in this file.
 #include "capi_common.h"
+#include "chain_spec_rtc.h"
 
 using namespace si;
 
@@ -345,6 +346,7 @@ static int32_t eval_density_f32(si_ctx* ctx, int c0, int nc, const double** yhat
 // d_zprop[:, c] -> d_sse[c]; optionally leaves the model outputs at *yhat_out (slot j at + j * out_dim*B after the fused
 // tail, at + j * act_elems otherwise)
 int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out) {
+  ctx->last_density_spec = 0;   // (si_chain_kernel_info reports the last evaluation)
   const int64_t N = ctx->iN, B = ctx->B, ldw = pad_ld(N);
   const int32_t M = ctx->iM;
   const double dn = (double)nc;
@@ -438,7 +440,23 @@ int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out) {
         const double by = ((double)N * dn + (double)ctx->in_dim * (double)B + (double)d * dn) * 8.0;
         ProfScope ps(ctx, SI_K_DENSE, fl, by);
         ProfScope pm(ctx, SI_K_DENSE_MAIN, fl, by);
-        launch_chain_fused(ctx->stream, fp, nb, wave_tiles, lds, ctx->d_w, ldw, ctx->d_X, ctx->d_yhat, d, nc);
+        const SpecKernels* sk = nullptr;
+        if (ctx->chain_spec && ctx->fuse_tail)   // the same kernel compiled for this chain's shapes (chain_spec_rtc.cpp; same bits)
+          sk = spec_kernels(ctx->layers.data(), (int)ctx->layers.size(), nb, dense_fused_slot_feats(ctx->layers[ctx->layers.size() - 2].out), 0, false,
+                            &ctx->spec_message);
+        ctx->last_density_spec = sk != nullptr;
+        if (sk) {
+          const double* wp = ctx->d_w;
+          const double* xp = ctx->d_X;
+          double* yp = ctx->d_yhat;
+          long long ws = ldw, ys = d;
+          int Bi = (int)B;
+          void* args[] = {&wp, &ws, &xp, &yp, &ys, &Bi};
+          SI_HIP(ctx, hipModuleLaunchKernel(sk->fused, (unsigned)((B + 16 * nb - 1) / (16 * nb)), (unsigned)nc, 1, 256, 1, 1,
+                                            (unsigned)((size_t)sk->lds_doubles * sizeof(double)), ctx->stream, args, nullptr));
+        } else {
+          launch_chain_fused(ctx->stream, fp, nb, wave_tiles, lds, ctx->d_w, ldw, ctx->d_X, ctx->d_yhat, d, nc);
+        }
       }
       {
         ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d * dn, 16.0 * (double)d * dn);

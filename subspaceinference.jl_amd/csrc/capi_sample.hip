@@ -3,6 +3,8 @@
 // entry point: the one-workgroup device-resident loop (kernels_chain.hip), the persistent grid loop (kernels_chain_grid.hip)
 // and the launch-per-step loop.  Host-side orchestration only; no CPU fallback anywhere in this file.
 #include "capi_common.h"
+#include "chain_spec_args.h"
+#include "chain_spec_rtc.h"
 
 using namespace si;
 
@@ -66,6 +68,7 @@ static bool chain_loop_applies(const si_ctx* ctx) {
 static int32_t sample_rwmh_impl(si_ctx* ctx, const char* who, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0,
                                 int32_t nchains, double* Z_out, double* lp_out, double* accept_rate_out, double* W_out) {
   CHECK_CTX(ctx);
+  ctx->last_density_spec = ctx->last_loop_spec = 0;   // (si_chain_kernel_info reports THIS call)
   if (!ctx->i_ready) return fail(ctx, SI_ERR_STATE, std::string(who) + ": call si_infer_setup first");
   if (itr <= 0 || nchains <= 0 || chain_id0 < 0 || !(sigma_z > 0.0))
     return fail(ctx, SI_ERR_INVALID, std::string(who) + ": itr, nchains, sigma_z must be positive");
@@ -169,25 +172,91 @@ static int32_t sample_rwmh_impl(si_ctx* ctx, const char* who, int64_t itr, doubl
         break;
       }
     }
+    // The loop specialised to this chain's shapes (chain_spec.inc through hiprtc; same bits): ONE barrier per transition, the
+    // weights handed over in fragment order.  Class: a narrow head, at most 1024 model outputs (four blocks of the SSE tree),
+    // every weight fragment in registers (spec_applies).
+    const SpecKernels* sk = nullptr;
+    SiSpecGridArgs sa{};
+    size_t lds_spec = 0;
+    if (nb != 0 && ctx->chain_spec && ctx->fuse_tail && (int64_t)ctx->out_dim * ctx->B <= 1024 && M <= 256) {
+      const int G = a.G;
+      const int rs = (int)((((N + G - 1) / G) + 15) & ~(int64_t)15);
+      sk = spec_kernels(ctx->layers.data(), L, nb, sf, M, rs <= 256 && M <= 32, &ctx->spec_message);
+      if (sk) {
+        auto even = [](int64_t v) { return (v + 1) & ~(int64_t)1; };
+        const int64_t d = (int64_t)ctx->out_dim * ctx->B;
+        int64_t off = sk->lds_doubles;
+        sa.y_in_lds = 1;
+        sa.o_y = (int)off;
+        off += even(d);
+        sa.o_blk = (int)off;
+        off += even(ctx->sse_blocks);
+        sa.o_z = (int)off;
+        off += even(5 * (int64_t)M);
+        sa.o_red = (int)off;
+        off += 24;
+        sa.o_flag = (int)off;
+        off += 2;
+        lds_spec = std::max((size_t)off * sizeof(double), (size_t)(81 * 1024));   // (more than half a CU's LDS: one workgroup per CU)
+        if (lds_spec > (size_t)160 * 1024 - 256) sk = nullptr;
+      }
+      if (sk && (ctx->spec_chains < C || ctx->spec_fo != sk->fo_total)) {
+        dev_free(ctx->d_specw);
+        dev_free(ctx->d_specy);
+        ctx->spec_chains = 0;
+        if (dev_alloc(&ctx->d_specw, (size_t)4 * (size_t)sk->fo_total * (size_t)C) != hipSuccess ||
+            dev_alloc(&ctx->d_specy, (size_t)2 * (size_t)ctx->out_dim * (size_t)ctx->B * (size_t)C) != hipSuccess)
+          return fail(ctx, SI_ERR_NOMEM, std::string(who) + ": allocation failed");
+        // (the padding elements of the fragment-ordered vectors are never written by K4: they must be finite)
+        if (hipMemsetAsync(ctx->d_specw, 0, (size_t)4 * (size_t)sk->fo_total * (size_t)C * sizeof(double), ctx->stream) != hipSuccess)
+          return fail(ctx, SI_ERR_HIP, std::string(who) + ": hipMemsetAsync failed");
+        ctx->spec_chains = C;
+        ctx->spec_fo = sk->fo_total;
+      }
+      if (sk && ctx->specperm_for != (const void*)sk) {
+        dev_free(ctx->d_specperm);
+        ctx->specperm_for = nullptr;
+        if (dev_alloc(&ctx->d_specperm, (size_t)N) != hipSuccess) return fail(ctx, SI_ERR_NOMEM, std::string(who) + ": allocation failed");
+        int* pp = ctx->d_specperm;
+        void* pargs[] = {&pp};
+        if (hipModuleLaunchKernel(sk->perm, (unsigned)((sk->max_wn + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, pargs, nullptr) != hipSuccess)
+          return fail(ctx, SI_ERR_HIP, std::string(who) + ": launch of the fragment-order permutation failed");
+        ctx->specperm_for = (const void*)sk;
+      }
+    }
+    const size_t sync_lines = sk ? (size_t)8 * (size_t)C + 1 : (size_t)C + 1;   // (the specialised loop shards each chain's counter over 8 lines)
     if (nb != 0) {
-      if (ctx->gridsync_chains < C) {
+      if ((size_t)ctx->gridsync_chains < sync_lines) {
         dev_free(ctx->d_gridsync);
         ctx->gridsync_chains = 0;
-        if (dev_alloc(&ctx->d_gridsync, (size_t)32 * ((size_t)C + 1)) != hipSuccess) return fail(ctx, SI_ERR_NOMEM, std::string(who) + ": allocation failed");
-        ctx->gridsync_chains = C;
+        if (dev_alloc(&ctx->d_gridsync, (size_t)32 * sync_lines) != hipSuccess) return fail(ctx, SI_ERR_NOMEM, std::string(who) + ": allocation failed");
+        ctx->gridsync_chains = (int)sync_lines;
       }
       a.swa = ctx->i_swa; a.P = ctx->i_P; a.X = ctx->d_X; a.Y = ctx->d_Y;
       a.wbuf = ctx->d_w; a.w_stride = ldw;
       a.ybuf = ctx->d_yhat; a.y_stride = (int64_t)ctx->out_dim * ctx->B;
-      a.cnt = ctx->d_gridsync; a.status = ctx->d_gridsync + (size_t)32 * (size_t)C;
+      a.cnt = ctx->d_gridsync; a.status = ctx->d_gridsync + (size_t)32 * (sync_lines - 1);
       a.Z_out = dZ; a.lp_out = dlp; a.nacc_out = ctx->d_nacc;
       a.ldP = ctx->ldP; a.itr = itr; a.seed = seed; a.sigma_z = sigma_z; a.c0 = c0; a.sigma2 = s2;
       a.N = (int)N; a.chain_id0 = chain_id0;
-      hipError_t e = hipMemsetAsync(ctx->d_gridsync, 0, (size_t)32 * ((size_t)C + 1) * sizeof(unsigned), ctx->stream);
+      hipError_t e = hipMemsetAsync(ctx->d_gridsync, 0, (size_t)32 * sync_lines * sizeof(unsigned), ctx->stream);
       if (e == hipSuccess) {
         const double fl = 2.0 * (double)N * (double)ctx->B * (double)itr * C;
         ProfScope ps(ctx, SI_K_RWMH, fl, 0.0);
-        e = launch_chain_grid(ctx->stream, a, nb, C, lds);
+        if (sk) {
+          sa.swa = a.swa; sa.P = a.P; sa.X = a.X; sa.Y = a.Y; sa.perm = ctx->d_specperm;
+          sa.wbuf = ctx->d_specw; sa.w_stride = sk->fo_total;
+          sa.ybuf = ctx->d_specy; sa.y_stride = a.y_stride;
+          sa.cnt = a.cnt; sa.status = a.status;
+          sa.Z_out = dZ; sa.lp_out = dlp; sa.nacc_out = (long long*)ctx->d_nacc;
+          sa.ldP = a.ldP; sa.itr = itr; sa.seed = seed; sa.sigma_z = sigma_z; sa.c0 = c0; sa.sigma2 = s2;
+          sa.N = (int)N; sa.M = M; sa.G = a.G; sa.B = (int)ctx->B; sa.chain_id0 = chain_id0; sa.nblocks = ctx->sse_blocks;
+          void* gargs[] = {&sa};
+          e = hipModuleLaunchKernel(sk->grid, (unsigned)(a.G * C), 1, 1, 256, 1, 1, (unsigned)lds_spec, ctx->stream, gargs, nullptr);
+          ctx->last_loop_spec = e == hipSuccess;
+        } else {
+          e = launch_chain_grid(ctx->stream, a, nb, C, lds);
+        }
       }
       std::vector<int64_t> nacc((size_t)C);
       unsigned status = 0;
@@ -326,11 +395,23 @@ int32_t si_sample_rwmh_weights(si_ctx* ctx, int64_t itr, double sigma_z, uint64_
 // stream (same seed / chain ids), so all ranks take identical accept decisions and keep identical chains.
 int32_t si_set_chain_loop(si_ctx* ctx, int32_t on) {
   CHECK_CTX(ctx);
-  if (on < 0 || on > 2) return fail(ctx, SI_ERR_INVALID, "si_set_chain_loop: 0 (one launch per layer and step), 1 (automatic) or 2 (fused launches, no device-resident loop)");
-  ctx->chain_mode = on;
+  if (on < 0 || on > 4)
+    return fail(ctx, SI_ERR_INVALID, "si_set_chain_loop: 0 (one launch per layer and step), 1 (automatic), 2 (fused launches, no device-resident loop), "
+                                     "3 / 4 (1 / 2 without the run-time specialised kernels)");
+  ctx->chain_mode = on >= 3 ? on - 2 : on;
+  ctx->chain_spec = on < 3;
   ctx->chain_loop_enabled = on != 0;
   return SI_OK;
 }
+
+int32_t si_chain_kernel_info(si_ctx* ctx, int32_t* density_specialised, int32_t* loop_specialised) {
+  CHECK_CTX(ctx);
+  if (density_specialised) *density_specialised = ctx->last_density_spec;
+  if (loop_specialised) *loop_specialised = ctx->last_loop_spec;
+  return SI_OK;
+}
+
+const char* si_chain_spec_message(si_ctx* ctx) { return ctx ? ctx->spec_message.c_str() : ""; }
 
 int32_t si_rwmh_begin(si_ctx* ctx, int64_t itr, double sigma_z, uint64_t seed, int32_t chain_id0, int32_t nchains,
                       int64_t d_total) {

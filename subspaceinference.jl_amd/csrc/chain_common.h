@@ -3,7 +3,15 @@
 // activation of the MFMA epilogues (kernels_gemm.hip apply_act), the 16-lane butterfly of the fused head and the
 // shuffle-down wave sum of the SSE kernels (kernels_stream.hip wave_sum).
 #pragma once
+#ifdef __HIPCC_RTC__   // compiled at run time with chain_spec.inc: only the activation codes of include/subspace_hip.h are needed
+enum { SI_ACT_IDENTITY = 0, SI_ACT_RELU = 1, SI_ACT_TANH = 2, SI_ACT_SIGMOID = 3 };   // (checked against the header in chain_spec_rtc.cpp)
+typedef unsigned int uint32_t;   // (hiprtc keeps its fixed-width types in a namespace of its own)
+typedef unsigned long uint64_t;
+typedef long int64_t;
+typedef unsigned long uintptr_t;
+#else
 #include "kernels_gemm.h"
+#endif
 
 namespace si {
 

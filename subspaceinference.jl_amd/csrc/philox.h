@@ -2,8 +2,10 @@
 // Replaces Julia's global MersenneTwister draws inside AdvancedMH's RWMH (reference
 // src/space_inference.jl:113-116): `rand(rng, proposal)` and `randexp(rng)`.
 #pragma once
+#ifndef __HIPCC_RTC__   // (hiprtc brings the runtime and the fixed-width types itself)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace si {
 

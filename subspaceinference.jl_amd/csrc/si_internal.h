@@ -266,6 +266,15 @@ struct Ctx {
   int gridsync_chains = 0;
   CgTileD* d_cgprog = nullptr;      // the chain's tile program (chain_fused_program)
   int cg_start[5] = {0}, cg_count[5] = {0}, cg_chunks[5] = {0};
+  // the same two kernels specialised to the chain's shapes at run time (chain_spec_rtc.cpp); buffers of the specialised loop
+  bool chain_spec = true;           // si_set_chain_loop 3 / 4: generic kernels only
+  double* d_specw = nullptr;        // 4 weight vectors in fragment order per chain ([parity][accepted, rejected])
+  double* d_specy = nullptr;        // 2 output vectors per chain ([parity])
+  int* d_specperm = nullptr;        // natural weight index -> fragment order
+  const void* specperm_for = nullptr;   // (the SpecKernels the permutation was generated by)
+  int spec_chains = 0, spec_fo = 0;
+  int last_density_spec = 0, last_loop_spec = 0;   // si_chain_kernel_info: did the last density / sampling call run specialised kernels
+  std::string spec_message;         // why not, when they did not (hiprtc log, class limits)
 };
 
 void free_train(Ctx* c);

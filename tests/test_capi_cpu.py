@@ -57,7 +57,8 @@ def test_shipped_library_has_no_development_knobs(si):
     SI_HOST_COPY_THREADS (host copy pool size) and SI_RCCL_LIB (explicit RCCL path)."""
     blob = open(si._capi.LIB_PATH, "rb").read()
     names = set(m.decode() for m in re.findall(rb"SI_[A-Z0-9_]{3,}", blob))
-    env_like = {n for n in names if not n.startswith(("SI_ERR", "SI_K_", "SI_F", "SI_ACT", "SI_LAYER", "SI_OK", "SI_COMM", "SI_HIP", "SI_NCCL", "SI_DTYPE_OF_DATA"))}   # (enum names inside error messages)
+    env_like = {n for n in names if not n.startswith(("SI_ERR", "SI_K_", "SI_F", "SI_ACT", "SI_LAYER", "SI_OK", "SI_COMM", "SI_HIP", "SI_NCCL", "SI_DTYPE_OF_DATA",
+                                                             "SI_SPEC", "SI_SPSTAMP", "SI_SPE"))}   # (enum names inside error messages; SI_SPEC_* / SI_SPSTAMP: macros in the kernel TEXT embedded for hiprtc, csrc/chain_spec.inc)
     assert env_like <= {"SI_HOST_COPY_THREADS", "SI_RCCL_LIB"}, env_like
     assert b"gram_spec" not in blob                       # the wave-specialised development Gram variant is not compiled in
     # every getenv in the sources is one of the two, or sits inside an #ifdef SI_DEV_KNOBS / SI_BWD_DEBUG_KNOB block

@@ -6,6 +6,9 @@ launch per layer (si_set_chain_loop(ctx, 0)), which is held against the oracle h
   mode 0  one launch per layer and per step            (the reference point)
   mode 2  every layer in one launch, one pass of launches per transition (chains stacked in the grid)
   mode 1  automatic: the persistent grid loop where ceil(B / tile) * nchains workgroups are resident, else mode 2's path
+  modes 3 / 4  = 1 / 2 with the generic kernels only.  In modes 1 / 2 chains with a narrow head whose weight fragments fit a wave's
+          registers run kernels compiled for their shapes at run time (csrc/chain_spec.inc through hiprtc; the loop then takes ONE
+          grid barrier per transition and hands the weights over in fragment order): same bits again.
 """
 import numpy as np
 import pytest
@@ -43,14 +46,16 @@ def test_fused_and_grid_loop_equal_launch_per_step_bit_for_bit(si, gpu_ctx, dims
     _setup(gpu_ctx, dims, acts, b, m)
     itr = 60 if nchains > 8 else 200
     try:
-        out = {}
-        for mode in (0, 2, 1):
+        out, spec = {}, {}
+        for mode in (0, 2, 1, 4, 3):
             gpu_ctx.set_chain_loop(mode)
             out[mode] = gpu_ctx.sample_rwmh(itr, 0.07, seed=11, chain_id0=2, nchains=nchains)
-        for mode in (2, 1):
+            spec[mode] = gpu_ctx.chain_kernel_info()
+        for mode in (2, 1, 4, 3):
             for a, bb in zip(out[0], out[mode]):
-                assert np.array_equal(a, bb), (mode, dims, nchains)
+                assert np.array_equal(a, bb), (mode, dims, nchains, spec[mode])
         assert 0.0 < out[1][2].mean() < 1.0   # the chains move and reject: both branches of the accept step ran
+        assert not spec[3][0] and not spec[3][1] and not spec[4][0] and not spec[4][1]   # generic kernels when asked for
     finally:
         gpu_ctx.set_chain_loop(1)
 
@@ -73,6 +78,26 @@ def test_nn_example_against_the_oracle(si, gpu_ctx):
         assert np.array_equal(got, gpu_ctx.logdensity(zz))
     finally:
         gpu_ctx.set_chain_loop(1)
+
+
+def test_the_specialised_kernels_are_the_ones_that_run(si, gpu_ctx):
+    """nn_example: the persistent loop (few chains) and the stacked density (many) run the kernels compiled for the chain's shapes;
+    a chain outside the class (wide head) or too wide for the register preload keeps the generic ones and says why"""
+    dims, acts, b, m = NN_EXAMPLE
+    _setup(gpu_ctx, dims, acts, b, 20, seed=1)
+    gpu_ctx.set_chain_loop(1)
+    gpu_ctx.sample_rwmh(30, 0.05, seed=1, nchains=2)
+    d, l, msg = gpu_ctx.chain_kernel_info()
+    assert l, msg
+    gpu_ctx.sample_rwmh(5, 0.05, seed=1, nchains=300)     # more chains than the grid loop holds: one pass of launches per transition
+    d, l, msg = gpu_ctx.chain_kernel_info()
+    assert d and not l, msg
+    gpu_ctx.logdensity(np.zeros((20, 7)))
+    assert gpu_ctx.chain_kernel_info()[0]
+    _setup(gpu_ctx, [12, 256, 130, 2], [1, 2, 0], 2500, 7)   # 256 x 130: the fragments of a wave do not fit its registers
+    gpu_ctx.sample_rwmh(5, 0.05, seed=1, nchains=1)
+    d, l, msg = gpu_ctx.chain_kernel_info()
+    assert not d and not l and "class" in msg
 
 
 def test_long_chain_stays_identical(si, gpu_ctx):
@@ -127,6 +152,7 @@ def test_many_chains_stack_in_one_pass(si, gpu_ctx):
 
 
 def test_chain_loop_mode_is_validated(si, gpu_ctx):
-    with pytest.raises(si.SubspaceError):
-        gpu_ctx.set_chain_loop(3)
+    for bad in (5, -1):
+        with pytest.raises(si.SubspaceError):
+            gpu_ctx.set_chain_loop(bad)
     gpu_ctx.set_chain_loop(1)

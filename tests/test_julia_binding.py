@@ -107,7 +107,7 @@ def test_the_wrapper_binds_the_whole_single_process_path():
     for name in unbound:
         assert re.search(r"_dev$|_ptr$|gram_get|gram_set|rwmh_|train_grad|train_apply|allreduce_grad|profiling|stats|stream|synchronize|"
                          r"version|device_name|get_A|host_sym_eig|host_jacobi|host_copy_plan|host_parse_cpu_max|set_chain_loop|set_storage|si_forward|push_batch|si_sample_rwmh$|"
-                         r"si_train_setup$|train_compute_dtype", name)   # (si_train_setup: bound in its _ex form; compute_dtype: a test read-back), "unbound without a reason: " + name
+                         r"si_train_setup$|train_compute_dtype|chain_kernel_info|chain_spec_message", name)   # (si_train_setup: bound in its _ex form; compute_dtype, chain_kernel_info / _message: test read-backs), "unbound without a reason: " + name
     jl = open(JL).read()
     assert "function init_gpus" in jl and "ngpu = 1, nchains = ngpu" in jl and "remotecall" in jl
 

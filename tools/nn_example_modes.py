@@ -30,6 +30,6 @@ for nch in chains:
         t0 = time.perf_counter()
         z, lp, acc = ctx.sample_rwmh(itr, 0.1, seed=1, nchains=nch)
         dt = time.perf_counter() - t0
-        print("mode %d %4d chains: %8.1f us per transition of all chains, %10.0f samples/s, %6.2f TFLOP/s, lp[-1]=%.6f" %
-              (mode, nch, dt / itr * 1e6, itr * nch / dt, flop * nch * itr / dt / 1e12, lp[-1, 0]), flush=True)
+        print("mode %d %4d chains: %8.1f us per transition of all chains, %10.0f samples/s, %6.2f TFLOP/s, lp[-1]=%.6f  specialised (density, loop) %s" %
+              (mode, nch, dt / itr * 1e6, itr * nch / dt, flop * nch * itr / dt / 1e12, lp[-1, 0], ctx.chain_kernel_info()[:2]), flush=True)
 ctx.close()
