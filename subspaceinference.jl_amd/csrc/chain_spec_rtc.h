@@ -14,11 +14,13 @@ namespace si {
 struct SpecKernels {
   hipModule_t mod = nullptr;
   hipFunction_t fused = nullptr;   // si_spec_fused_kernel
+  hipFunction_t stack = nullptr;   // si_spec_stack_kernel: activations in registers, the weights in LDS (nullptr: they do not fit)
   hipFunction_t grid = nullptr;    // si_spec_grid_kernel (nullptr: compiled without the loop)
   hipFunction_t perm = nullptr;    // si_spec_perm_kernel
   int nb = 0, m = 0, preg = 0;
   int lds_doubles = 0;             // dynamic LDS of the forward (doubles); the loop adds its own behind it
   int fo_total = 0;                // doubles per weight vector in fragment order
+  int wvec_doubles = 0;            // dynamic LDS of the stacked kernel (doubles): the chain's whole weight vector
   int max_wn = 0;                  // max over the matrix layers of in * out (grid of the perm kernel)
   std::string error;               // non-empty: compilation failed (kept so that it is not retried)
 };

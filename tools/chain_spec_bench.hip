@@ -19,6 +19,7 @@
 #endif
 #include "../subspaceinference.jl_amd/csrc/chain_spec_args.h"
 #include "../subspaceinference.jl_amd/csrc/chain_spec.inc"
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -67,7 +68,12 @@ int main(int argc, char** argv) {
   printf("N %d, %d chains, NB %d: generic LDS %zu B, specialised LDS %zu B, grid %u x %u\n", N, nch, NB, lds, lds_spec, grid.x, grid.y);
   auto run_generic = [&]() { launch_chain_fused(0, p, NB, false, lds, W, ldw, X, dY0, B, nch); };
   auto run_spec = [&]() { hipLaunchKernelGGL(si_spec_fused_kernel, grid, dim3(256), lds_spec, 0, W, (long long)ldw, X, dY1, (long long)B, B); };
-  run_generic(); run_spec();
+  double* dY2; hipMalloc(&dY2, (size_t)B * nch * 8); hipMemset(dY2, 0x3f, (size_t)B * nch * 8);
+  const size_t lds_stack = (size_t)sispec::WVEC * 8;
+  const int splits = nch >= 256 ? 1 : std::min(8, (256 + nch - 1) / nch);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(si_spec_stack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stack);
+  auto run_stack = [&]() { hipLaunchKernelGGL(si_spec_stack_kernel, dim3(splits, nch), dim3(512), lds_stack, 0, W, (long long)ldw, X, dY2, (long long)B, B); };
+  run_generic(); run_spec(); run_stack();
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); return 1; }
   std::vector<double> y0((size_t)B * nch), y1((size_t)B * nch);
@@ -75,13 +81,21 @@ int main(int argc, char** argv) {
   size_t diff = 0;
   for (size_t i = 0; i < y0.size(); ++i) diff += memcmp(&y0[i], &y1[i], 8) != 0;
   printf("yhat: %zu of %zu values differ in their bits (y[0] = %.17g / %.17g)\n", diff, y0.size(), y0[0], y1[0]);
-  for (int which = 0; which < 2; ++which)
+  {
+    std::vector<double> y2((size_t)B * nch);
+    hipMemcpy(y2.data(), dY2, y2.size() * 8, hipMemcpyDeviceToHost);
+    size_t d2 = 0; double maxd = 0;
+    for (size_t i = 0; i < y0.size(); ++i) { d2 += memcmp(&y0[i], &y2[i], 8) != 0; maxd = fmax(maxd, fabs(y0[i] - y2[i])); }
+    printf("register-resident stacked kernel (%d splits x %d chains, LDS %zu B): %zu of %zu values differ in their bits, max |diff| %.3e (y[0] = %.17g)\n", splits, nch, lds_stack, d2, y0.size(), maxd, y2[0]);
+    diff += d2;
+  }
+  for (int which = 0; which < 3; ++which)
     for (int rep = 0; rep < 3; ++rep) {
       hipEventRecord(e0, 0);
-      for (int i = 0; i < 10; ++i) which ? run_spec() : run_generic();
+      for (int i = 0; i < 10; ++i) which == 2 ? run_stack() : which ? run_spec() : run_generic();
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
-      printf("  %-11s %.1f us per launch = %.2f TFLOP/s (useful 2 N B per chain)\n", which ? "specialised" : "generic", ms * 100.0, 2.0 * N * B * nch / (ms * 1e-4) / 1e12);
+      printf("  %-11s %.1f us per launch = %.2f TFLOP/s (useful 2 N B per chain)\n", which == 2 ? "stacked-reg" : which ? "specialised" : "generic", ms * 100.0, 2.0 * N * B * nch / (ms * 1e-4) / 1e12);
     }
   if (itr > 0) {   // the persistent loop: generic against specialised, Z and lp bit for bit
     const double* swa = W + (size_t)ldw * std::max(nch, lch); const double* P = swa + ldw; const double* Y = X + 2 * B;
