@@ -686,15 +686,19 @@ def run_chains(args, rk, real_stdout):
                              nrng.standard_normal((2, nb_obs)), nrng.standard_normal((1, nb_obs)), 1.0)
             nctx.sample_rwmh(50, 0.1, seed=1)
             t0 = time.perf_counter()
-            nctx.sample_rwmh(2000, 0.1, seed=1)
-            extras["nn_example_us_per_transition"] = (time.perf_counter() - t0) / 2000 * 1e6
+            nctx.sample_rwmh(20000, 0.1, seed=1)   # (sample(model, spl, itr) of the docs runs thousands of transitions per call)
+            extras["nn_example_us_per_transition"] = (time.perf_counter() - t0) / 20000 * 1e6
+            extras["nn_example_kernels_specialised_at_run_time"] = bool(nctx.chain_kernel_info()[1])
             nctx.sample_rwmh(10, 0.1, seed=1, nchains=512)
             t0 = time.perf_counter()
             nctx.sample_rwmh(100, 0.1, seed=1, nchains=512)
             extras["nn_example_512_chains_samples_per_s"] = 100 * 512 / (time.perf_counter() - t0)
+            extras["nn_example_kernels_specialised_at_run_time"] = extras["nn_example_kernels_specialised_at_run_time"] and bool(nctx.chain_kernel_info()[0])
         extras["nn_example_note"] = ("docs/src/nn_example.md's MLP, N = 15801, B = 1000, M = 20 (the largest M of its sweep): one chain in the "
-                                     "persistent grid loop (63 workgroups, two grid barriers per transition); 512 chains stacked in the "
-                                     "one-launch density (csrc/kernels_chain_grid.hip); round 4: 41.0 us and 0.336 M samples/s")
+                                     "persistent grid loop (63 workgroups, ONE grid barrier per transition, 20 000 transitions in one launch); "
+                                     "512 chains stacked in the one-launch density with the activations in registers; both kernels compiled for "
+                                     "this chain's shapes at run time (csrc/chain_spec.inc through hiprtc; the generic kernels of "
+                                     "csrc/kernels_chain_grid.hip give 22 us and 0.65 M samples/s); round 4: 41.0 us and 0.336 M samples/s")
 
     if rank == 0:
         dm = st["dense_main"]

@@ -19,6 +19,7 @@
 #endif
 #include "../subspaceinference.jl_amd/csrc/chain_spec_args.h"
 #include "../subspaceinference.jl_amd/csrc/chain_spec.inc"
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -133,12 +134,17 @@ int main(int argc, char** argv) {
       for (int which = 0; which < 2; ++which)
         for (int rep = 0; rep < 3; ++rep) {
           hipMemset(dsync, 0, 128 * (8 * lch + 1));
+          const auto wt0 = std::chrono::steady_clock::now();
           hipEventRecord(e0, 0);
-          if (which) hipLaunchKernelGGL(si_spec_grid_kernel, dim3(G * lch), dim3(256), ldss, 0, sa); else launch_chain_grid(0, a, NB, lch, ldsg);
+          static hipStream_t lst = nullptr;
+          if (!lst && getenv("SI_HARNESS_STREAM")) hipStreamCreateWithFlags(&lst, hipStreamNonBlocking);   // (the library launches on a stream of its own)
+          if (which) hipLaunchKernelGGL(si_spec_grid_kernel, dim3(G * lch), dim3(256), ldss, lst, sa); else launch_chain_grid(0, a, NB, lch, ldsg);
+          if (lst) hipStreamSynchronize(lst);
           hipEventRecord(e1, 0); hipEventSynchronize(e1);
           float ms; hipEventElapsedTime(&ms, e0, e1);
           unsigned stt; hipMemcpy(&stt, sa.status, 4, hipMemcpyDeviceToHost);
-          printf("  %-11s %.3f ms = %.2f us per transition, status %u\n", which ? "specialised" : "generic", ms, ms * 1e3 / itr, stt);
+          const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - wt0).count() * 1e3;
+          printf("  %-11s %.3f ms = %.2f us per transition (host wall %.3f ms), status %u\n", which ? "specialised" : "generic", ms, ms * 1e3 / itr, wall, stt);
         }
     }
     std::vector<double> z0((size_t)M * itr * lch), z1(z0.size()), l0((size_t)itr * lch), l1(l0.size());

@@ -23,7 +23,7 @@ ctx.infer_setup(table, off, m, 0.3 * rng.standard_normal(off), 0.05 * rng.standa
                 rng.standard_normal((dims[0], b)), rng.standard_normal((dims[-1], b)), 1.0)
 flop = 2.0 * off * b
 for nch in chains:
-    itr = 2000 if nch <= 8 else (400 if nch <= 64 else 100)
+    itr = (20000 if nch == 1 else 2000) if nch <= 8 else (400 if nch <= 64 else 100)
     for mode in modes:
         ctx.set_chain_loop(mode)
         ctx.sample_rwmh(20, 0.1, seed=1, nchains=nch)

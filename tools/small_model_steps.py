@@ -25,7 +25,7 @@ for name, dims, acts, b, m in (("README toy", [10, 20, 20, 2], [0, 0, 0], 100, 3
     ctx.infer_setup(table, n, m, 0.3 * rng.standard_normal(n), 0.05 * rng.standard_normal((n, m)),
                     rng.standard_normal((dims[0], b)), rng.standard_normal((dims[-1], b)), 1.0)
     ctx.sample_rwmh(50, 0.1, seed=1)
-    itr = 2000
+    itr = 20000   # (a call carries ~2 ms of fixed cost: set-up of the loop, the copies of the samples, the first launch)
     t0 = time.perf_counter()
     z, lp, acc = ctx.sample_rwmh(itr, 0.1, seed=1)
     dt = time.perf_counter() - t0
