@@ -60,9 +60,9 @@ B, M, K_SNAP = 100000, 20, 100
 SIGMA_Z, SIGMA_M = 0.1, 1.0
 PEAK_F64_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet; the guide's table has no f64 row -- DESIGN.md section 4)
 PEAK_F32_TFLOPS = 157.3  # MI355X fp32 matrix peak (guide: v_mfma_f32_32x32x2_f32, 155 measured)
-PMC_PROFILE_F32 = "r04_pmc_dense_f32_main.json"   # the same passes on the fp32 kernel (sha-keyed to kernels_gemm_f32.hip)
+PMC_PROFILE_F32 = "r05_pmc_dense_f32_main.json"   # the same passes on the fp32 kernel (sha-keyed to kernels_gemm_f32.hip)
 PEAK_HBM_GBS = 8000.0
-PMC_PROFILE = "r04_pmc_dense_main.json"
+PMC_PROFILE = "r05_pmc_dense_main.json"
 CFG = {  # construct-only configurations
     "cfg2": dict(n=1047361, k=100, m=20),
     "cfg4": dict(n=5200266, k=200, m=20),

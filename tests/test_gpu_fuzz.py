@@ -5,7 +5,8 @@ through host / device / batched pushes, the column shift, the Gram kernels of ev
 tools/guard_fuzz_api.py: predictive, prior term, step-wise RWMH over two data shards, output-map pipeline, device hand-over,
 gradient samplers; tools/guard_fuzz_e2e.py: the drop-in subspace_construction call with the training step on the device
 against the host-stepped one -- ragged last batches, shuffling, three optimisers -- then sub_inference; tools/guard_fuzz_comm.py: the sharded flows over the in-library RCCL communicator at world 1 against the
-single-GPU entry points, bit for bit).  The widths favour the tile edges of the
+single-GPU entry points, bit for bit; tools/guard_fuzz_chain.py (round 5): narrow Dense chains under every sampler schedule -- per-layer
+launches, generic fused kernels, kernels specialised at run time -- bit for bit).  The widths favour the tile edges of the
 kernels.  Round 3 ran the same sweeps at 250 / 150 cases over the development library with the guard-page allocator
 (profiles/r03_guard_page_runs.log); they found the two addressing bugs fixed that round.  Here: fixed
 seeds, the shipped library, a few dozen cases each."""
@@ -19,7 +20,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,cases,seed", [("guard_fuzz.py", 60, 21), ("guard_fuzz_cnn.py", 40, 22), ("guard_fuzz_gram.py", 40, 23), ("guard_fuzz_api.py", 30, 24), ("guard_fuzz_e2e.py", 15, 25), ("guard_fuzz_comm.py", 15, 26)])
+@pytest.mark.parametrize("tool,cases,seed", [("guard_fuzz.py", 60, 21), ("guard_fuzz_cnn.py", 40, 22), ("guard_fuzz_gram.py", 40, 23), ("guard_fuzz_api.py", 30, 24), ("guard_fuzz_e2e.py", 15, 25), ("guard_fuzz_comm.py", 15, 26),
+                                             ("guard_fuzz_chain.py", 14, 27)])
 def test_random_shape_sweep_through_the_c_abi(tool, cases, seed):
     env = dict(os.environ)
     env.pop("SI_PROBE_DEV", None)

@@ -8,6 +8,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${ROUND:-r4}prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+# ONLY_BENCH=1: step [4] alone (the bench lines read the PMC json that steps [1]-[3] of an earlier call produced); SKIP_BENCH=1: the rest
+if [ -z "${ONLY_BENCH:-}" ]; then
 echo "[1] bench.py under rocprofv3 --kernel-trace --stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_kt -o b -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 python3 $R/tools/kstats.py $O/bench_kt 25 > $O/bench_kernel_stats.txt
@@ -42,6 +44,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/cnns_kt -o s -- pytho
 python3 $R/tools/kstats.py $O/cnns_kt 12 > $O/cfg4_cnn_sample_kernel_stats.txt
 python3 $R/tools/per_layer.py $O/cnns_kt 14 15 >> $O/cfg4_cnn_sample_kernel_stats.txt
 rm -rf $O/cnn_kt $O/cnng_kt $O/cnns_kt $O/bench_kt
+fi
+if [ -n "${SKIP_BENCH:-}" ]; then echo done; exit 0; fi
 echo "[4] bench lines"
 cd $R
 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err
