@@ -146,6 +146,7 @@ void free_infer(Ctx* c) {
   c->fuse_tail = false;
   dev_free(c->d_Xc);
   dev_free(c->d_wpack);
+  dev_free(c->d_wpack32);
   dev_free(c->d_wsq);
   dev_free(c->d_wsqpart);
   c->sigma_p = 0.0;

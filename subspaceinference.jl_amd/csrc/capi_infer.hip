@@ -105,8 +105,6 @@ static int32_t infer_setup_common(si_ctx* ctx, const si_layer* layers, int32_t L
     const int32_t prc = net_plan(ctx, "si_infer_setup", layers, L, N, in_dim, out_dim, plan);
     if (prc != SI_OK) return prc;
   }
-  if (compute_dtype == SI_F32 && plan.has_conv)
-    return fail(ctx, SI_ERR_INVALID, "si_infer_setup: compute_dtype = SI_F32 is implemented for Dense chains; Conv / MaxPool / flatten chains compute in SI_F64");
   int main_layer = 0;
   double main_flops = -1.0;
   for (int l = 0; l < L; ++l) {
@@ -183,7 +181,8 @@ static int32_t infer_setup_common(si_ctx* ctx, const si_layer* layers, int32_t L
     SI_HIP(ctx, hipMemcpy(ctx->d_cgprog, prog.data(), prog.size() * sizeof(CgTileD), hipMemcpyHostToDevice));
   }
   if (dev_alloc(&ctx->d_X, (size_t)in_dim * B) != hipSuccess || dev_alloc(&ctx->d_Y, (size_t)out_dim * B) != hipSuccess ||
-      (ctx->f32 && dev_alloc(&ctx->d_X32, (size_t)pad_ld((int64_t)in_dim * B)) != hipSuccess) ||
+      (ctx->f32 && dev_alloc(&ctx->d_X32, (size_t)pad_ld(std::max<int64_t>((int64_t)in_dim * B, plan.input_spatial ? plan.in_elems * B : 0))) != hipSuccess) ||
+      (ctx->f32 && plan.has_conv && dev_alloc(&ctx->d_wpack32, plan.wpack_elems) != hipSuccess) ||
       !alloc_forward(ctx, 1) ||
       (plan.has_conv && dev_alloc(&ctx->d_wpack, plan.wpack_elems) != hipSuccess) ||
       (plan.input_spatial && dev_alloc(&ctx->d_Xc, (size_t)plan.in_elems * B) != hipSuccess)) {
@@ -196,7 +195,10 @@ static int32_t infer_setup_common(si_ctx* ctx, const si_layer* layers, int32_t L
     SI_HIP(ctx, hipMemcpyAsync(ctx->d_Y, Y, (size_t)out_dim * B * sizeof(double), kind, ctx->stream));
   }
   if (plan.input_spatial) net_input(ctx, plan, ctx->d_X, ctx->d_Xc, B);  // (W, H, C, N) -> channel-fastest, once
-  if (ctx->f32) launch_narrow_f32(ctx->stream, ctx->d_X, ctx->d_X32, (int64_t)in_dim * B);   // X rounded to fp32 once
+  if (ctx->f32 && plan.input_spatial)   // X rounded to fp32 once, in the layout the conv kernels read (pad channels: zero)
+    launch_narrow_f32(ctx->stream, ctx->d_Xc, ctx->d_X32, plan.in_elems * B);
+  else if (ctx->f32)
+    launch_narrow_f32(ctx->stream, ctx->d_X, ctx->d_X32, (int64_t)in_dim * B);   // X rounded to fp32 once
   SI_HIP(ctx, hipGetLastError());
   SI_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->i_ready = true;
@@ -357,6 +359,21 @@ int32_t eval_density(si_ctx* ctx, int c0, int nc, const double** yhat_out) {
   }
   if (ctx->sigma_p > 0.0)  // ||new_W||^2 per chain for the optional prior term (same fixed-order reduction as the SSE)
     launch_sse(ctx->stream, ctx->d_w, nullptr, N, ctx->d_wsqpart, ctx->wsq_blocks, ctx->d_wsq + c0, nc, ldw);
+  if (ctx->plan.has_conv && ctx->f32) {
+    // compute_dtype = SI_F32 on a Conv chain: the same pass on fp32 operands (net_forward_f32); the squared errors in fp64
+    float* last32 = nullptr;
+    const int32_t rc = net_forward_f32(ctx, ctx->plan, ctx->d_w32, ctx->d_X32, B, ctx->d_act32, ctx->d_wpack32, &last32);
+    if (rc != SI_OK) return rc;
+    const int64_t d = (int64_t)ctx->out_dim * B;
+    {
+      ProfScope ps(ctx, SI_K_SSE, 3.0 * (double)d, 12.0 * (double)d);
+      launch_sse_f32(ctx->stream, last32, ctx->d_Y, d, ctx->d_ssepart, ctx->sse_blocks, ctx->d_sse + c0, 1, ctx->act_elems,
+                     yhat_out ? ctx->d_yhat : nullptr, d, !ctx->defer_sse_final);
+    }
+    SI_HIP(ctx, hipGetLastError());
+    if (yhat_out) *yhat_out = ctx->d_yhat;
+    return SI_OK;
+  }
   if (ctx->plan.has_conv) {
     // generic path (capi_net.hip): Conv / MaxPool / flatten / Dense layers one after the other, ping-pong activations
     double* last = nullptr;
@@ -579,6 +596,8 @@ int32_t si_logdensity(si_ctx* ctx, const double* Z, int32_t C, double* lp_out) {
 static int32_t ensure_grad(si_ctx* ctx) {
   if (ctx->g_ready) return SI_OK;
   const int64_t B = ctx->B;
+  if (ctx->plan.has_conv && ctx->f32)
+    return fail(ctx, SI_ERR_INVALID, "si_logdensity_grad: compute_dtype = SI_F32 has a reverse sweep for Dense chains only; set a Conv chain up with SI_F64 for gradients");
   if (ctx->plan.has_conv) {
     const NetPlan& p = ctx->plan;
     size_t nb, nr, nw, nd;

@@ -216,6 +216,67 @@ int32_t net_forward(Ctx* c, const NetPlan& p, const double* w, const double* xin
   return SI_OK;
 }
 
+// compute_dtype = SI_F32 on a Conv chain: the forward pass of net_forward (ping-pong activations, Conv + 2x2 MaxPool fused where it
+// applies) on fp32 operands -- the conv kernels compiled for float (kernels_conv.hip -DSI_CONV_F32: v_mfma_f32_16x16x4_f32), the
+// Dense layers behind `flatten` on kernels_gemm_f32.hip.  w32: the evaluation's weights rounded once from the fp64 sum (K4).
+int32_t net_forward_f32(Ctx* c, const NetPlan& p, const float* w, const float* xin, int64_t B, float* const* outs, float* wpack,
+                        float** final_out) {
+  hipStream_t st = c->stream;
+  const float* h = xin;
+  size_t executed = 0;
+  for (size_t l = 0; l < p.L.size(); ++l) {
+    const LayerPlan& q = p.L[l];
+    float* o = outs[executed & 1];
+    ++executed;
+    if (final_out) *final_out = o;
+    if ((double)std::max(q.in_elems, q.out_elems) * (double)B >= 2147483648.0)
+      return fail(c, SI_ERR_INVALID, "activation tensors of 2^31 elements or more are not supported by the conv kernels");
+    switch (q.kind) {
+      case SI_LAYER_DENSE: {
+        ProfScope ps(c, SI_K_DENSE, 2.0 * (double)q.in_feat * q.out_feat * (double)B,
+                     ((double)q.in_feat * q.out_feat + q.out_feat + (double)(q.in_feat + q.out_feat) * (double)B) * 4.0);
+        if (dense_narrow_applies(q.out_feat, q.in_feat, B, c->num_cu))
+          launch_dense_narrow(st, w + q.w_off, w + q.b_off, h, o, q.out_feat, q.in_feat, B, q.act);
+        else
+          launch_dense_f32(st, w + q.w_off, w + q.b_off, h, o, q.out_feat, q.in_feat, B, q.act);
+        break;
+      }
+      case SI_LAYER_CONV: {
+        const int64_t npos = (int64_t)q.Wo * q.Ho * B;
+        {
+          ProfScope ps(c, SI_K_CONV_AUX, 0.0, ((double)q.KW * q.KH * q.C * q.Co + (double)q.Cop * q.Kp) * 4.0);
+          launch_conv_pack(st, w + q.w_off, w + q.b_off, wpack + q.wp_off, wpack + q.bp_off, q.KW, q.KH, q.C, q.Co, q.Cp, q.Cop, q.Kp);
+        }
+        if (net_pool_fusable(p, l)) {   // the pooled tensor is all the next layer reads: skip the MaxPool layer
+          ProfScope ps(c, SI_K_CONV, 2.0 * (double)q.KW * q.KH * q.C * q.Co * (double)npos,
+                       ((double)q.in_elems + (double)p.L[l + 1].out_elems) * (double)B * 4.0 + (double)q.Cop * q.Kp * 4.0);
+          launch_conv_forward_pool2(st, wpack + q.wp_off, wpack + q.bp_off, h, o, q.g, q.Cop, q.Kp, npos, q.act);
+          ++l;
+          break;
+        }
+        ProfScope ps(c, SI_K_CONV, 2.0 * (double)q.KW * q.KH * q.C * q.Co * (double)npos,
+                     ((double)q.in_elems + (double)q.out_elems) * (double)B * 4.0 + (double)q.Cop * q.Kp * 4.0);
+        launch_conv_forward(st, wpack + q.wp_off, wpack + q.bp_off, h, o, q.g, q.Cop, q.Kp, npos, q.act);
+        break;
+      }
+      case SI_LAYER_MAXPOOL: {
+        ProfScope ps(c, SI_K_CONV_AUX, 0.0, ((double)q.in_elems + (double)q.out_elems) * (double)B * 4.0);
+        launch_maxpool(st, h, o, q.Cp, q.Wi, q.Hi, q.Wo, q.Ho, q.KW, q.KH, q.sw, q.sh, B);
+        break;
+      }
+      default: {  // flatten: channel-fastest -> the reference's (W, H, C) feature order
+        ProfScope ps(c, SI_K_CONV_AUX, 0.0, ((double)q.in_elems + (double)q.out_elems) * (double)B * 4.0);
+        launch_cwhn_to_whcn(st, h, o, q.Wi, q.Hi, q.C, q.Cp, B);
+        break;
+      }
+    }
+    h = o;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, SI_ERR_HIP, std::string("net_forward_f32: ") + hipGetErrorString(e));
+  return SI_OK;
+}
+
 void net_scratch_sizes(const NetPlan& p, int64_t B, int num_cu, size_t* bwpart, size_t* rspart, size_t* wt, size_t* dbtmp) {
   size_t part = 1;
   for (const LayerPlan& q : p.L) {

@@ -7,12 +7,43 @@
 //   LAY = 0 "row-fast"  X[r + ld*k]  -> LDS [k][R+16]          LAY = 1 "k-fast"  X[k + ld*r] -> LDS [r][18]
 // Interface: static LAY, LDS_ELEMS, RP, KP;  load(kt), store(dst), load_edge(kt, klen), store_edge(dst, kt, klen).
 // `Stager` below reads a plain matrix; kernels_conv.hip adds stagers that gather im2col patches on the fly.
+//
+// The element type is a macro (default double, namespace gp64): kernels_conv.hip is compiled a second time with
+// -DSI_CONV_F32 (float operands on v_mfma_f32_16x16x4_f32 -- the same 16 x 16 x 4 shape and lane map, so every stager, LDS image
+// and index map below serves both; namespace gp32) for compute_dtype = SI_F32 on Conv chains.
 #pragma once
 #include <type_traits>
 
 #include "kernels_gemm.h"
 
+#ifdef SI_CONV_F32
+#define SI_GP_NS gp32
+#define SI_GP_REAL float
+#define SI_GP_REAL2 float2
+#define SI_GP_MAKE2 make_float2
+#define SI_GP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+// component r of the accumulator in lane (q, c) is row 4 q + r of the 16 x 16 tile (the fp64 instruction: q + 4 r); a 2 x 2 pooling
+// window keeps its four inputs in ONE lane either way: position p of a 16-position slice = window / input as below
+#define SI_GP_ROW(q, r) (4 * (q) + (r))
+#define SI_GP_PWIN(p) (((p) >> 2) & 3)
+#define SI_GP_PIN(p) ((p) & 3)
+#else
+#define SI_GP_NS gp64
+#define SI_GP_REAL double
+#define SI_GP_REAL2 double2
+#define SI_GP_MAKE2 make_double2
+#define SI_GP_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0)
+#define SI_GP_ROW(q, r) ((q) + 4 * (r))
+#define SI_GP_PWIN(p) ((p) & 3)
+#define SI_GP_PIN(p) (((p) >> 2) & 3)
+#endif
+
 namespace si {
+namespace SI_GP_NS {
+
+typedef SI_GP_REAL real;
+typedef SI_GP_REAL2 real2;
+typedef real r4 __attribute__((ext_vector_type(4)));
 
 // one operand tile: R rows (feature / batch index) x 16 k values
 template <int R, int LAY_, int NT, bool VEC>
@@ -32,8 +63,8 @@ struct Stager {
   int go_[NGO], lds_[NS], kk_[NS];
   bool live_[NS];
   int ldi;
-  double reg[NREG][E];
-  const double* base;
+  real reg[NREG][E];
+  const real* base;
   int64_t ld;
 
   __device__ __forceinline__ int go(int r) const {
@@ -53,7 +84,7 @@ struct Stager {
     else return live_[r];
   }
 
-  __device__ __forceinline__ void init(const double* X, int64_t ld_, int64_t r0, int64_t rmax, int64_t k0, int tid) {
+  __device__ __forceinline__ void init(const real* X, int64_t ld_, int64_t r0, int64_t rmax, int64_t k0, int tid) {
     ld = ld_;
     ldi = (int)ld_;
 #pragma unroll
@@ -89,11 +120,11 @@ struct Stager {
   // edge logic inline the 16-deep tile cost ~60 VALU instructions per wave next to its 24 MFMAs, and the split-K weight
   // gradient ran at 51 TFLOP/s.)
   __device__ __forceinline__ void load(int kt) {
-    const double* p = base + (LAY == 0 ? ld * 16 : (int64_t)16) * kt;
+    const real* p = base + (LAY == 0 ? ld * 16 : (int64_t)16) * kt;
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
       if constexpr (VEC) {
-        const double2 v = *reinterpret_cast<const double2*>(p + go(r));
+        const real2 v = *reinterpret_cast<const real2*>(p + go(r));
         reg[r][0] = v.x;
         reg[r][1] = v.y;
       } else {
@@ -101,12 +132,12 @@ struct Stager {
       }
     }
   }
-  __device__ __forceinline__ void store(double* dst) const {
+  __device__ __forceinline__ void store(real* dst) const {
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
       if (!live(r)) continue;
       if constexpr (VEC)
-        *reinterpret_cast<double2*>(dst + lds(r)) = make_double2(reg[r][0], reg[r][1]);
+        *reinterpret_cast<real2*>(dst + lds(r)) = SI_GP_MAKE2(reg[r][0], reg[r][1]);
       else
         dst[lds(r)] = reg[r][0];
     }
@@ -114,7 +145,7 @@ struct Stager {
   // Ragged last tile (klen % 16 != 0): k indices past the end are clamped to a legal address and zero-filled in LDS
   // (they would add into valid outputs).  klen_total = k values of this block's split.
   __device__ __forceinline__ void load_edge(int kt, int64_t klen_total) {
-    const double* p = base + (LAY == 0 ? ld * 16 : (int64_t)16) * kt;
+    const real* p = base + (LAY == 0 ? ld * 16 : (int64_t)16) * kt;
     const int64_t kmax = klen_total - (LAY == 1 ? E : 1) - (int64_t)kt * 16;  // last legal k (pair start) in this tile
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
@@ -123,7 +154,7 @@ struct Stager {
       // moved like a live one it would read up to 21 k values BEFORE a first tile, i.e. outside the operand)
       if ((LAY == 1 || live(r)) && kk(r) > kmax) o -= (int)(LAY == 0 ? ld : 1) * (int)(kk(r) - (kmax > 0 ? kmax : 0));
       if constexpr (VEC) {
-        const double2 v = *reinterpret_cast<const double2*>(p + o);
+        const real2 v = *reinterpret_cast<const real2*>(p + o);
         reg[r][0] = v.x;
         reg[r][1] = v.y;
       } else {
@@ -131,15 +162,15 @@ struct Stager {
       }
     }
   }
-  __device__ __forceinline__ void store_edge(double* dst, int kt, int64_t klen_total) const {
+  __device__ __forceinline__ void store_edge(real* dst, int kt, int64_t klen_total) const {
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
       if (!live(r)) continue;
       const bool ok = (int64_t)kt * 16 + kk(r) < klen_total;
       if constexpr (VEC)
-        *reinterpret_cast<double2*>(dst + lds(r)) = make_double2(ok ? reg[r][0] : 0.0, ok ? reg[r][1] : 0.0);
+        *reinterpret_cast<real2*>(dst + lds(r)) = SI_GP_MAKE2(ok ? reg[r][0] : (real)0, ok ? reg[r][1] : (real)0);
       else
-        dst[lds(r)] = ok ? reg[r][0] : 0.0;
+        dst[lds(r)] = ok ? reg[r][0] : (real)0;
     }
   }
 };
@@ -148,17 +179,17 @@ struct Stager {
 // may be ragged).  smem: [2][SA::LDS_ELEMS] then [2][SB::LDS_ELEMS].  wm / wn: this wave's position in the WM x WN grid.
 // NOEDGE: the caller guarantees klen % 16 == 0 (no ragged tile): the edge variants of the stagers are not even compiled in.
 template <int BM, int BN, int WM, int WN, bool NOEDGE = false, class SA, class SB>
-__device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, double* smem, int nk, int64_t klen, int wm, int wn, int lane,
-                                              d4 (&acc)[BM / WM / 16][BN / WN / 16], int dbg) {
+__device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, real* smem, int nk, int64_t klen, int wm, int wn, int lane,
+                                              r4 (&acc)[BM / WM / 16][BN / WN / 16], int dbg) {
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   constexpr int ALAY = SA::LAY, BLAY = SB::LAY;
-  double* sAbuf = smem;
-  double* sBbuf = smem + 2 * SA::LDS_ELEMS;
+  real* sAbuf = smem;
+  real* sBbuf = smem + 2 * SA::LDS_ELEMS;
   const int q = lane >> 4, c = lane & 15;
-  double fa[2][TM], fb[2][TN];
+  real fa[2][TM], fb[2][TN];
   const int aw = wm * (BM / WM) + c, bw = wn * (BN / WN) + c;
-  const double* pa0 = sAbuf + (ALAY == 0 ? q * SA::RP + aw : aw * SA::KP + q);
-  const double* pb0 = sBbuf + (BLAY == 0 ? q * SB::RP + bw : bw * SB::KP + q);
+  const real* pa0 = sAbuf + (ALAY == 0 ? q * SA::RP + aw : aw * SA::KP + q);
+  const real* pb0 = sBbuf + (BLAY == 0 ? q * SB::RP + bw : bw * SB::KP + q);
   auto read_frags = [&](auto BUF, auto S, auto SET) {
     constexpr int buf = decltype(BUF)::value, s = decltype(S)::value, set = decltype(SET)::value;
 #pragma unroll
@@ -175,7 +206,7 @@ __device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, double* smem, int 
 #pragma unroll
     for (int t = lo; t < hi; ++t) {
       const int a = t / TN, b = t % TN;
-      acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[set][b], fa[set][a], acc[a][b], 0, 0, 0);
+      acc[a][b] = SI_GP_MFMA(fb[set][b], fa[set][a], acc[a][b]);
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -255,7 +286,7 @@ __device__ __forceinline__ void gemm_mainloop(SA& sa, SB& sb, double* smem, int 
 // store instruction writes 16 B per lane over whole rows of C.  SMEM_ELEMS = doubles of staging LDS available.
 // f(value, element offset, m) -> value is applied per element (bias + activation, act' factor, ...).
 template <int BM, int BN, int WM, int WN, bool VEC, int SMEM_ELEMS, class F>
-__device__ __forceinline__ void gemm_epilogue(d4 (&acc)[BM / WM / 16][BN / WN / 16], double* smem, double* __restrict__ Cout,
+__device__ __forceinline__ void gemm_epilogue(r4 (&acc)[BM / WM / 16][BN / WN / 16], real* smem, real* __restrict__ Cout,
                                               int64_t ldc, int m0, int64_t n0, int Mrows, int64_t Ncols, int wm, int wn, int lane,
                                               int wave, F f) {
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -266,26 +297,26 @@ __device__ __forceinline__ void gemm_epilogue(d4 (&acc)[BM / WM / 16][BN / WN / 
   const int64_t nw0 = n0 + wn * (BN / WN);
   if constexpr (WIDE) {
     constexpr int CH_ROW = WI / 2, NCH = 16 * CH_ROW / 64;
-    double* reg = smem + wave * (16 * WI);
+    real* reg = smem + wave * (16 * WI);
     __syncthreads();  // all waves are done with the staging buffers (the loop's last barrier precedes the last reads)
 #pragma unroll
     for (int bt = 0; bt < TN; ++bt) {
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) reg[(q + 4 * r) * WI + a * 16 + c] = acc[a][bt][r];
+        for (int r = 0; r < 4; ++r) reg[SI_GP_ROW(q, r) * WI + a * 16 + c] = acc[a][bt][r];
 #pragma unroll
       for (int p = 0; p < NCH; ++p) {
         const int chunk = p * 64 + lane;
         const int row = chunk / CH_ROW, col2 = chunk % CH_ROW;
-        double2 v = *reinterpret_cast<const double2*>(reg + 2 * chunk);
+        real2 v = *reinterpret_cast<const real2*>(reg + 2 * chunk);
         const int gm = mw0 + 2 * col2;
         const int64_t gn = nw0 + bt * 16 + row;
         if (gm + 1 < Mrows && gn < Ncols) {
           const int64_t off = gm + ldc * gn;
           v.x = f(v.x, off, gm);
           v.y = f(v.y, off + 1, gm + 1);
-          *reinterpret_cast<double2*>(Cout + off) = v;
+          *reinterpret_cast<real2*>(Cout + off) = v;
         }
       }
     }
@@ -297,7 +328,7 @@ __device__ __forceinline__ void gemm_epilogue(d4 (&acc)[BM / WM / 16][BN / WN / 
       for (int b = 0; b < TN; ++b) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t gn = nw0 + b * 16 + q + 4 * r;
+          const int64_t gn = nw0 + b * 16 + SI_GP_ROW(q, r);
           if (gm < Mrows && gn < Ncols) {
             const int64_t off = gm + ldc * gn;
             Cout[off] = f(acc[a][b][r], off, gm);
@@ -308,4 +339,6 @@ __device__ __forceinline__ void gemm_epilogue(d4 (&acc)[BM / WM / 16][BN / WN / 
   }
 }
 
+}  // namespace SI_GP_NS
+using namespace SI_GP_NS;
 }  // namespace si

@@ -25,7 +25,7 @@
 
 namespace si {
 
-__device__ __forceinline__ double conv_act(double v, int act) {
+__device__ __forceinline__ real conv_act(real v, int act) {
   switch (act) {
     case SI_ACT_RELU: return v > 0.0 ? v : 0.0;
     case SI_ACT_TANH: return tanh(v);
@@ -33,7 +33,7 @@ __device__ __forceinline__ double conv_act(double v, int act) {
     default: return v;   // (GEMM epilogues only see the first four: launch_conv_forward finishes the later ones elementwise)
   }
 }
-__device__ __forceinline__ double conv_dact(double h, int act) {
+__device__ __forceinline__ real conv_dact(real h, int act) {
   switch (act) {
     case SI_ACT_RELU: return h > 0.0 ? 1.0 : 0.0;
     case SI_ACT_TANH: return 1.0 - h * h;
@@ -42,8 +42,21 @@ __device__ __forceinline__ double conv_dact(double h, int act) {
   }
 }
 
+static int conv_pick_bm(int rows) {
+  if (rows <= 64) return 64;
+  auto padded = [&](int bm) { return (rows + bm - 1) / bm * bm; };
+  const int p96 = padded(96), p128 = padded(128), p64 = padded(64);
+  if (p96 < p128 && p96 <= p64) return 96;
+  return p128 <= p64 ? 128 : 64;
+}
+static unsigned idx_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
 // `y ≈ x` of NNlib's ∇maxpool (Julia isapprox: rtol = sqrt(eps), atol = 0), see pool_chosen below
-__device__ __forceinline__ bool pool_approx(double x, double y) {
+__device__ __forceinline__ bool pool_approx(real x, real y) {
   return x == y || (isfinite(x) && isfinite(y) && fabs(x - y) <= 1.4901161193847656e-08 * fmax(fabs(x), fabs(y)));
 }
 
@@ -67,11 +80,11 @@ struct GatherK {
   int pb[NREG], wb[NREG], hb[NREG];
   int kk, lds0;
   int t_cin, t_adil, t_cdil;   // CELLU: the (block-uniform) tap of the NEXT k tile; the mainloop asks for the tiles in order
-  double2 reg[NREG];
-  const double* T;
+  real2 reg[NREG];
+  const real* T;
   ConvGeom g;
 
-  __device__ __forceinline__ void init(const double* T_, const ConvGeom& g_, int64_t n0, int64_t npos, int tid) {
+  __device__ __forceinline__ void init(const real* T_, const ConvGeom& g_, int64_t n0, int64_t npos, int tid) {
     T = T_;
     g = g_;
     const int wh = g.Wo * g.Ho;
@@ -91,10 +104,10 @@ struct GatherK {
         // The clamp is on the WINDOW: in the last slice of a tensor whose window count is not a multiple of 4 the inputs
         // 1..3 of the valid windows sit at positions >= npos (clamping the position there handed them the first input of a
         // window past the end -- wrong maxima in the last windows, and a read behind the input tensor).
-        int64_t win = ((pos & ~(int64_t)15) >> 2) + (pos & 3);
+        int64_t win = ((pos & ~(int64_t)15) >> 2) + SI_GP_PWIN((int)(pos & 15));
         const int64_t nwin = npos >> 2;
         if (win > nwin - 1) win = nwin - 1;  // clamped windows only feed outputs that are never stored
-        const int e = (int)((pos >> 2) & 3), W2 = g.Wo >> 1, wh2 = W2 * (g.Ho >> 1);
+        const int e = SI_GP_PIN((int)(pos & 15)), W2 = g.Wo >> 1, wh2 = W2 * (g.Ho >> 1);
         img = (int)(win / wh2);
         const int sp = (int)(win - (int64_t)img * wh2);
         const int ho2 = sp / W2, wo2 = sp - ho2 * W2;
@@ -122,8 +135,8 @@ struct GatherK {
     }
     ok = ok && wi < g.Wi && hi < g.Hi;
     const int off = ok ? pb[r] + g.Cp * (wi + g.Wi * hi) + cin : 0;
-    const double2 v = *reinterpret_cast<const double2*>(T + off);
-    reg[r] = ok ? v : make_double2(0.0, 0.0);
+    const real2 v = *reinterpret_cast<const real2*>(T + off);
+    reg[r] = ok ? v : SI_GP_MAKE2(0.0, 0.0);
   }
   __device__ __forceinline__ void load(int kt) {
     if constexpr (CELLU) {
@@ -149,13 +162,13 @@ struct GatherK {
       }
     }
   }
-  __device__ __forceinline__ void store(double* dst) const {
+  __device__ __forceinline__ void store(real* dst) const {
 #pragma unroll
-    for (int r = 0; r < NREG; ++r) *reinterpret_cast<double2*>(dst + lds0 + r * (NT / 8) * KP) = reg[r];
+    for (int r = 0; r < NREG; ++r) *reinterpret_cast<real2*>(dst + lds0 + r * (NT / 8) * KP) = reg[r];
   }
   // k is padded to whole tiles (Kp % 16 == 0, taps past Kvalid read as zero): there is no ragged tile
   __device__ __forceinline__ void load_edge(int kt, int64_t) { load(kt); }
-  __device__ __forceinline__ void store_edge(double* dst, int, int64_t) const { store(dst); }
+  __device__ __forceinline__ void store_edge(real* dst, int, int64_t) const { store(dst); }
 };
 
 // B operand of the weight-gradient GEMM: B(k = pos, n = k') = patch[k', pos] -- rows are the taps (fixed per slot), the
@@ -177,12 +190,12 @@ struct GatherN {
   // Only slot 0's pixel is kept; slot r's is KSTEP * r positions further (a carry per digit, like the advance per tile).
   int aoff, coff, lds0;
   int left0, wo0, ho0, ioff0;
-  double2 reg[NREG];
-  const double* T;
+  real2 reg[NREG];
+  const real* T;
   ConvGeom g;
   int dw16, dh16, di16, dws, dhs, dis;
 
-  __device__ __forceinline__ void init(const double* T_, const ConvGeom& g_, int64_t n0, int64_t k0, int64_t kend, int tid) {
+  __device__ __forceinline__ void init(const real* T_, const ConvGeom& g_, int64_t n0, int64_t k0, int64_t kend, int tid) {
     static_assert(KSTEP <= 16, "slots of a thread lie inside one k tile");
     T = T_;
     g = g_;
@@ -228,32 +241,32 @@ struct GatherN {
       const int wi = w * g.snum_w + aoff, hi = h * g.snum_h + coff;
       const bool ok = 16 * kt + KSTEP * r < left0 && wi >= 0 && hi >= 0 && wi < g.Wi && hi < g.Hi;
       const int off = ok ? im + g.Cp * (wi + g.Wi * hi) : 0;
-      const double2 v = *reinterpret_cast<const double2*>(T + off);
-      reg[r] = ok ? v : make_double2(0.0, 0.0);
+      const real2 v = *reinterpret_cast<const real2*>(T + off);
+      reg[r] = ok ? v : SI_GP_MAKE2(0.0, 0.0);
       if (r + 1 < NREG) step(w, h, im, dws, dhs, dis, g);
     }
     step(wo0, ho0, ioff0, dw16, dh16, di16, g);   // the next k tile: 16 positions further
   }
-  __device__ __forceinline__ void store(double* dst) const {
+  __device__ __forceinline__ void store(real* dst) const {
 #pragma unroll
-    for (int r = 0; r < NREG; ++r) *reinterpret_cast<double2*>(dst + lds0 + r * KSTEP * RP) = reg[r];
+    for (int r = 0; r < NREG; ++r) *reinterpret_cast<real2*>(dst + lds0 + r * KSTEP * RP) = reg[r];
   }
   __device__ __forceinline__ void load_edge(int kt, int64_t) { load(kt); }  // positions past the split's end are masked in load()
-  __device__ __forceinline__ void store_edge(double* dst, int, int64_t) const { store(dst); }
+  __device__ __forceinline__ void store_edge(real* dst, int, int64_t) const { store(dst); }
 };
 
 // ------------------------------------------------------------------------------------------------ GEMM kernels
 // Out[m + Mp*pos] = f(sum_k' Wp[m + Mp*k'] * gather(k', pos))      (forward: f = act(. + bias[m]); data gradient: f = id)
 template <int BM, int BN, int WM, int WN, int MINW, bool CELLU, bool DEN, bool BIASACT>
-__global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_kernel(const double* __restrict__ Wp, int Mp,
-                                                                       const double* __restrict__ T, double* __restrict__ Out,
-                                                                       const double* __restrict__ bias, ConvGeom g, int64_t npos,
+__global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_kernel(const real* __restrict__ Wp, int Mp,
+                                                                       const real* __restrict__ T, real* __restrict__ Out,
+                                                                       const real* __restrict__ bias, ConvGeom g, int64_t npos,
                                                                        int Kp, int act, int nMt, int64_t nNt) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   using SA = Stager<BM, 0, NT, true>;
   using SB = GatherK<BN, NT, CELLU, DEN>;
-  extern __shared__ double smem[];
+  extern __shared__ real smem[];
   const int64_t bid = blockIdx.x;
   int mt;
   int64_t nt;
@@ -271,18 +284,18 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_kernel(const dou
   const int wm = wave % WM, wn = wave / WM;
   const int m0 = mt * BM;
   const int64_t n0 = nt * BN;
-  d4 acc[TM][TN];
+  r4 acc[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < TN; ++b) acc[a][b] = (r4){0.0, 0.0, 0.0, 0.0};
   SA sa;
   SB sb;
   sa.init(Wp, Mp, m0, Mp, 0, tid);
   sb.init(T, g, n0, npos, tid);
   gemm_mainloop<BM, BN, WM, WN, true>(sa, sb, smem, Kp / 16, (int64_t)Kp, wm, wn, lane, acc, 0);
   gemm_epilogue<BM, BN, WM, WN, true, 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS)>(
-      acc, smem, Out, (int64_t)Mp, m0, n0, Mp, npos, wm, wn, lane, wave, [&](double v, int64_t, int gm) {
+      acc, smem, Out, (int64_t)Mp, m0, n0, Mp, npos, wm, wn, lane, wave, [&](real v, int64_t, int gm) {
         if constexpr (BIASACT) v = conv_act(v + bias[gm], act);
         return v;
       });
@@ -299,16 +312,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_kernel(const dou
 // With it the un-pooled activation never has to exist: act'(chosen input) = act'(pooled output), so the Delta tensor
 // of the layer follows from (pooled gradient, pooled output, index) alone (pool2_bwd_idx_kernel).
 template <int BM, int BN, int WM, int WN, int MINW, bool CELLU, bool IDX>
-__global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_pool_kernel(const double* __restrict__ Wp, int Mp,
-                                                                            const double* __restrict__ T, double* __restrict__ Out,
-                                                                            const double* __restrict__ bias, ConvGeom g, int64_t npos,
+__global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_pool_kernel(const real* __restrict__ Wp, int Mp,
+                                                                            const real* __restrict__ T, real* __restrict__ Out,
+                                                                            const real* __restrict__ bias, ConvGeom g, int64_t npos,
                                                                             int Kp, int act, int nMt, int64_t nNt,
                                                                             uint8_t* __restrict__ Idx) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   using SA = Stager<BM, 0, NT, true>;
   using SB = GatherK<BN, NT, CELLU, false, true>;
-  extern __shared__ double smem[];
+  extern __shared__ real smem[];
   const int64_t bid = blockIdx.x;
   int mt;
   int64_t nt;
@@ -326,11 +339,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_pool_kernel(cons
   const int wm = wave % WM, wn = wave / WM;
   const int m0 = mt * BM;
   const int64_t n0 = nt * BN;
-  d4 acc[TM][TN];
+  r4 acc[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < TN; ++b) acc[a][b] = (r4){0.0, 0.0, 0.0, 0.0};
   SA sa;
   SB sb;
   sa.init(Wp, Mp, m0, Mp, 0, tid);
@@ -341,14 +354,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_pool_kernel(cons
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
     const int gm = m0 + wm * (BM / WM) + a * 16 + c;
-    const double bv = gm < Mp ? bias[gm] : 0.0;
+    const real bv = gm < Mp ? bias[gm] : 0.0;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       // D[n = q + 4r][m = c]: window q of the slice, its input r (dx + 2 dy: NNlib's kw-fastest scan order)
-      double vin[4];
+      real vin[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) vin[r] = conv_act(acc[a][b][r] + bv, act);
-      const double o = fmax(fmax(vin[0], vin[1]), fmax(vin[2], vin[3]));
+      const real o = fmax(fmax(vin[0], vin[1]), fmax(vin[2], vin[3]));
       int oi = 4;
       if constexpr (IDX) {
 #pragma unroll
@@ -376,11 +389,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_gemm_pool_kernel(cons
 // The k steps run in the same order with the same 4-wide grouping as the GEMM pipeline and skipped steps only ever added
 // zeros, so the results are bit-identical to conv_gemm_pool_kernel's.
 template <int NS, int NTM, bool IDX>
-__global__ __launch_bounds__(256, 3) void conv_first_pool_kernel(const double* __restrict__ Wp, int Mp, const double* __restrict__ T,
-                                                              double* __restrict__ Out, const double* __restrict__ bias, ConvGeom g,
+__global__ __launch_bounds__(256, 3) void conv_first_pool_kernel(const real* __restrict__ Wp, int Mp, const real* __restrict__ T,
+                                                              real* __restrict__ Out, const real* __restrict__ bias, ConvGeom g,
                                                               int64_t npos, int Kp, int act, uint8_t* __restrict__ Idx) {
   constexpr int MP = NTM * 16 + 16;   // LDS row pitch
-  extern __shared__ double sW[];      // [4 * NS][MP]
+  extern __shared__ real sW[];      // [4 * NS][MP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, c = lane & 15;
   for (int e = tid; e < 4 * NS * MP; e += 256) {
@@ -402,57 +415,57 @@ __global__ __launch_bounds__(256, 3) void conv_first_pool_kernel(const double* _
   const int W2 = g.Wo >> 1, wh2 = W2 * (g.Ho >> 1);
   const int64_t nslice = (npos + 15) >> 4, nwin = npos >> 2;
   const int64_t sstride = (int64_t)gridDim.x * 4;
-  auto gather = [&](int64_t sl, double(&f)[NS]) {
+  auto gather = [&](int64_t sl, real(&f)[NS]) {
     // lane c of the patch operand = position c of the slice = window (c & 3), input (c >> 2) of it (see GatherK<POOLP>);
     // 32-bit index arithmetic: the caller guarantees fewer than 2^31 positions
-    int win = 4 * (int)sl + (c & 3);
+    int win = 4 * (int)sl + SI_GP_PWIN(c);
     if (win > (int)nwin - 1) win = (int)nwin - 1;   // clamped windows are never stored
-    const int e = c >> 2;
+    const int e = SI_GP_PIN(c);
     const int img = win / wh2, sp = win - img * wh2;
     const int ho2 = sp / W2, wo2 = sp - ho2 * W2;
     const int wb = (2 * wo2 + (e & 1)) * g.snum_w, hb = (2 * ho2 + (e >> 1)) * g.snum_h;
-    const double* base = T + (int64_t)img * g.img_stride;
+    const real* base = T + (int64_t)img * g.img_stride;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int wi = wb + (int)((tp[s] >> 8) & 0xff) - 128, hi = hb + (int)((tp[s] >> 16) & 0xff) - 128;
       const bool ok = (int)tp[s] >= 0 && wi >= 0 && hi >= 0 && wi < g.Wi && hi < g.Hi;
-      const double v = base[ok ? g.Cp * (wi + g.Wi * hi) + (int)(tp[s] & 0xff) : 0];
+      const real v = base[ok ? g.Cp * (wi + g.Wi * hi) + (int)(tp[s] & 0xff) : 0];
       f[s] = ok ? v : 0.0;
     }
   };
-  double bv[NTM];
+  real bv[NTM];
 #pragma unroll
   for (int t = 0; t < NTM; ++t) bv[t] = 16 * t + c < Mp ? bias[16 * t + c] : 0.0;
-  const double* wfrag = sW + q * MP + c;
+  const real* wfrag = sW + q * MP + c;
   int64_t sl = (int64_t)blockIdx.x * 4 + wave;
-  double fcur[NS], fnext[NS];
+  real fcur[NS], fnext[NS];
   if (sl < nslice) gather(sl, fcur);
   for (; sl < nslice; sl += sstride) {
     const bool more = sl + sstride < nslice;
     if (more) gather(sl + sstride, fnext);   // in flight under the MFMAs below
-    d4 acc[NTM];
+    r4 acc[NTM];
 #pragma unroll
-    for (int t = 0; t < NTM; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < NTM; ++t) acc[t] = (r4){0.0, 0.0, 0.0, 0.0};
     // the weight fragments are re-read from LDS for every slice (4 cycles of LDS time per MFMA of 64): kept in registers --
     // where the compiler puts loop-invariant loads by itself -- they cost 8 registers per k step and channel tile and
     // the kernel ran at two waves per SIMD instead of three (measured: 6.52 against 6.46 ms of conv time per transition)
     int woff = 0;
     asm volatile("" : "+v"(woff));
-    const double* wf = wfrag + woff;
+    const real* wf = wfrag + woff;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
       for (int t = 0; t < NTM; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fcur[s], wf[4 * s * MP + 16 * t], acc[t], 0, 0, 0);
+        acc[t] = SI_GP_MFMA(fcur[s], wf[4 * s * MP + 16 * t], acc[t]);
     }
     // D[position q + 4r][channel c]: window q of the slice, input r of the window -- the maximum is lane-local
 #pragma unroll
     for (int t = 0; t < NTM; ++t) {
       const int gm = 16 * t + c;
-      double vin[4];
+      real vin[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) vin[r] = conv_act(acc[t][r] + bv[t], act);
-      const double o = fmax(fmax(vin[0], vin[1]), fmax(vin[2], vin[3]));
+      const real o = fmax(fmax(vin[0], vin[1]), fmax(vin[2], vin[3]));
       int oi = 4;
       if constexpr (IDX) {
 #pragma unroll
@@ -479,14 +492,14 @@ static bool conv_first_applies(const ConvGeom& g, int COUTp) {
 }
 
 template <int NS, bool IDX>
-static void launch_conv_first_ns(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, uint8_t* Idx,
+static void launch_conv_first_ns(hipStream_t st, const real* Wp, const real* bp, const real* In, real* Out, uint8_t* Idx,
                                  const ConvGeom& g, int COUTp, int Kp, int64_t npos, int act) {
   const int ntm = (COUTp + 15) / 16;
   const int64_t nslice = (npos + 15) / 16;
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, (nslice + 3) / 4));
 #define SI_FIRST_CASE(NTM)                                                                                                  \
   {                                                                                                                         \
-    constexpr size_t lds = (size_t)4 * NS * (NTM * 16 + 16) * sizeof(double);                                               \
+    constexpr size_t lds = (size_t)4 * NS * (NTM * 16 + 16) * sizeof(real);                                               \
     hipLaunchKernelGGL((conv_first_pool_kernel<NS, NTM, IDX>), dim3(grid), dim3(256), lds, st, Wp, COUTp, In, Out, bp, g,   \
                        npos, Kp, act, Idx);                                                                                 \
   }
@@ -499,7 +512,7 @@ static void launch_conv_first_ns(hipStream_t st, const double* Wp, const double*
 #undef SI_FIRST_CASE
 }
 template <bool IDX>
-static void launch_conv_first(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, uint8_t* Idx,
+static void launch_conv_first(hipStream_t st, const real* Wp, const real* bp, const real* In, real* Out, uint8_t* Idx,
                               const ConvGeom& g, int COUTp, int Kp, int64_t npos, int act) {
   const int ns = (g.Kvalid + 3) / 4;   // k steps that carry taps; the instantiation rounds up, the surplus reads zeros
   if (ns <= 5)
@@ -508,18 +521,19 @@ static void launch_conv_first(hipStream_t st, const double* Wp, const double* bp
     launch_conv_first_ns<9, IDX>(st, Wp, bp, In, Out, Idx, g, COUTp, Kp, npos, act);
 }
 
+#ifndef SI_CONV_F32   // (reverse sweep: fp64 only)
 // part[split][m + Mp*k'] = sum over the split's positions of Delta[m + Mp*pos] * patch[k', pos]
 // NOEDGE: npos % 16 == 0, so every split is a whole number of k tiles (the ragged-tile code is not compiled in)
 template <int BM, int BN, int WM, int WN, int MINW, bool NOEDGE>
-__global__ __launch_bounds__(64 * WM * WN, MINW) void conv_dw_kernel(const double* __restrict__ Delta, int Mp,
-                                                                     const double* __restrict__ T, double* __restrict__ part,
+__global__ __launch_bounds__(64 * WM * WN, MINW) void conv_dw_kernel(const real* __restrict__ Delta, int Mp,
+                                                                     const real* __restrict__ T, real* __restrict__ part,
                                                                      ConvGeom g, int64_t npos, int Kp, int64_t ksplit, int nMt,
                                                                      int nNt) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   using SA = Stager<BM, 0, NT, true>;
   using SB = GatherN<BN, NT>;
-  extern __shared__ double smem[];
+  extern __shared__ real smem[];
   const int mt = (int)(blockIdx.x % nMt), nt = (int)(blockIdx.x / nMt);
   const int64_t split = blockIdx.y;
   const int64_t k0 = split * ksplit;
@@ -529,11 +543,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_dw_kernel(const doubl
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
   const int m0 = mt * BM, n0 = nt * BN;
-  d4 acc[TM][TN];
+  r4 acc[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < TN; ++b) acc[a][b] = (r4){0.0, 0.0, 0.0, 0.0};
   SA sa;
   SB sb;
   sa.init(Delta, Mp, m0, Mp, k0, tid);
@@ -541,24 +555,18 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_dw_kernel(const doubl
   gemm_mainloop<BM, BN, WM, WN, NOEDGE>(sa, sb, smem, (int)((klen + 15) / 16), klen, wm, wn, lane, acc, 0);
   gemm_epilogue<BM, BN, WM, WN, true, 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS)>(
       acc, smem, part + split * (int64_t)Mp * Kp, (int64_t)Mp, m0, (int64_t)n0, Mp, (int64_t)Kp, wm, wn, lane, wave,
-      [&](double v, int64_t, int) { return v; });
+      [&](real v, int64_t, int) { return v; });
 }
 
-static int conv_pick_bm(int rows) {
-  if (rows <= 64) return 64;
-  auto padded = [&](int bm) { return (rows + bm - 1) / bm * bm; };
-  const int p96 = padded(96), p128 = padded(128), p64 = padded(64);
-  if (p96 < p128 && p96 <= p64) return 96;
-  return p128 <= p64 ? 128 : 64;
-}
 
+#endif
 template <int BM, bool CELLU, bool DEN, bool BIASACT>
-static void launch_conv_gemm_bm(hipStream_t st, const double* Wp, int Mp, const double* T, double* Out, const double* bias,
+static void launch_conv_gemm_bm(hipStream_t st, const real* Wp, int Mp, const real* T, real* Out, const real* bias,
                                 const ConvGeom& g, int64_t npos, int Kp, int act) {
   constexpr int BN = 128, WM = 2, WN = 4, NT = 512;
   using SA = Stager<BM, 0, NT, true>;
   using SB = GatherK<BN, NT, CELLU, DEN>;
-  constexpr size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(double);
+  constexpr size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(real);
   const int nMt = (Mp + BM - 1) / BM;
   const int64_t nNt = (npos + BN - 1) / BN;
   const int64_t grid = nNt >= 8 ? (nNt + 7) / 8 * nMt * 8 : nNt * nMt;
@@ -569,7 +577,7 @@ static void launch_conv_gemm_bm(hipStream_t st, const double* Wp, int Mp, const 
 }
 
 template <bool DEN, bool BIASACT>
-static void launch_conv_gemm(hipStream_t st, const double* Wp, int Mp, const double* T, double* Out, const double* bias,
+static void launch_conv_gemm(hipStream_t st, const real* Wp, int Mp, const real* T, real* Out, const real* bias,
                              const ConvGeom& g, int64_t npos, int Kp, int act) {
   const bool cellu = g.Cp % 16 == 0;
   const int bm = conv_pick_bm(Mp);
@@ -589,17 +597,17 @@ static void launch_conv_gemm(hipStream_t st, const double* Wp, int Mp, const dou
 }
 
 // H[e] = act(H[e]) for the activations the GEMM epilogues do not carry (kernels_gemm.h)
-__global__ __launch_bounds__(256) void act_inplace_kernel(double* __restrict__ H, int64_t n, int act) {
+__global__ __launch_bounds__(256) void act_inplace_kernel(real* __restrict__ H, int64_t n, int act) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) H[e] = act_full(H[e], act);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) H[e] = (real)act_full((double)H[e], act);
 }
-void launch_act_inplace(hipStream_t st, double* H, int64_t n, int act) {
+void launch_act_inplace(hipStream_t st, real* H, int64_t n, int act) {
   int64_t b = (n + 255) / 256;
   if (b > 8192) b = 8192;
   hipLaunchKernelGGL(act_inplace_kernel, dim3((unsigned)(b < 1 ? 1 : b)), dim3(256), 0, st, H, n, act);
 }
 
-void launch_conv_forward(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, const ConvGeom& g,
+void launch_conv_forward(hipStream_t st, const real* Wp, const real* bp, const real* In, real* Out, const ConvGeom& g,
                          int COUTp, int Kp, int64_t npos, int act) {
   if (act_is_extra(act)) {   // bias in the GEMM epilogue, the later activation elementwise (pad channels: act(0), as in the fused case)
     launch_conv_gemm<false, true>(st, Wp, COUTp, In, Out, bp, g, npos, Kp, SI_ACT_IDENTITY);
@@ -610,12 +618,12 @@ void launch_conv_forward(hipStream_t st, const double* Wp, const double* bp, con
 }
 
 template <int BM, bool CELLU, bool IDX>
-static void launch_conv_pool_bm(hipStream_t st, const double* Wp, int Mp, const double* T, double* Out, const double* bias,
+static void launch_conv_pool_bm(hipStream_t st, const real* Wp, int Mp, const real* T, real* Out, const real* bias,
                                 const ConvGeom& g, int64_t npos, int Kp, int act, uint8_t* Idx) {
   constexpr int BN = 128, WM = 2, WN = 4, NT = 512;
   using SA = Stager<BM, 0, NT, true>;
   using SB = GatherK<BN, NT, CELLU, false, true>;
-  constexpr size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(double);
+  constexpr size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(real);
   const int nMt = (Mp + BM - 1) / BM;
   const int64_t nNt = (npos + BN - 1) / BN;
   const int64_t grid = nNt >= 8 ? (nNt + 7) / 8 * nMt * 8 : nNt * nMt;
@@ -625,7 +633,7 @@ static void launch_conv_pool_bm(hipStream_t st, const double* Wp, int Mp, const 
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, Wp, Mp, T, Out, bias, g, npos, Kp, act, nMt, nNt, Idx);
 }
 template <bool IDX>
-static void launch_conv_pool_any(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, const ConvGeom& g,
+static void launch_conv_pool_any(hipStream_t st, const real* Wp, const real* bp, const real* In, real* Out, const ConvGeom& g,
                                  int COUTp, int Kp, int64_t npos, int act, uint8_t* Idx) {
   const bool cellu = g.Cp % 16 == 0;
   const int bm = conv_pick_bm(COUTp);
@@ -644,7 +652,7 @@ static void launch_conv_pool_any(hipStream_t st, const double* Wp, const double*
 #undef SI_POOL_CASE
 }
 // conv + bias + act + MaxPool((2, 2), stride 2) -> pooled CWHN tensor; needs even Wo and Ho (the caller checks)
-void launch_conv_forward_pool2(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, const ConvGeom& g,
+void launch_conv_forward_pool2(hipStream_t st, const real* Wp, const real* bp, const real* In, real* Out, const ConvGeom& g,
                                int COUTp, int Kp, int64_t npos, int act) {
   if (act_is_extra(act)) {   // increasing activations commute with the maximum: pool the pre-activations, finish on the pooled tensor
     launch_conv_forward_pool2(st, Wp, bp, In, Out, g, COUTp, Kp, npos, SI_ACT_IDENTITY);
@@ -659,7 +667,7 @@ void launch_conv_forward_pool2(hipStream_t st, const double* Wp, const double* b
 }
 // the same in GRADIENT mode (identity / relu / tanh / sigmoid only): also the window index the reverse sweep needs (one byte per
 // pooled element, Idx[m + COUTp * window]); the un-pooled activation is neither stored nor read again
-void launch_conv_forward_pool2_idx(hipStream_t st, const double* Wp, const double* bp, const double* In, double* Out, uint8_t* Idx,
+void launch_conv_forward_pool2_idx(hipStream_t st, const real* Wp, const real* bp, const real* In, real* Out, uint8_t* Idx,
                                    const ConvGeom& g, int COUTp, int Kp, int64_t npos, int act) {
   if (conv_first_applies(g, COUTp)) {
     launch_conv_first<true>(st, Wp, bp, In, Out, Idx, g, COUTp, Kp, npos, act);
@@ -668,7 +676,8 @@ void launch_conv_forward_pool2_idx(hipStream_t st, const double* Wp, const doubl
   launch_conv_pool_any<true>(st, Wp, bp, In, Out, g, COUTp, Kp, npos, act, Idx);
 }
 
-void launch_conv_backward_data(hipStream_t st, const double* Wt, const double* Delta, double* dX, const ConvGeom& gT, int CINp,
+#ifndef SI_CONV_F32   // (reverse sweep: fp64 only)
+void launch_conv_backward_data(hipStream_t st, const real* Wt, const real* Delta, real* dX, const ConvGeom& gT, int CINp,
                                int KpT, int64_t npos_in) {
   if (gT.sden_w > 1 || gT.sden_h > 1)
     launch_conv_gemm<true, false>(st, Wt, CINp, Delta, dX, nullptr, gT, npos_in, KpT, 0);
@@ -707,12 +716,12 @@ int conv_dw_max_splits(int COUTp, int Kp, int64_t npos, int num_cu) {
 }
 
 template <int BM, int BN, int MINW>
-static void launch_conv_dw_bm(hipStream_t st, const double* Delta, int Mp, const double* In, double* part, const ConvGeom& g,
+static void launch_conv_dw_bm(hipStream_t st, const real* Delta, int Mp, const real* In, real* part, const ConvGeom& g,
                               int64_t npos, int Kp, int nsplit, int64_t ksplit) {
   constexpr int WM = 2, WN = 4, NT = 512;
   using SA = Stager<BM, 0, NT, true>;
   using SB = GatherN<BN, NT>;
-  constexpr size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(double);
+  constexpr size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(real);
   const int nMt = (Mp + BM - 1) / BM, nNt = (Kp + BN - 1) / BN;
   if (npos % 16 == 0) {   // (ksplit is a multiple of 16 by construction)
     auto kern = conv_dw_kernel<BM, BN, WM, WN, MINW, true>;
@@ -729,7 +738,7 @@ static void launch_conv_dw_bm(hipStream_t st, const double* Delta, int Mp, const
   }
 }
 
-void launch_conv_backward_weight(hipStream_t st, const double* Delta, const double* In, double* part, const ConvGeom& g,
+void launch_conv_backward_weight(hipStream_t st, const real* Delta, const real* In, real* part, const ConvGeom& g,
                                  int COUTp, int Kp, int64_t npos, int nsplit, int64_t ksplit) {
   if (conv_dw_narrow(COUTp, Kp)) {
     launch_conv_dw_bm<64, 64, 6>(st, Delta, COUTp, In, part, g, npos, Kp, nsplit, ksplit);
@@ -743,16 +752,12 @@ void launch_conv_backward_weight(hipStream_t st, const double* Delta, const doub
 }
 
 // ------------------------------------------------------------------------------------------------ index kernels
-static unsigned idx_grid(int64_t n) {
-  int64_t b = (n + 255) / 256;
-  if (b > 4096) b = 4096;
-  return (unsigned)(b < 1 ? 1 : b);
-}
 
+#endif
 // Wp[co + COUTp*k'] = w[(KW-1-a) + KW*((KH-1-c) + KH*(cin + CIN*co))],  k' = cin + CINp*(a + KW*c); zeros elsewhere.
 // bp[co] = b[co] (0 for the pad channel).
-__global__ __launch_bounds__(256) void conv_pack_kernel(const double* __restrict__ w, const double* __restrict__ b,
-                                                        double* __restrict__ Wp, double* __restrict__ bp, int KW, int KH, int CIN,
+__global__ __launch_bounds__(256) void conv_pack_kernel(const real* __restrict__ w, const real* __restrict__ b,
+                                                        real* __restrict__ Wp, real* __restrict__ bp, int KW, int KH, int CIN,
                                                         int COUT, int CINp, int COUTp, int Kp) {
   const int64_t total = (int64_t)COUTp * Kp;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -760,21 +765,22 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const double* __restrict
     const int co = (int)(e % COUTp), kp = (int)(e / COUTp);
     const int cell = kp / CINp, cin = kp - cell * CINp;
     const int c = cell / KW, a = cell - c * KW;
-    double v = 0.0;
+    real v = 0.0;
     if (co < COUT && cin < CIN && c < KH) v = w[(KW - 1 - a) + KW * ((KH - 1 - c) + KH * (cin + (int64_t)CIN * co))];
     Wp[e] = v;
     if (e < COUTp) bp[e] = e < COUT ? b[e] : 0.0;
   }
 }
-void launch_conv_pack(hipStream_t st, const double* w, const double* b, double* Wp, double* bp, int KW, int KH, int CIN, int COUT,
+void launch_conv_pack(hipStream_t st, const real* w, const real* b, real* Wp, real* bp, int KW, int KH, int CIN, int COUT,
                       int CINp, int COUTp, int Kp) {
   hipLaunchKernelGGL(conv_pack_kernel, dim3(idx_grid((int64_t)COUTp * Kp)), dim3(256), 0, st, w, b, Wp, bp, KW, KH, CIN, COUT,
                      CINp, COUTp, Kp);
 }
 
+#ifndef SI_CONV_F32   // (reverse sweep: fp64 only)
 // data gradient: dX[cin, pin] = sum_{co, a', c'} Wt[cin + CINp*k''] * Delta[co, (pin + pad' ... )],  k'' = co + COUTp*(a' + KW*c'),
 // Wt = w[a' + KW*(c' + KH*(cin + CIN*co))]  (the forward kernel flipped twice = not flipped)
-__global__ __launch_bounds__(256) void conv_pack_t_kernel(const double* __restrict__ w, double* __restrict__ Wt, int KW, int KH,
+__global__ __launch_bounds__(256) void conv_pack_t_kernel(const real* __restrict__ w, real* __restrict__ Wt, int KW, int KH,
                                                           int CIN, int COUT, int CINp, int COUTp, int KpT) {
   const int64_t total = (int64_t)CINp * KpT;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -782,36 +788,36 @@ __global__ __launch_bounds__(256) void conv_pack_t_kernel(const double* __restri
     const int cin = (int)(e % CINp), kp = (int)(e / CINp);
     const int cell = kp / COUTp, co = kp - cell * COUTp;
     const int c = cell / KW, a = cell - c * KW;
-    double v = 0.0;
+    real v = 0.0;
     if (co < COUT && cin < CIN && c < KH) v = w[a + KW * (c + KH * (cin + (int64_t)CIN * co))];
     Wt[e] = v;
   }
 }
-void launch_conv_pack_t(hipStream_t st, const double* w, double* Wt, int KW, int KH, int CIN, int COUT, int CINp, int COUTp,
+void launch_conv_pack_t(hipStream_t st, const real* w, real* Wt, int KW, int KH, int CIN, int COUT, int CINp, int COUTp,
                         int KpT) {
   hipLaunchKernelGGL(conv_pack_t_kernel, dim3(idx_grid((int64_t)CINp * KpT)), dim3(256), 0, st, w, Wt, KW, KH, CIN, COUT, CINp,
                      COUTp, KpT);
 }
 
 // gw[(KW-1-a) + KW*((KH-1-c) + KH*(cin + CIN*co))] = sum_split part[split][co + COUTp*k'],  fixed order
-__global__ __launch_bounds__(256) void conv_unpack_dw_kernel(const double* __restrict__ part, int nsplit, double* __restrict__ gw,
+__global__ __launch_bounds__(256) void conv_unpack_dw_kernel(const real* __restrict__ part, int nsplit, real* __restrict__ gw,
                                                              int KW, int KH, int CIN, int COUT, int CINp, int COUTp, int Kp) {
   // walks the SOURCE order (co fastest: coalesced reads of the nsplit partial planes, which are 14-768x the bytes of the
   // result) and scatters the 8-byte results; in destination order every read touched its own cache line (0.6 TB/s).
   // Block = 32 source elements x 8 split phases: phase j adds splits j, j + 8, ... in order, the eight phase sums are added
   // in a fixed tree (a first layer has 3072 elements and 768 splits: one thread per element was 768 dependent loads).
-  __shared__ double red[8][33];
+  __shared__ real red[8][33];
   const int64_t plane = (int64_t)COUTp * Kp;
   const int il = threadIdx.x & 31, cl = threadIdx.x >> 5;
   for (int64_t s0 = (int64_t)blockIdx.x * 32; s0 < plane; s0 += (int64_t)gridDim.x * 32) {
     const int64_t src = s0 + il;
-    double s = 0.0;
+    real s = 0.0;
     if (src < plane)
       for (int sp = cl; sp < nsplit; sp += 8) s += part[(int64_t)sp * plane + src];
     red[cl][il] = s;
     __syncthreads();
     if (cl == 0 && src < plane) {
-      const double t = ((red[0][il] + red[1][il]) + (red[2][il] + red[3][il])) + ((red[4][il] + red[5][il]) + (red[6][il] + red[7][il]));
+      const real t = ((red[0][il] + red[1][il]) + (red[2][il] + red[3][il])) + ((red[4][il] + red[5][il]) + (red[6][il] + red[7][il]));
       const int co = (int)(src % COUTp), kp = (int)(src / COUTp);
       const int cell = kp / CINp, cin = kp - cell * CINp;
       const int c = cell / KW, a = cell - c * KW;
@@ -821,15 +827,16 @@ __global__ __launch_bounds__(256) void conv_unpack_dw_kernel(const double* __res
     __syncthreads();
   }
 }
-void launch_conv_unpack_dw(hipStream_t st, const double* part, int nsplit, double* gw, int KW, int KH, int CIN, int COUT,
+void launch_conv_unpack_dw(hipStream_t st, const real* part, int nsplit, real* gw, int KW, int KH, int CIN, int COUT,
                            int CINp, int COUTp, int Kp) {
   const int64_t blocks = std::min<int64_t>(8192, ((int64_t)COUTp * Kp + 31) / 32);
   hipLaunchKernelGGL(conv_unpack_dw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, nsplit, gw, KW, KH, CIN, COUT, CINp,
                      COUTp, Kp);
 }
 
+#endif
 // (W, H, C, N) column-major  ->  channel-fastest with pitch Cp (pad channels zero)
-__global__ __launch_bounds__(256) void whcn_to_cwhn_kernel(const double* __restrict__ X, double* __restrict__ Xc, int W, int H,
+__global__ __launch_bounds__(256) void whcn_to_cwhn_kernel(const real* __restrict__ X, real* __restrict__ Xc, int W, int H,
                                                            int C, int Cp, int64_t B) {
   const int64_t total = (int64_t)Cp * W * H * B;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -842,11 +849,11 @@ __global__ __launch_bounds__(256) void whcn_to_cwhn_kernel(const double* __restr
     Xc[e] = c < C ? X[sp + (int64_t)wh * (c + (int64_t)C * n)] : 0.0;
   }
 }
-void launch_whcn_to_cwhn(hipStream_t st, const double* X, double* Xc, int W, int H, int C, int Cp, int64_t B) {
+void launch_whcn_to_cwhn(hipStream_t st, const real* X, real* Xc, int W, int H, int C, int Cp, int64_t B) {
   hipLaunchKernelGGL(whcn_to_cwhn_kernel, dim3(idx_grid((int64_t)Cp * W * H * B)), dim3(256), 0, st, X, Xc, W, H, C, Cp, B);
 }
 // channel-fastest (pitch Cp) -> the reference's flatten order  w + W*(h + H*c)  per observation
-__global__ __launch_bounds__(256) void cwhn_to_whcn_kernel(const double* __restrict__ Xc, double* __restrict__ X, int W, int H,
+__global__ __launch_bounds__(256) void cwhn_to_whcn_kernel(const real* __restrict__ Xc, real* __restrict__ X, int W, int H,
                                                            int C, int Cp, int64_t B) {
   const int64_t total = (int64_t)C * W * H * B;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -859,12 +866,12 @@ __global__ __launch_bounds__(256) void cwhn_to_whcn_kernel(const double* __restr
     X[e] = Xc[c + (int64_t)Cp * (sp + (int64_t)wh * n)];
   }
 }
-void launch_cwhn_to_whcn(hipStream_t st, const double* Xc, double* X, int W, int H, int C, int Cp, int64_t B) {
+void launch_cwhn_to_whcn(hipStream_t st, const real* Xc, real* X, int W, int H, int C, int Cp, int64_t B) {
   hipLaunchKernelGGL(cwhn_to_whcn_kernel, dim3(idx_grid((int64_t)C * W * H * B)), dim3(256), 0, st, Xc, X, W, H, C, Cp, B);
 }
 
 // MaxPool on the channel-fastest layout
-__global__ __launch_bounds__(256) void maxpool_kernel(const double* __restrict__ In, double* __restrict__ Out, int Cp, int Wi, int Hi,
+__global__ __launch_bounds__(256) void maxpool_kernel(const real* __restrict__ In, real* __restrict__ Out, int Cp, int Wi, int Hi,
                                                       int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B) {
   const int64_t total = (int64_t)Cp * Wo * Ho * B;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -875,28 +882,29 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const double* __restrict__
     t /= Wo;
     const int ho = (int)(t % Ho);
     const int64_t n = t / Ho;
-    const double* src = In + c + (int64_t)Cp * ((int64_t)Wi * Hi * n);
-    double m = -__builtin_inf();
+    const real* src = In + c + (int64_t)Cp * ((int64_t)Wi * Hi * n);
+    real m = -__builtin_inf();
     for (int d = 0; d < PH; ++d)
       for (int a = 0; a < PW; ++a) {
-        const double v = src[(int64_t)Cp * ((wo * sw + a) + Wi * (ho * sh + d))];
+        const real v = src[(int64_t)Cp * ((wo * sw + a) + Wi * (ho * sh + d))];
         m = v > m ? v : m;
       }
     Out[e] = m;
   }
 }
-void launch_maxpool(hipStream_t st, const double* In, double* Out, int Cp, int Wi, int Hi, int Wo, int Ho, int PW, int PH, int sw,
+void launch_maxpool(hipStream_t st, const real* In, real* Out, int Cp, int Wi, int Hi, int Wo, int Ho, int PW, int PH, int sw,
                     int sh, int64_t B) {
   hipLaunchKernelGGL(maxpool_kernel, dim3(idx_grid((int64_t)Cp * Wo * Ho * B)), dim3(256), 0, st, In, Out, Cp, Wi, Hi, Wo, Ho, PW,
                      PH, sw, sh, B);
 }
+#ifndef SI_CONV_F32   // (reverse sweep: fp64 only)
 // MaxPool gradient [upstream NNlib 0.7.23 src/impl/pooling_direct.jl `∇maxpool_direct!`, from memory]: for each window the
 // inputs are walked `for kh in 1:kernel_h, kw in 1:kernel_w` (kw fastest) and the window's gradient goes to the FIRST input
 // with `y ≈ x` (`maxpool_already_chosen`; isapprox: rtol = sqrt(eps), atol = 0) -- ONE element per window, not every
 // element equal to the maximum: exact ties (constant image regions -> conv output = bias) would otherwise count 4 times.
 // does input (a, d) of the window whose first input is at `win0` (element stride `es`, row stride `rs`) receive the
 // window's gradient?  x = that input's value, ymax = the window's stored maximum
-__device__ __forceinline__ bool pool_chosen(const double* __restrict__ win0, int64_t es, int64_t rs, double x, double ymax, int a,
+__device__ __forceinline__ bool pool_chosen(const real* __restrict__ win0, int64_t es, int64_t rs, real x, real ymax, int a,
                                             int d, int PW) {
   if (!pool_approx(ymax, x)) return false;
   for (int dd = 0; dd <= d; ++dd) {
@@ -906,8 +914,8 @@ __device__ __forceinline__ bool pool_chosen(const double* __restrict__ win0, int
   }
   return true;
 }
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const double* __restrict__ In, const double* __restrict__ Out,
-                                                          const double* __restrict__ Gout, double* __restrict__ Gin, int Cp, int Wi,
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const real* __restrict__ In, const real* __restrict__ Out,
+                                                          const real* __restrict__ Gout, real* __restrict__ Gin, int Cp, int Wi,
                                                           int Hi, int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B) {
   const int64_t total = (int64_t)Cp * Wi * Hi * B;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -918,8 +926,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const double* __restri
     t /= Wi;
     const int hi = (int)(t % Hi);
     const int64_t n = t / Hi;
-    const double x = In[e];
-    double gsum = 0.0;
+    const real x = In[e];
+    real gsum = 0.0;
     // windows (wo, ho) with wo*sw <= wi < wo*sw + PW
     const int wo_hi = wi / sw, ho_hi = hi / sh;
     for (int ho = ho_hi; ho >= 0 && ho * sh + PH > hi; --ho) {
@@ -927,26 +935,26 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const double* __restri
       for (int wo = wo_hi; wo >= 0 && wo * sw + PW > wi; --wo) {
         if (wo >= Wo) continue;
         const int64_t o = c + (int64_t)Cp * (wo + (int64_t)Wo * (ho + (int64_t)Ho * n));
-        const double* win0 = In + c + (int64_t)Cp * ((wo * sw) + (int64_t)Wi * ((ho * sh) + (int64_t)Hi * n));
+        const real* win0 = In + c + (int64_t)Cp * ((wo * sw) + (int64_t)Wi * ((ho * sh) + (int64_t)Hi * n));
         if (pool_chosen(win0, Cp, (int64_t)Cp * Wi, x, Out[o], wi - wo * sw, hi - ho * sh, PW)) gsum += Gout[o];
       }
     }
     Gin[e] = gsum;
   }
 }
-void launch_maxpool_bwd(hipStream_t st, const double* In, const double* Out, const double* Gout, double* Gin, int Cp, int Wi, int Hi,
+void launch_maxpool_bwd(hipStream_t st, const real* In, const real* Out, const real* Gout, real* Gin, int Cp, int Wi, int Hi,
                         int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B) {
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(idx_grid((int64_t)Cp * Wi * Hi * B)), dim3(256), 0, st, In, Out, Gout, Gin, Cp, Wi,
                      Hi, Wo, Ho, PW, PH, sw, sh, B);
 }
 
 // D[e] = G[e] * act'(H[e])   (pre-activation gradient of a layer from the gradient of its output)
-__global__ __launch_bounds__(256) void mul_dact_kernel(const double* __restrict__ G, const double* __restrict__ H, int64_t n, int act,
-                                                       double* __restrict__ D) {
+__global__ __launch_bounds__(256) void mul_dact_kernel(const real* __restrict__ G, const real* __restrict__ H, int64_t n, int act,
+                                                       real* __restrict__ D) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) D[e] = G[e] * dact_full(H[e], act);
 }
-void launch_mul_dact(hipStream_t st, const double* G, const double* H, int64_t n, int act, double* D) {
+void launch_mul_dact(hipStream_t st, const real* G, const real* H, int64_t n, int act, real* D) {
   hipLaunchKernelGGL(mul_dact_kernel, dim3(idx_grid(n)), dim3(256), 0, st, G, H, n, act, D);
 }
 
@@ -957,17 +965,17 @@ void launch_mul_dact(hipStream_t st, const double* G, const double* H, int64_t n
 // act'), which saves writing and re-reading the un-pooled gradient.  rows = channels (fastest index), columns = pixels.
 // Fixed-order sums: 4 column phases per chunk, then the chunks in 16 strided groups, each in order (bit-reproducible).
 template <bool POOL>
-__global__ __launch_bounds__(256) void dact_rowsum_kernel(const double* __restrict__ G, const double* __restrict__ H,
-                                                          const double* __restrict__ PoolOut, int rows, int64_t ncols, int64_t per,
-                                                          int act, double* __restrict__ D, double* __restrict__ part, int Wi, int Hi,
+__global__ __launch_bounds__(256) void dact_rowsum_kernel(const real* __restrict__ G, const real* __restrict__ H,
+                                                          const real* __restrict__ PoolOut, int rows, int64_t ncols, int64_t per,
+                                                          int act, real* __restrict__ D, real* __restrict__ part, int Wi, int Hi,
                                                           int Wo, int Ho, int PW, int PH, int sw, int sh) {
-  __shared__ double red[4][64];
+  __shared__ real red[4][64];
   const int il = threadIdx.x & 63, cl = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + il;
   const int64_t b0 = (int64_t)blockIdx.y * per;
   int64_t b1 = b0 + per;
   if (b1 > ncols) b1 = ncols;
-  double s = 0.0;
+  real s = 0.0;
   if (i < rows) {
     int64_t b = b0 + cl;
     int wi = 0, hi = 0, dw = 0, dh = 0;
@@ -984,8 +992,8 @@ __global__ __launch_bounds__(256) void dact_rowsum_kernel(const double* __restri
 #pragma unroll 4
     for (; b < b1; b += 4) {
       const int64_t off = i + (int64_t)rows * b;
-      const double x = H[off];
-      double g;
+      const real x = H[off];
+      real g;
       if constexpr (POOL) {
         g = 0.0;  // the first input (kw fastest) that is ≈ the window's maximum receives its gradient [upstream NNlib, pool_chosen]
         for (int ho = hi / sh; ho >= 0 && ho * sh + PH > hi; --ho) {
@@ -993,7 +1001,7 @@ __global__ __launch_bounds__(256) void dact_rowsum_kernel(const double* __restri
           for (int wo = wi / sw; wo >= 0 && wo * sw + PW > wi; --wo) {
             if (wo >= Wo) continue;
             const int64_t o = i + (int64_t)rows * (wo + (int64_t)Wo * (ho + (int64_t)Ho * n));
-            const double* win0 = H + i + (int64_t)rows * ((wo * sw) + (int64_t)Wi * ((ho * sh) + (int64_t)Hi * n));
+            const real* win0 = H + i + (int64_t)rows * ((wo * sw) + (int64_t)Wi * ((ho * sh) + (int64_t)Hi * n));
             if (pool_chosen(win0, rows, (int64_t)rows * Wi, x, PoolOut[o], wi - wo * sw, hi - ho * sh, PW)) g += G[o];
           }
         }
@@ -1011,7 +1019,7 @@ __global__ __launch_bounds__(256) void dact_rowsum_kernel(const double* __restri
       } else {
         g = G[off];
       }
-      const double d = g * dact_full(x, act);
+      const real d = g * dact_full(x, act);
       D[off] = d;
       s += d;
     }
@@ -1020,12 +1028,12 @@ __global__ __launch_bounds__(256) void dact_rowsum_kernel(const double* __restri
   __syncthreads();
   if (cl == 0 && i < rows) part[(int64_t)blockIdx.y * rows + i] = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
 }
-__global__ __launch_bounds__(1024) void rowsum_chunks_final_kernel(const double* __restrict__ part, int rows, int nchunks, int nout,
-                                                                   double* __restrict__ db) {
-  __shared__ double red[16][64];
+__global__ __launch_bounds__(1024) void rowsum_chunks_final_kernel(const real* __restrict__ part, int rows, int nchunks, int nout,
+                                                                   real* __restrict__ db) {
+  __shared__ real red[16][64];
   const int il = threadIdx.x & 63, cl = threadIdx.x >> 6;  // 16 strided groups of chunks, each summed in order
   const int i = blockIdx.x * 64 + il;
-  double s = 0.0;
+  real s = 0.0;
   if (i < nout) {
 #pragma unroll 8
     for (int ch = cl; ch < nchunks; ch += 16) s += part[(int64_t)ch * rows + i];
@@ -1033,7 +1041,7 @@ __global__ __launch_bounds__(1024) void rowsum_chunks_final_kernel(const double*
   red[cl][il] = s;
   __syncthreads();
   if (cl == 0 && i < nout) {
-    double t = 0.0;
+    real t = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += red[q][il];
     db[i] = t;
@@ -1048,8 +1056,8 @@ static int dact_rowsum_chunks(int rows, int64_t ncols) {
 }
 size_t dact_rowsum_ws_elems(int max_rows) { return (size_t)4096 * 64 + (size_t)128 * (size_t)max_rows + 64; }
 // D may alias G (in place).  db receives the first `nout` row sums (nout <= rows: pad channels are dropped).
-void launch_mul_dact_rowsum(hipStream_t st, const double* G, const double* H, int rows, int64_t ncols, int act, double* D, double* part,
-                            int nout, double* db) {
+void launch_mul_dact_rowsum(hipStream_t st, const real* G, const real* H, int rows, int64_t ncols, int act, real* D, real* part,
+                            int nout, real* db) {
   const int nch = dact_rowsum_chunks(rows, ncols);
   const int64_t per = (ncols + nch - 1) / nch;
   hipLaunchKernelGGL(dact_rowsum_kernel<false>, dim3((rows + 63) / 64, nch), dim3(256), 0, st, G, H, nullptr, rows, ncols, per, act, D,
@@ -1057,9 +1065,9 @@ void launch_mul_dact_rowsum(hipStream_t st, const double* G, const double* H, in
   hipLaunchKernelGGL(rowsum_chunks_final_kernel, dim3((nout + 63) / 64), dim3(1024), 0, st, part, rows, nch, nout, db);
 }
 // MaxPool gradient + act' + bias row sum of the conv layer in front of the pool, one pass (D must not alias anything).
-void launch_maxpool_bwd_dact_rowsum(hipStream_t st, const double* In, const double* Out, const double* Gout, double* D, int Cp, int Wi,
-                                    int Hi, int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B, int act, double* part, int nout,
-                                    double* db) {
+void launch_maxpool_bwd_dact_rowsum(hipStream_t st, const real* In, const real* Out, const real* Gout, real* D, int Cp, int Wi,
+                                    int Hi, int Wo, int Ho, int PW, int PH, int sw, int sh, int64_t B, int act, real* part, int nout,
+                                    real* db) {
   const int64_t ncols = (int64_t)Wi * Hi * B;
   const int nch = dact_rowsum_chunks(Cp, ncols);
   const int64_t per = (ncols + nch - 1) / nch;
@@ -1081,17 +1089,17 @@ void launch_maxpool_bwd_dact_rowsum(hipStream_t st, const double* In, const doub
 // writes the 4 * 8 bytes of D: 3.2 GB instead of 5.3 GB behind the first layer of the cfg4 CNN, and the forward no longer
 // writes (2.1 GB) and re-reads (MaxPool pass, 2.1 GB) the un-pooled activation.  Same block shape and fixed-order sums as
 // dact_rowsum_kernel: 64 rows x 4 window phases, chunks of windows in grid.y.
-__global__ __launch_bounds__(256) void pool2_bwd_idx_kernel(const double* __restrict__ G, const double* __restrict__ Hp,
+__global__ __launch_bounds__(256) void pool2_bwd_idx_kernel(const real* __restrict__ G, const real* __restrict__ Hp,
                                                             const uint8_t* __restrict__ Idx, int rows, int64_t nwin, int64_t per,
-                                                            int act, double* __restrict__ D, double* __restrict__ part, int W2,
+                                                            int act, real* __restrict__ D, real* __restrict__ part, int W2,
                                                             int H2) {
-  __shared__ double red[4][64];
+  __shared__ real red[4][64];
   const int il = threadIdx.x & 63, cl = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + il;
   const int64_t b0 = (int64_t)blockIdx.y * per;
   int64_t b1 = b0 + per;
   if (b1 > nwin) b1 = nwin;
-  double s = 0.0;
+  real s = 0.0;
   if (i < rows) {
     int64_t b = b0 + cl;
     // window (w2, h2, image n) of index b, advanced by 4 windows per iteration (one carry per digit)
@@ -1105,11 +1113,11 @@ __global__ __launch_bounds__(256) void pool2_bwd_idx_kernel(const double* __rest
 #pragma unroll 2
     for (; b < b1; b += 4) {
       const int64_t off = i + (int64_t)rows * b;
-      const double d = G[off] * conv_dact(Hp[off], act);
+      const real d = G[off] * conv_dact(Hp[off], act);
       const int k = Idx[off];
       s += k < 4 ? d : 0.0;   // (k = 4: no input was ≈ the maximum, e.g. a NaN -- nothing is routed, as in the reference)
       const int64_t p00 = (2 * w2) + (int64_t)Wf * ((2 * h2) + (int64_t)Hf * n);
-      double* dst = D + i + (int64_t)rows * p00;
+      real* dst = D + i + (int64_t)rows * p00;
       dst[0] = k == 0 ? d : 0.0;
       dst[rows] = k == 1 ? d : 0.0;
       dst[(int64_t)rows * Wf] = k == 2 ? d : 0.0;
@@ -1131,8 +1139,8 @@ __global__ __launch_bounds__(256) void pool2_bwd_idx_kernel(const double* __rest
   __syncthreads();
   if (cl == 0 && i < rows) part[(int64_t)blockIdx.y * rows + i] = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
 }
-void launch_pool2_bwd_idx(hipStream_t st, const double* G, const double* Hp, const uint8_t* Idx, double* D, int Cp, int W2, int H2,
-                          int64_t B, int act, double* part, int nout, double* db) {
+void launch_pool2_bwd_idx(hipStream_t st, const real* G, const real* Hp, const uint8_t* Idx, real* D, int Cp, int W2, int H2,
+                          int64_t B, int act, real* part, int nout, real* db) {
   const int64_t nwin = (int64_t)W2 * H2 * B;
   const int nch = dact_rowsum_chunks(Cp, nwin);
   const int64_t per = (nwin + nch - 1) / nch;
@@ -1140,34 +1148,35 @@ void launch_pool2_bwd_idx(hipStream_t st, const double* G, const double* Hp, con
   hipLaunchKernelGGL(rowsum_chunks_final_kernel, dim3((nout + 63) / 64), dim3(1024), 0, st, part, Cp, nch, nout, db);
 }
 
+#endif
 // Dense layer with a NARROW output (out <= 16: the 10-class head of a CNN) on a small batch.  The MFMA kernel gives such a
 // layer one 32-row tile per 128 columns -- 32 workgroups at B = 4096, each walking all of `in` as one dependent chain of k
 // tiles (0.22 ms for 4096 -> 10 at B = 4096, 0.6 TB/s).  Here a WAVE owns CW columns: lanes stride over k (coalesced reads
 // of the activation column and of W's 8*out-byte rows), out * CW accumulators per lane, one butterfly reduction at the end.
 // Fixed summation order (k = lane, lane + 64, ... then the xor butterfly): bit-reproducible.
 template <int CW>
-__global__ __launch_bounds__(256) void dense_narrow_kernel(const double* __restrict__ W, const double* __restrict__ bias,
-                                                           const double* __restrict__ Hin, double* __restrict__ Hout, int out, int in,
+__global__ __launch_bounds__(256) void dense_narrow_kernel(const real* __restrict__ W, const real* __restrict__ bias,
+                                                           const real* __restrict__ Hin, real* __restrict__ Hout, int out, int in,
                                                            int64_t B, int act) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * CW;
   if (b0 >= B) return;
-  double acc[CW][16];
+  real acc[CW][16];
 #pragma unroll
   for (int c = 0; c < CW; ++c)
 #pragma unroll
     for (int o = 0; o < 16; ++o) acc[c][o] = 0.0;
-  const double* hcol[CW];
+  const real* hcol[CW];
 #pragma unroll
   for (int c = 0; c < CW; ++c) hcol[c] = Hin + (int64_t)in * (b0 + c < B ? b0 + c : B - 1);
   for (int k = lane; k < in; k += 64) {
-    double h[CW];
+    real h[CW];
 #pragma unroll
     for (int c = 0; c < CW; ++c) h[c] = hcol[c][k];
-    const double* wk = W + (int64_t)out * k;
+    const real* wk = W + (int64_t)out * k;
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
-      const double wv = o < out ? wk[o] : 0.0;
+      const real wv = o < out ? wk[o] : 0.0;
 #pragma unroll
       for (int c = 0; c < CW; ++c) acc[c][o] = fma(wv, h[c], acc[c][o]);
     }
@@ -1176,25 +1185,27 @@ __global__ __launch_bounds__(256) void dense_narrow_kernel(const double* __restr
   for (int c = 0; c < CW; ++c)
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
-      double v = acc[c][o];
+      real v = acc[c][o];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
       acc[c][o] = v;
     }
   if (lane < 16 * CW) {
     const int c = lane >> 4, o = lane & 15;
-    double v = 0.0;
+    real v = 0.0;
 #pragma unroll
     for (int cc = 0; cc < CW; ++cc)
 #pragma unroll
       for (int oo = 0; oo < 16; ++oo)
         if (cc == c && oo == o) v = acc[cc][oo];
-    if (o < out && b0 + c < B) Hout[o + (int64_t)out * (b0 + c)] = act_full(v + bias[o], act);
+    if (o < out && b0 + c < B) Hout[o + (int64_t)out * (b0 + c)] = (real)act_full((double)(v + bias[o]), act);
   }
 }
 // true when the narrow kernel is the better choice: few MFMA workgroups and a long k chain
+#ifndef SI_CONV_F32
 bool dense_narrow_applies(int out, int in, int64_t B, int num_cu) { return out <= 16 && in >= 256 && (B + 127) / 128 < 2 * (int64_t)num_cu; }
-void launch_dense_narrow(hipStream_t st, const double* W, const double* bias, const double* Hin, double* Hout, int out, int in, int64_t B,
+#endif
+void launch_dense_narrow(hipStream_t st, const real* W, const real* bias, const real* Hin, real* Hout, int out, int in, int64_t B,
                          int act) {
   constexpr int CW = 2;
   const int64_t blocks = (B + 4 * CW - 1) / (4 * CW);

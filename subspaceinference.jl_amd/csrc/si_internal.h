@@ -237,6 +237,7 @@ struct Ctx {
   NetPlan plan;
   double* d_Xc = nullptr;      // X re-laid channel-fastest (input_spatial)
   double* d_wpack = nullptr;   // packed conv weights of the current evaluation
+  float* d_wpack32 = nullptr;  // the same in fp32 (compute_dtype = SI_F32 on a Conv chain)
   NetScratch g_scratch;
   std::vector<uint8_t*> d_pidx;  // per layer: window-index bytes of a Conv layer fused with its MaxPool (gradient workspace)
   // sampler state (device)
@@ -503,6 +504,21 @@ void launch_maxpool_bwd(hipStream_t st, const double* In, const double* Out, con
 void launch_mul_dact(hipStream_t st, const double* G, const double* H, int64_t n, int act, double* D);
 size_t dact_rowsum_ws_elems(int max_rows);
 void launch_act_inplace(hipStream_t st, double* H, int64_t n, int act);
+// the same forward kernels on fp32 operands (kernels_conv.hip compiled a second time with -DSI_CONV_F32: v_mfma_f32_16x16x4_f32,
+// the same stagers, LDS images and index maps) -- compute_dtype = SI_F32 on Conv chains
+void launch_conv_pack(hipStream_t st, const float* w, const float* b, float* Wp, float* bp, int KW, int KH, int CIN, int COUT, int CINp,
+                      int COUTp, int Kp);
+void launch_conv_forward(hipStream_t st, const float* Wp, const float* bp, const float* In, float* Out, const ConvGeom& g, int COUTp,
+                         int Kp, int64_t npos, int act);
+void launch_conv_forward_pool2(hipStream_t st, const float* Wp, const float* bp, const float* In, float* Out, const ConvGeom& g,
+                               int COUTp, int Kp, int64_t npos, int act);
+void launch_whcn_to_cwhn(hipStream_t st, const float* X, float* Xc, int W, int H, int C, int Cp, int64_t B);
+void launch_cwhn_to_whcn(hipStream_t st, const float* Xc, float* X, int W, int H, int C, int Cp, int64_t B);
+void launch_maxpool(hipStream_t st, const float* In, float* Out, int Cp, int Wi, int Hi, int Wo, int Ho, int PW, int PH, int sw, int sh,
+                    int64_t B);
+void launch_act_inplace(hipStream_t st, float* H, int64_t n, int act);
+void launch_dense_narrow(hipStream_t st, const float* W, const float* bias, const float* Hin, float* Hout, int out, int in, int64_t B,
+                         int act);
 bool dense_narrow_applies(int out, int in, int64_t B, int num_cu);
 void launch_dense_narrow(hipStream_t st, const double* W, const double* bias, const double* Hin, double* Hout, int out, int in, int64_t B,
                          int act);
@@ -521,6 +537,8 @@ void net_input(Ctx* c, const NetPlan& p, const double* X, double* Xc, int64_t B)
 // kernel, and *final_out is the buffer that holds the last layer's output.
 // pidx != nullptr (gradient mode, outs[l] per layer): a Conv layer with net_grad_fused(p, l) runs fused with its MaxPool, writes
 // outs[l + 1] and pidx[l] and leaves outs[l] untouched (it may be nullptr)
+int32_t net_forward_f32(Ctx* c, const NetPlan& p, const float* w, const float* xin, int64_t B, float* const* outs, float* wpack,
+                        float** final_out);
 int32_t net_forward(Ctx* c, const NetPlan& p, const double* w, const double* xin, int64_t B, double* const* outs, double* wpack,
                     bool pingpong = false, double** final_out = nullptr, uint8_t* const* pidx = nullptr);
 // Conv layer l directly followed by MaxPool((2, 2), stride 2) on even sizes, activation carried by the GEMM epilogue: in

@@ -72,14 +72,41 @@ def test_f32_forward_and_lp_vs_fp64_oracle(si, gpu_ctx, dims, acts, b):
     assert np.array_equal(gpu_ctx.logdensity(z), lp)
 
 
-def test_f32_refused_for_conv_chains(si, gpu_ctx):
+def _conv_cases():
+    from tests.test_gpu_conv import CASES
+    return CASES
+
+
+@pytest.mark.parametrize("case", range(15))
+def test_f32_conv_chains_vs_fp64_oracle(si, gpu_ctx, case):
+    """compute_dtype = SI_F32 on Conv / MaxPool / flatten chains (round 5; kernels_conv.hip compiled for fp32 operands on
+    v_mfma_f32_16x16x4_f32, the Dense layers behind flatten on kernels_gemm_f32.hip; squared errors in fp64): model outputs within
+    5e-5 of their scale and lp within rtol 1e-5 of the fp64 oracle on every CNN case of tests/test_gpu_conv.py -- strided, dilated,
+    padded convolutions, fused and un-fused pools, odd sizes, ragged tiles, every activation.  The reverse sweep stays fp64: a
+    gradient on such a set-up is refused with a message."""
     from subspaceinference_jl_amd import _capi
-    spec = [("conv", (3, 3), 4, 1, (1, 1), (1, 1)), ("maxpool", (2, 2)), ("flatten",), ("dense", 3, 0)]
-    table, n = so.conv_table(spec, (8, 8, 2))
-    rng = np.random.default_rng(0)
+    from tests.test_gpu_conv import CASES, _problem
+    if case >= len(CASES):
+        pytest.skip("no such case")
+    whc, spec, b = CASES[case]
+    m = 3
+    table, n, w_swa, p, x, y = _problem(whc, spec, b, m, seed=case)
+    gpu_ctx.infer_setup(table, n, m, w_swa, p, x, y, 0.8, compute_dtype=_capi.SI_F32)
+    z = np.asfortranarray(0.2 * np.random.default_rng(99).standard_normal((m, 2)))
+    yh = gpu_ctx.forward(z[:, 0])
+    ref = so.forward(table, w_swa + p @ z[:, 0], x)
+    err = np.abs(yh - ref).max() / max(1.0, np.abs(ref).max())
+    lp = gpu_ctx.logdensity(z)
+    lp_ref = np.array([so.logdensity(table, w_swa, p, x, y, 0.8, z[:, c]) for c in range(2)])
+    rel = np.abs(lp / lp_ref - 1.0).max()
+    print("f32 conv case %d: max |y - y_ref| / scale = %.2e, lp rel %.2e" % (case, err, rel))
+    assert err <= 5e-5 and rel <= 1e-5
+    assert np.array_equal(lp, gpu_ctx.logdensity(z))         # same inputs, same bits
+    zc, lpc, _ = gpu_ctx.sample_rwmh(6, 0.05, seed=3, nchains=2)
+    z1, lp1, _ = gpu_ctx.sample_rwmh(6, 0.05, seed=3, chain_id0=1, nchains=1)
+    assert np.array_equal(zc[:, :, 1], z1[:, :, 0]) and np.array_equal(lpc[:, 1], lp1[:, 0])
     with pytest.raises(si.SubspaceError, match="SI_F32"):
-        gpu_ctx.infer_setup(table, n, 2, rng.standard_normal(n), rng.standard_normal((n, 2)), rng.standard_normal((128, 5)),
-                            rng.standard_normal((3, 5)), 1.0, compute_dtype=_capi.SI_F32)
+        gpu_ctx.logdensity_grad(z[:, 0])
 
 
 def test_f32_rwmh_chain_follows_the_f64_chain_on_a_small_model(si, gpu_ctx):

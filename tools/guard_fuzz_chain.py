@@ -48,6 +48,9 @@ for case in range(cases):
     ctx.set_chain_loop(1)
     spec = any(info[k][0] or info[k][1] for k in info if k[1] in (1, 2))
     nspec += spec
+    # the class of chain_spec.inc (spec_applies): a narrow head, every layer <= 256 wide, <= 96 fragment doubles per lane
+    in_class = dims[-1] <= 4 and max(dims) <= 256 and sum(-(-((o + 15) // 16) // 4) * ((i + 3) // 4 + 1) for i, o in zip(dims[:-2], dims[1:-1])) <= 96
+    assert spec == in_class, (dims, spec, in_class, ctx.chain_kernel_info()[2][:300])
     assert not any(info[k][0] or info[k][1] for k in info if k[1] in (0, 3, 4))
     print("case %d dims %s acts %s B %d M %d: specialised %s %s" % (case, dims, acts, b, m, spec, "" if spec else "(" + ctx.chain_kernel_info()[2][:60] + ")"), flush=True)
 ctx.close()
