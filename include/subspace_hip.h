@@ -101,7 +101,7 @@ typedef struct {
   double bytes[SI_K_COUNT];     /* accumulated ALGORITHMIC HBM bytes per class                 */
 } si_stats;
 
-int32_t si_version(void); /* 500: + narrow-chain fused density / grid loop, si_train_setup_ex; 400: + compute_dtype = SI_F32 (300: RCCL communicator, streamed output map, pipelined host push) */
+int32_t si_version(void); /* 500: + narrow-chain fused density / grid loop (specialised at run time), si_train_setup_ex, SI_F32 on Conv chains; 400: + compute_dtype = SI_F32 (300: RCCL communicator, streamed output map, pipelined host push) */
 
 /* ---- context ------------------------------------------------------------------------------- */
 int32_t si_create(si_ctx** out, int32_t device_id);
@@ -198,16 +198,21 @@ int32_t si_construct_get_A(si_ctx* ctx, int64_t k0, int64_t nk, double* A_out);
  * column-major fp64.
  * compute_dtype: SI_F64 = the reference's arithmetic (src/subspace_construction.jl:31,33 and README.md:56-57 make W_swa, P,
  *   the data and therefore the whole density Float64 -- SURVEY section 0, Q6).
- * SI_F32 (Dense chains; Conv chains are refused) = the measured fp32 option of SURVEY section 0 Q6 / 8(b),(d): X is rounded to
+ * SI_F32 = the measured fp32 option of SURVEY section 0 Q6 / 8(b),(d): X is rounded to
  *   fp32 once, W_swa + P*z is formed in fp64 and rounded to fp32 once per evaluation, every Dense layer multiplies and
  *   accumulates in fp32 (v_mfma_f32_32x32x2_f32) with fp32 activations; a narrow last layer (out <= 4), its bias /
  *   activation and the sum of squared errors are fp64.  It applies to si_logdensity, si_forward, the RWMH samplers
  *   (si_sample_rwmh*, si_rwmh_*) and -- since round 5 -- si_logdensity_grad (the fp32 forward with kept activations and the
  *   fp32 reverse sweep of the training step; the pull-back P' g and the optional prior term in fp64: grad rtol 2e-5 of its
- *   scale against the fp64 oracle, tests/test_gpu_f32.py); si_predict keeps computing in fp64, and the output map
+ *   scale against the fp64 oracle, tests/test_gpu_f32.py; Dense chains only: on a Conv chain set up with SI_F32 the gradient is
+ *   refused with SI_ERR_INVALID); si_predict keeps computing in fp64, and the output map
  *   (si_sample_rwmh_weights, si_reconstruct) delivers the fp64 W_swa + P*z.  Stated tolerance (tests/test_gpu_f32.py,
  *   against the fp64 oracle): model outputs 2e-5 of their scale, lp rtol 1e-5 (north_star: 1e-4); at BASELINE cfg2 the
- *   measured lp difference is rtol 2e-8 or better and none of 1000 accept decisions changes.                                       */
+ *   measured lp difference is rtol 2e-8 or better and none of 1000 accept decisions changes.
+ *   Conv / MaxPool / flatten chains (round 5): the same option -- the convolution kernels on fp32 operands
+ *   (v_mfma_f32_16x16x4_f32), fp32 activations and pooling, the Dense layers behind `flatten` on the fp32 GEMM kernels, the
+ *   squared errors in fp64; outputs within 5e-5 of their scale and lp rtol 1e-5 on the CNN cases of the tests (BASELINE cfg4's
+ *   CNN, 4096 images: lp rtol 9e-8, no accept decision of 200 differs, 7.3 -> 4.3 ms per transition).                            */
 int32_t si_infer_setup(si_ctx* ctx, const si_layer* layers, int32_t L, int64_t N, int32_t M,
                        const double* W_swa, const double* P, const double* X, const double* Y,
                        int32_t in_dim, int32_t out_dim, int64_t B, double sigma_m,

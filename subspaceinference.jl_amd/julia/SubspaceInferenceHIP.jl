@@ -320,7 +320,7 @@ function reconstruct(ctx::Ctx, Z::Matrix{Float64}, N)
 end
 
 # include_prior = true adds the term the reference writes after its `return` (dead code, :95); default: as the reference
-# compute_dtype = :f32 (non-default; SURVEY section 0 Q6): the density of a Dense chain on the fp32 matrix instruction -- X rounded
+# compute_dtype = :f32 (non-default; SURVEY section 0 Q6): the density of a Dense or Conv chain on the fp32 matrix instructions -- X rounded
 # once, W_swa + P*z formed in Float64 and rounded once per transition, Float32 activations, head + sum of squared errors in Float64
 function sub_inference(in_model, data, W_swa, P; σ_z = 1.0, σ_m = 1.0, σ_p = 1.0, itr = 100, M = 3, alg = :rwmh,
                        backend = :forwarddiff, device = 0, ctx = Ctx(device), seed = 0, chain_id = 0, include_prior = false,
