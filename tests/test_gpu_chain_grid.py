@@ -58,7 +58,7 @@ def test_fused_and_grid_loop_equal_launch_per_step_bit_for_bit(si, gpu_ctx, dims
         assert not spec[3][0] and not spec[3][1] and not spec[4][0] and not spec[4][1]   # generic kernels when asked for
         # a narrow head and fragments that fit a wave's registers: the kernels compiled for the chain's shapes ran in modes 1 / 2
         in_class = dims[-1] <= 4 and len(dims) >= 3 and sum(-(-((o + 15) // 16) // 4) * ((i + 3) // 4 + 1) for i, o in zip(dims[:-2], dims[1:-1])) <= 96
-        assert (spec[2][0] and (spec[1][0] or spec[1][1])) == in_class, (dims, spec, in_class)
+        assert spec[2][0] == in_class, (dims, spec, in_class)   # (mode 1's LOOP is specialised only up to 1024 model outputs: four blocks of the SSE tree)
     finally:
         gpu_ctx.set_chain_loop(1)
 
