@@ -630,7 +630,7 @@ __device__ __forceinline__ void gram_spec_consumer(int64_t N, double* __restrict
         if (i < cnt2) {
           double sum = 0.0;
 #pragma unroll
-          for (int kg2 = 0; kg2 < KS; ++kg2) sum += sA[((g2 * KS + kg2) * R + j) * TP + (el & 15) + 17 * (el >> 4)];
+          for (int kg2 = 0; kg2 < KS; ++kg2) sum += sA[((g2 * KS + kg2) * R + j) * 256 + el];
           out[(lo2 + i) * 256 + el] = sum;
         }
       }

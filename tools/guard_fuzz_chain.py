@@ -2,7 +2,7 @@
 si_set_chain_loop 0 (one launch per layer and step) against 1 / 2 (kernels specialised at run time where the chain is of that
 class) and 3 / 4 (generic kernels), 1 ... 70 chains -- the persistent loop at tiles of 16 / 32 / 64 observations, the B-tiled
 density, the register-resident stacked density -- bit for bit; the density against the oracle.
-Usage: guard_fuzz_chain.py [cases] [seed]"""
+Usage: [SI_PROBE_DEV=1 SI_GUARD_ALLOC=end|begin] guard_fuzz_chain.py [cases] [seed]"""
 import os
 import sys
 
@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import subspaceinference_jl_amd as si  # noqa: E402
 from oracle import subspace_oracle as so  # noqa: E402
 
+if os.environ.get("SI_PROBE_DEV"):   # the development build (guard-page runs: SI_GUARD_ALLOC=end|begin)
+    si._capi.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bin", "libsubspace_hip_dev.so")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
