@@ -694,10 +694,24 @@ def run_chains(args, rk, real_stdout):
             nctx.sample_rwmh(100, 0.1, seed=1, nchains=512)
             extras["nn_example_512_chains_samples_per_s"] = 100 * 512 / (time.perf_counter() - t0)
             extras["nn_example_kernels_specialised_at_run_time"] = extras["nn_example_kernels_specialised_at_run_time"] and bool(nctx.chain_kernel_info()[0])
+        # the same single-chain call from a C process (tools/nn_capi_probe.c through the C ABI, no interpreter in the process): the
+        # kernel of this call runs 9 % slower inside a Python process (three clocks) -- what a ccall / cgo caller sees
+        probe = os.path.join(ROOT, "tools", "bin", "nn_capi_probe")
+        if os.path.exists(probe):
+            try:
+                import subprocess
+                pr = subprocess.run([probe, os.path.join(ROOT, "subspaceinference.jl_amd", "libsubspace_hip.so")], capture_output=True, text=True, timeout=120)
+                vals = [float(ln.split(":")[1].split("us")[0]) for ln in pr.stdout.splitlines() if ln.startswith("C ABI without Python")]
+                if vals:
+                    extras["nn_example_us_per_transition_c_process"] = min(vals)
+            except Exception as e:   # (a measurement helper: never fatal)
+                extras["nn_example_us_per_transition_c_process_error"] = repr(e)
         extras["nn_example_note"] = ("docs/src/nn_example.md's MLP, N = 15801, B = 1000, M = 20 (the largest M of its sweep): one chain in the "
                                      "persistent grid loop (63 workgroups, ONE grid barrier per transition, 20 000 transitions in one launch); "
                                      "512 chains stacked in the one-launch density with the activations in registers; both kernels compiled for "
-                                     "this chain's shapes at run time (csrc/chain_spec.inc through hiprtc; the generic kernels of "
+                                     "this chain's shapes at run time (csrc/chain_spec.inc through hiprtc); nn_example_us_per_transition is measured in THIS process, which "
+                                     "runs PyTorch's bundled HIP runtime (ROCm 7.0 in the wheel: the loop is 5 % slower under it, DESIGN 10.1b) and copies the samples "
+                                     "into untouched NumPy pages; _c_process: the same call from a C process on the system runtime (the generic kernels of "
                                      "csrc/kernels_chain_grid.hip give 22 us and 0.65 M samples/s); round 4: 41.0 us and 0.336 M samples/s")
 
     if rank == 0:
