@@ -297,6 +297,7 @@ int32_t si_destroy(si_ctx* ctx) {
   free_wstream(ctx);
   dev_free(ctx->d_nvals);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+  if (ctx->h_outpin) (void)hipHostFree(ctx->h_outpin);
   for (int b = 0; b < 2; ++b) {
     if (ctx->h_stage[b]) (void)hipHostFree(ctx->h_stage[b]);
     dev_free(ctx->d_stage[b]);

@@ -130,6 +130,8 @@ struct Ctx {
   // pinned host staging for the small construct-time transfers (G down, V up): pageable copies cost tens of us each
   double* h_pin = nullptr;
   size_t h_pin_cap = 0;
+  char* h_outpin = nullptr;      // pinned staging of the samples / lp of a device-resident loop on their way to the caller's arrays
+  size_t h_outpin_cap = 0;
   double* h_stage[2] = {nullptr, nullptr};   // pinned staging of si_reconstruct's output pipeline (kept between calls)
   size_t h_stage_cap = 0;
   double *d_stage[2] = {nullptr, nullptr}, *d_zstage[2] = {nullptr, nullptr};   // its device-side double buffer
