@@ -492,6 +492,8 @@ void launch_dense_f64(hipStream_t st, const double* W, const double* bias, const
     launch_dense_small_f64(st, W, bias, Hin, Hout, out, in, B, act, dense_fused_slot_feats(out), cb);
     return;
   }
+  if (cb.n <= 1 && dense_panel_applies(W, out, in, B, act) && launch_dense_f64_panel(st, W, bias, Hin, Hout, out, in, B, act))
+    return;   // a wide first layer (kernels_gemm_panel.hip, same bits)
   FuseArgs fa;
   fa.cb = cb;
   switch (pick_bm(out)) {

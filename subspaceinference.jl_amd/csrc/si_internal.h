@@ -366,6 +366,12 @@ int dense_fused_slots(int32_t out);
 void launch_dense_f64_fused(hipStream_t st, const double* W, const double* bias, const double* Hin, int32_t out,
                             int32_t in, int64_t B, int32_t act, const double* Wlast, int32_t out_last, double* part,
                             const ChainBatch& cb = ChainBatch(), double* Hkeep = nullptr /* also store the layer's output */);
+// K5 for a wide layer with a short reduction (kernels_gemm_panel.hip: in <= 128, persistent workgroups that keep their X operands in
+// registers, stream W through an LDS ring and let every store drain under the MFMAs of the next tiles); same bits as the big-tile
+// kernel.  launch_dense_f64 routes single-chain layers to it by shape (dense_panel_applies).
+bool dense_panel_applies(const double* W, int32_t out, int32_t in, int64_t B, int32_t act);
+bool launch_dense_f64_panel(hipStream_t st, const double* W, const double* bias, const double* Hin, double* Hout, int32_t out,
+                            int32_t in, int64_t B, int32_t act, int grid = 0);
 // K5 for small layers (kernels_gemm_small.hip): one wave per (feature slot, 16 observations) tile, operands straight from global
 // memory; same bits as the big-tile kernel.  launch_dense_f64 / _fused route to it by shape (dense_small_applies).
 bool dense_small_applies(int32_t out, int32_t in, int64_t B, int nchains, int32_t bm);
