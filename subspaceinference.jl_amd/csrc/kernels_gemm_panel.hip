@@ -28,6 +28,10 @@ namespace si {
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr_p;
 
+#if defined(SI_PANEL_KNOB) && (SI_PANEL_KNOB & 8)   // harness only: per workgroup, shader cycles of the unit loop and its entry / loop start / loop end in 100 MHz ticks
+__device__ long long si_panel_stamps[4 * 2048];
+#endif
+
 __device__ __forceinline__ double panel_act(double v, int act) {
   switch (act) {
     case SI_ACT_RELU: return v > 0.0 ? v : 0.0;
@@ -101,6 +105,9 @@ __global__ __launch_bounds__(512, 4) void dense_f64_panel_kernel(const double* _
   static_assert(RD >= 2 && NWAIT <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ double ring[];                  // [RD][SLOT], then the bias as the tiles see it [ntile][16]
 
+#if defined(SI_PANEL_KNOB) && (SI_PANEL_KNOB & 8)
+  const long long sr_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   const int64_t u0 = units * blockIdx.x / gridDim.x, u1 = units * (blockIdx.x + 1) / gridDim.x;
   if (u0 >= u1) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c = lane & 15;
@@ -163,6 +170,9 @@ __global__ __launch_bounds__(512, 4) void dense_f64_panel_kernel(const double* _
     tpre = tpre + 1 == ntile ? 0 : tpre + 1;
   }
 
+#if defined(SI_PANEL_KNOB) && (SI_PANEL_KNOB & 8)
+  const long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const unsigned frag0 = (unsigned)(uintptr_t)(panel_lds_cptr)(ring + q * 16 + c);   // LDS byte address of the lane's fragment column
   int slot = 0;
   for (int64_t u = u0; u < u1; ++u) {
@@ -220,6 +230,14 @@ __global__ __launch_bounds__(512, 4) void dense_f64_panel_kernel(const double* _
       if (u + 1 < u1) load_panel();
     }
   }
+#if defined(SI_PANEL_KNOB) && (SI_PANEL_KNOB & 8)
+  if (tid == 0 && blockIdx.x < 2048) {
+    si_panel_stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st0;
+    si_panel_stamps[4 * blockIdx.x + 1] = sr_entry;
+    si_panel_stamps[4 * blockIdx.x + 2] = sr0;
+    si_panel_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail fetches must land before the workgroup retires
 }
 

@@ -71,6 +71,40 @@ int main(int argc, char** argv) {
     }
     printf("%-22s alone %7.4f ms  queued %7.4f ms = %6.2f TFLOP/s  elements that differ from dense_f64_kernel: %zu\n", name, best, ms10 / 10,
            flops / (ms10 / 10 * 1e-3) / 1e12, bad);
+#if defined(SI_PANEL_KNOB) && (SI_PANEL_KNOB & 8)
+    if (check) {   // in-kernel clock and cycles per unit of the LAST launch (the queued ones)
+      std::vector<long long> st(4 * 2048);
+      (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(si::si_panel_stamps), st.size() * 8);
+      std::vector<double> cyc, clk, pro, loop;
+      long long first = 1ll << 62, lastentry = 0, lastend = 0, firstend = 1ll << 62;
+      for (int g = 0; g < 2048; ++g) {
+        const long long* t = &st[4 * g];
+        if (t[3] <= t[2]) continue;
+        cyc.push_back((double)t[0]); clk.push_back((double)t[0] / (double)(t[3] - t[2]) * 0.1);
+        pro.push_back((t[2] - t[1]) * 0.01); loop.push_back((t[3] - t[2]) * 0.01);
+        first = std::min(first, t[1]); lastentry = std::max(lastentry, t[1]); lastend = std::max(lastend, t[3]); firstend = std::min(firstend, t[3]);
+      }
+      std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end()); std::sort(pro.begin(), pro.end()); std::sort(loop.begin(), loop.end());
+      {
+        double xs[8] = {0}, xc[8] = {0}, xmx[8] = {0}; int xn[8] = {0};
+        for (int g = 0; g < 2048; ++g) {
+          const long long* t = &st[4 * g];
+          if (t[3] <= t[2]) continue;
+          xs[g & 7] += (t[3] - t[2]) * 0.01; xc[g & 7] += (double)t[0] / (double)(t[3] - t[2]) * 0.1; xn[g & 7]++;
+          xmx[g & 7] = std::max(xmx[g & 7], (t[3] - t[2]) * 0.01);
+        }
+        printf("   per XCD (workgroup index mod 8): loop us mean / max, clock GHz:");
+        for (int x = 0; x < 8; ++x) if (xn[x]) printf("  %.0f/%.0f %.2f", xs[x] / xn[x], xmx[x], xc[x] / xn[x]);
+        printf("\n");
+      }
+      const double units = (double)((B + 127) / 128) * ((out + 15) / 16) / (double)cyc.size();
+      if (!cyc.empty())
+        printf("   in-kernel: clock med %.3f GHz, unit loop med %.0f cycles = %.0f per unit (8192 = four waves' MFMAs back to back)\n"
+               "   us: workgroup entries spread %.1f, prologue med %.1f max %.1f, loop med %.1f max %.1f, first entry -> first end %.1f -> last end %.1f\n",
+               clk[clk.size() / 2], cyc[cyc.size() / 2], cyc[cyc.size() / 2] / units, (lastentry - first) * 0.01, pro[pro.size() / 2], pro.back(),
+               loop[loop.size() / 2], loop.back(), (firstend - first) * 0.01, (lastend - first) * 0.01);
+    }
+#endif
     fflush(stdout);
   };
   run("dense_f64 96x128", [&](double* y) { launch_dense_cfg<96, 128, 2, 4, 4>(0, dW, db, dX, y, out, in, B, act); }, dRef, false);
