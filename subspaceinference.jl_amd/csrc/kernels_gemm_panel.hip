@@ -1,4 +1,4 @@
-// K5, the wide first layer of a regression MLP:  H = act.(W*X .+ b)  with a SHORT reduction (in = 16, 32, ... 128) and a wide
+// K5, the wide first layer of a regression MLP:  H = act.(W*X .+ b)  with a SHORT reduction (in <= 128) and a wide
 // output (reference src/space_inference.jl:92-94 through Flux's Dense; cfg2: 128 -> 960 on 1e5 points, 768 MB of output).
 //
 // dense_f64_kernel (kernels_gemm.hip) runs this layer at 0.66 of the fp64 MFMA peak: its 96x128 tile has only 8 k tiles, and
@@ -27,6 +27,10 @@
 namespace si {
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr_p;
+
+// what the DMA fetches for the k rows past `in` of a reduction that is not a multiple of 16 (zeros, like the zero fill of
+// dense_f64_kernel's ragged k tile: a clamped row of W would turn an Inf weight into 0 * Inf)
+__device__ __attribute__((aligned(16))) double si_panel_zero[16];
 
 #if defined(SI_PANEL_KNOB) && (SI_PANEL_KNOB & 8)   // harness only: per workgroup, shader cycles of the unit loop and its entry / loop start / loop end in 100 MHz ticks
 __device__ long long si_panel_stamps[4 * 2048];
@@ -95,8 +99,8 @@ __device__ __forceinline__ void panel_chunks(unsigned fa, const double (&xf)[4 *
 template <int KT, int RD>
 __global__ __launch_bounds__(512, 4) void dense_f64_panel_kernel(const double* __restrict__ W, const double* __restrict__ bias,
                                                                   const double* __restrict__ Hin, double* __restrict__ Hout, int out,
-                                                                  int64_t B, int act, int ntile, int64_t units) {
-  constexpr int IN = 16 * KT, KS = 4 * KT;          // k steps of one tile
+                                                                  int in, int64_t B, int act, int ntile, int64_t units) {
+  constexpr int IN = 16 * KT, KS = 4 * KT;          // the reduction padded to whole k tiles (in <= IN: rows past `in` are zeros), k steps of one tile
   constexpr int SLOT = IN * 16;                     // doubles per ring slot: [k][16 features]
   constexpr int NINST = 2 * KT;                     // DMA instructions per tile (1 KB each)
   constexpr int NDMA = (NINST + 7) / 8;             // per wave
@@ -123,18 +127,22 @@ __global__ __launch_bounds__(512, 4) void dense_f64_panel_kernel(const double* _
   // ---- DMA plan: instruction id covers k rows 8 id .. 8 id + 7 of a tile; lane -> (k = 8 id + lane / 8, feature pair lane % 8)
   const double* src[NDMA];
   int dsto[NDMA];
+  bool pad[NDMA];
 #pragma unroll
   for (int s = 0; s < NDMA; ++s) {
     int id = wave + 8 * s;
     if (id > NINST - 1) id = NINST - 1;             // a spare instruction repeats the last one (same data, same place)
-    src[s] = W + (int64_t)out * (8 * id + (lane >> 3)) + 2 * (lane & 7);
+    const int k = 8 * id + (lane >> 3);
+    pad[s] = k >= in;                               // (zeros do not move with the tile)
+    src[s] = pad[s] ? si_panel_zero + 2 * (lane & 7) : W + (int64_t)out * k + 2 * (lane & 7);
     dsto[s] = id * 128;
   }
   auto issue = [&](int tt, int slot) {
     const int shift = tt == ntile - 1 ? 16 * tt - tail : 16 * tt;   // ... and then holds feature 16 tt + cc - tail in column cc
     panel_static_for<NDMA>([&](auto SC) {
       constexpr int s = decltype(SC)::value;
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src[s] + shift), (lds_void_ptr_p)(ring + slot * SLOT + dsto[s]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pad[s] ? src[s] : src[s] + shift), (lds_void_ptr_p)(ring + slot * SLOT + dsto[s]), 16,
+                                       0, 0);
     });
   };
 
@@ -146,9 +154,13 @@ __global__ __launch_bounds__(512, 4) void dense_f64_panel_kernel(const double* _
   auto load_panel = [&]() {
     int64_t gb = pan * 128 + 16 * wave + c;
     if (gb > B - 1) gb = B - 1;                     // (a column past the edge repeats column B - 1, value and address)
-    const double* xp = Hin + (int64_t)IN * gb + q;
+    const double* xp = Hin + (int64_t)in * gb;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) xf[s] = xp[4 * s];
+    for (int s = 0; s < KS; ++s) {
+      const int k = 4 * s + q;
+      const double xv = xp[k < in ? k : in - 1];    // (unconditional load of a valid element, then the select)
+      xf[s] = k < in ? xv : 0.0;
+    }
     const int64_t left = B - 1 - pan * 128;         // last valid column of the panel
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(512, 4) void dense_f64_panel_kernel(const double* _
 
 template <int KT>
 static void launch_panel_inst(hipStream_t st, const double* W, const double* bias, const double* Hin, double* Hout, int32_t out,
-                              int64_t B, int32_t act, int grid) {
+                              int32_t in, int64_t B, int32_t act, int grid) {
 #ifdef SI_PANEL_RD
   constexpr int RD = SI_PANEL_RD;
 #else
@@ -254,7 +266,7 @@ static void launch_panel_inst(hipStream_t st, const double* W, const double* bia
   if (grid > units) grid = (int)units;
   auto kern = dense_f64_panel_kernel<KT, RD>;
   const size_t lds = ((size_t)RD * KT * 256 + 16 * (size_t)ntile) * sizeof(double);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, W, bias, Hin, Hout, (int)out, B, (int)act, ntile, units);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, W, bias, Hin, Hout, (int)out, (int)in, B, (int)act, ntile, units);
 }
 
 // two workgroups per CU of the current device
@@ -272,35 +284,35 @@ static int panel_grid() {
   return g;
 }
 
-// The class: a reduction of 16, 32, ... 128 (the X operands of a wave live in registers), 64 <= out <= 1024 and even with W
+// The class: a reduction of at most 128 (the X operands of a wave live in registers; padded with zeros to whole k tiles), 64 <= out <= 1024 and even with W
 // 16-byte aligned (the DMA moves feature pairs), one of the four epilogue activations, and a batch that gives every workgroup of
-// the persistent grid a run of at least 8 tiles.  (Development build: SI_PANEL=0 in the environment sends these layers to
+// the persistent grid a run of at least 16 tiles (below that the prologue -- 15 us of a workgroup's life -- eats the gain).  (Development build: SI_PANEL=0 in the environment sends these layers to
 // dense_f64_kernel -- the A/B runs of DESIGN section 10.8.)
 bool dense_panel_applies(const double* W, int32_t out, int32_t in, int64_t B, int32_t act) {
 #ifdef SI_DEV_KNOBS   // development build only (tests/test_capi_cpu.py: the shipped library reads no SI_* knobs)
   static const bool off = [] { const char* e = getenv("SI_PANEL"); return e && e[0] == '0'; }();
   if (off) return false;
 #endif
-  if (in < 16 || in > 128 || in % 16 != 0 || out < 64 || out > 1024 || out % 2 != 0 || act_is_extra(act) || B < 1) return false;
+  if (in < 1 || in > 128 || out < 64 || out > 1024 || out % 2 != 0 || act_is_extra(act) || B < 1) return false;
   if ((reinterpret_cast<uintptr_t>(W) & 15) != 0) return false;
-  return (int64_t)((out + 15) / 16) * ((B + 127) / 128) >= 8 * (int64_t)panel_grid();
+  return (int64_t)((out + 15) / 16) * ((B + 127) / 128) >= 16 * (int64_t)panel_grid();
 }
 
 // true = launched (`grid` = workgroups, 0 = two per CU; the harness sweeps it and skips the size rule of dense_panel_applies).
 bool launch_dense_f64_panel(hipStream_t st, const double* W, const double* bias, const double* Hin, double* Hout, int32_t out,
                             int32_t in, int64_t B, int32_t act, int grid) {
-  if (in < 16 || in > 128 || in % 16 != 0 || out < 16 || out > 1024 || out % 2 != 0 || act_is_extra(act) || B < 1 || grid < 0) return false;
+  if (in < 1 || in > 128 || out < 16 || out > 1024 || out % 2 != 0 || act_is_extra(act) || B < 1 || grid < 0) return false;
   if ((reinterpret_cast<uintptr_t>(W) & 15) != 0) return false;
   if (grid == 0) grid = panel_grid();
-  switch (in / 16) {
-    case 1: launch_panel_inst<1>(st, W, bias, Hin, Hout, out, B, act, grid); break;
-    case 2: launch_panel_inst<2>(st, W, bias, Hin, Hout, out, B, act, grid); break;
-    case 3: launch_panel_inst<3>(st, W, bias, Hin, Hout, out, B, act, grid); break;
-    case 4: launch_panel_inst<4>(st, W, bias, Hin, Hout, out, B, act, grid); break;
-    case 5: launch_panel_inst<5>(st, W, bias, Hin, Hout, out, B, act, grid); break;
-    case 6: launch_panel_inst<6>(st, W, bias, Hin, Hout, out, B, act, grid); break;
-    case 7: launch_panel_inst<7>(st, W, bias, Hin, Hout, out, B, act, grid); break;
-    default: launch_panel_inst<8>(st, W, bias, Hin, Hout, out, B, act, grid); break;
+  switch ((in + 15) / 16) {
+    case 1: launch_panel_inst<1>(st, W, bias, Hin, Hout, out, in, B, act, grid); break;
+    case 2: launch_panel_inst<2>(st, W, bias, Hin, Hout, out, in, B, act, grid); break;
+    case 3: launch_panel_inst<3>(st, W, bias, Hin, Hout, out, in, B, act, grid); break;
+    case 4: launch_panel_inst<4>(st, W, bias, Hin, Hout, out, in, B, act, grid); break;
+    case 5: launch_panel_inst<5>(st, W, bias, Hin, Hout, out, in, B, act, grid); break;
+    case 6: launch_panel_inst<6>(st, W, bias, Hin, Hout, out, in, B, act, grid); break;
+    case 7: launch_panel_inst<7>(st, W, bias, Hin, Hout, out, in, B, act, grid); break;
+    default: launch_panel_inst<8>(st, W, bias, Hin, Hout, out, in, B, act, grid); break;
   }
   return true;
 }

@@ -1,4 +1,4 @@
-"""K5 for a wide first layer with a short reduction (csrc/kernels_gemm_panel.hip): in = 16 .. 128, persistent workgroups that keep
+"""K5 for a wide first layer with a short reduction (csrc/kernels_gemm_panel.hip): in <= 128, persistent workgroups that keep
 their X operands in registers and stream W through an LDS ring.  launch_dense_f64 routes single-chain layers of that class to it;
 the same layer of STACKED chains (grid.y = chain slot) runs dense_f64_kernel.  Both must give the same bits, and the oracle's number
 (reference src/space_inference.jl:92-94 + the density of :88-96).  (tools/panel_bench.hip compares whole layer outputs of the two
@@ -11,12 +11,15 @@ from oracle import subspace_oracle as so
 
 pytestmark = pytest.mark.gpu
 
-# (dims, acts, B): every first layer is inside dense_panel_applies -- ceil(out / 16) * ceil(B / 128) >= 8 * 512 tiles
+# (dims, acts, B): every first layer is inside dense_panel_applies -- ceil(out / 16) * ceil(B / 128) >= 16 * 512 tiles
 CASES = [
     ([128, 960, 64, 1], [1, 1, 0], 20000),    # cfg2's first layer (BASELINE.json configs[1]) on a fifth of its batch
-    ([48, 130, 64, 1], [2, 1, 0], 60001),     # a ragged last feature tile (130 = 8 x 16 + 2), a ragged last panel, tanh
-    ([16, 1024, 32, 2], [3, 1, 0], 9000),     # the shortest reduction and the widest layer of the class, sigmoid
-    ([112, 256, 40, 1], [0, 2, 0], 33000),    # identity epilogue, 7 k tiles
+    ([48, 130, 64, 1], [2, 1, 0], 120001),     # a ragged last feature tile (130 = 8 x 16 + 2), a ragged last panel, tanh
+    ([16, 1024, 32, 2], [3, 1, 0], 17000),     # the shortest reduction and the widest layer of the class, sigmoid
+    ([112, 256, 40, 1], [0, 2, 0], 66000),    # identity epilogue, 7 k tiles
+    ([13, 512, 24, 1], [1, 1, 0], 33000),     # a reduction that is not a multiple of 4: zero-padded k rows (dense_f64_kernel: its ragged k tile)
+    ([100, 300, 32, 1], [2, 1, 0], 56000),    # 100 = 6 k tiles + 4, 300 = 18 feature tiles + 12
+    ([1, 128, 16, 1], [1, 1, 0], 132000),      # a single input feature
 ]
 
 
@@ -38,7 +41,7 @@ def test_panel_first_layer_same_bits_as_the_tile_kernel(si, gpu_ctx, dims, acts,
 
 def test_panel_layer_in_a_chain(si, gpu_ctx):
     """a short RWMH chain on a model whose first layer is in the class equals the oracle's chain on the same Philox stream"""
-    dims, acts, b, m = [32, 512, 48, 1], [1, 1, 0], 17000, 4
+    dims, acts, b, m = [32, 512, 48, 1], [1, 1, 0], 33000, 4
     table, n = so.layer_table(dims, acts)
     rng = np.random.default_rng(3)
     x, y = rng.standard_normal((dims[0], b)), rng.standard_normal((dims[-1], b))
