@@ -30,7 +30,7 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr_p;
 
 // what the DMA fetches for the k rows past `in` of a reduction that is not a multiple of 16 (zeros, like the zero fill of
 // dense_f64_kernel's ragged k tile: a clamped row of W would turn an Inf weight into 0 * Inf)
-__device__ __attribute__((aligned(16))) double si_panel_zero[16];
+__device__ __attribute__((aligned(16))) double si_panel_zero[1024 + 16];   // (as long as the widest layer: a padded lane's address moves with the tile too)
 
 #if defined(SI_PANEL_KNOB) && (SI_PANEL_KNOB & 8)   // harness only: per workgroup, shader cycles of the unit loop and its entry / loop start / loop end in 100 MHz ticks
 __device__ long long si_panel_stamps[4 * 2048];
@@ -96,7 +96,7 @@ __device__ __forceinline__ void panel_chunks(unsigned fa, const double (&xf)[4 *
 // contiguous runs to the G workgroups of the grid (two per CU), panel-major -- a run crosses a panel boundary a couple of times
 // and reloads its X operands there; W tiles just keep streaming (tile index modulo ntile).  No tail round: every workgroup
 // ends within one tile of every other.
-template <int KT, int RD>
+template <int KT, int RD, bool RAG>   // RAG: in < 16 KT
 __global__ __launch_bounds__(512, 4) void dense_f64_panel_kernel(const double* __restrict__ W, const double* __restrict__ bias,
                                                                   const double* __restrict__ Hin, double* __restrict__ Hout, int out,
                                                                   int in, int64_t B, int act, int ntile, int64_t units) {
@@ -127,22 +127,19 @@ __global__ __launch_bounds__(512, 4) void dense_f64_panel_kernel(const double* _
   // ---- DMA plan: instruction id covers k rows 8 id .. 8 id + 7 of a tile; lane -> (k = 8 id + lane / 8, feature pair lane % 8)
   const double* src[NDMA];
   int dsto[NDMA];
-  bool pad[NDMA];
 #pragma unroll
   for (int s = 0; s < NDMA; ++s) {
     int id = wave + 8 * s;
     if (id > NINST - 1) id = NINST - 1;             // a spare instruction repeats the last one (same data, same place)
     const int k = 8 * id + (lane >> 3);
-    pad[s] = k >= in;                               // (zeros do not move with the tile)
-    src[s] = pad[s] ? si_panel_zero + 2 * (lane & 7) : W + (int64_t)out * k + 2 * (lane & 7);
+    src[s] = RAG && k >= in ? si_panel_zero + 2 * (lane & 7) : W + (int64_t)out * k + 2 * (lane & 7);
     dsto[s] = id * 128;
   }
   auto issue = [&](int tt, int slot) {
     const int shift = tt == ntile - 1 ? 16 * tt - tail : 16 * tt;   // ... and then holds feature 16 tt + cc - tail in column cc
     panel_static_for<NDMA>([&](auto SC) {
       constexpr int s = decltype(SC)::value;
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(pad[s] ? src[s] : src[s] + shift), (lds_void_ptr_p)(ring + slot * SLOT + dsto[s]), 16,
-                                       0, 0);
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src[s] + shift), (lds_void_ptr_p)(ring + slot * SLOT + dsto[s]), 16, 0, 0);
     });
   };
 
@@ -154,12 +151,20 @@ __global__ __launch_bounds__(512, 4) void dense_f64_panel_kernel(const double* _
   auto load_panel = [&]() {
     int64_t gb = pan * 128 + 16 * wave + c;
     if (gb > B - 1) gb = B - 1;                     // (a column past the edge repeats column B - 1, value and address)
-    const double* xp = Hin + (int64_t)in * gb;
+    if constexpr (RAG) {
+      // (predicated loads off ONE base with the k step in the immediate offset: clamped per-element addresses cost the loop its
+      //  registers -- the allocator then reloads the DMA pointers from scratch behind every barrier)
+      const double* xp = Hin + (int64_t)in * gb + q;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int k = 4 * s + q;
-      const double xv = xp[k < in ? k : in - 1];    // (unconditional load of a valid element, then the select)
-      xf[s] = k < in ? xv : 0.0;
+      for (int s = 0; s < KS; ++s) {
+        double xv = 0.0;
+        if (4 * s + q < in) xv = xp[4 * s];
+        xf[s] = xv;
+      }
+    } else {
+      const double* xp = Hin + (int64_t)IN * gb + q;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) xf[s] = xp[4 * s];
     }
     const int64_t left = B - 1 - pan * 128;         // last valid column of the panel
 #pragma unroll
@@ -264,9 +269,13 @@ static void launch_panel_inst(hipStream_t st, const double* W, const double* bia
   const int ntile = (out + 15) / 16;
   const int64_t npan = (B + 127) / 128, units = npan * ntile;
   if (grid > units) grid = (int)units;
-  auto kern = dense_f64_panel_kernel<KT, RD>;
   const size_t lds = ((size_t)RD * KT * 256 + 16 * (size_t)ntile) * sizeof(double);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, W, bias, Hin, Hout, (int)out, (int)in, B, (int)act, ntile, units);
+  if (in == 16 * KT)
+    hipLaunchKernelGGL((dense_f64_panel_kernel<KT, RD, false>), dim3((unsigned)grid), dim3(512), lds, st, W, bias, Hin, Hout, (int)out, (int)in, B, (int)act,
+                       ntile, units);
+  else
+    hipLaunchKernelGGL((dense_f64_panel_kernel<KT, RD, true>), dim3((unsigned)grid), dim3(512), lds, st, W, bias, Hin, Hout, (int)out, (int)in, B, (int)act,
+                       ntile, units);
 }
 
 // two workgroups per CU of the current device
