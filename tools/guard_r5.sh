@@ -15,7 +15,7 @@ for mode in end begin; do
     if [ $rc -ne 0 ]; then grep -a "fault\|Fault\|Error" $R/gpurun_out/guard_r5_${1%.py}_$mode.log | tail -3 >> $L; cat $L; exit 1; fi
   done
   echo "== SI_GUARD_ALLOC=$mode: round-5 GPU tests" >> $L
-  SI_TEST_LIB=tools/bin/libsubspace_hip_dev.so SI_GUARD_ALLOC=$mode timeout -k 10 900 python3 -m pytest $R/tests/test_gpu_chain_grid.py $R/tests/test_gpu_train_f32.py $R/tests/test_gpu_f32.py $R/tests/test_gpu_a32.py $R/tests/test_gpu_conv.py -q -m gpu -k "not cfg4 and not long_chain" -x > $R/gpurun_out/guard_r5_tests_$mode.log 2>&1
+  SI_TEST_LIB=tools/bin/libsubspace_hip_dev.so SI_GUARD_ALLOC=$mode timeout -k 10 900 python3 -m pytest $R/tests/test_gpu_chain_grid.py $R/tests/test_gpu_train_f32.py $R/tests/test_gpu_f32.py $R/tests/test_gpu_a32.py $R/tests/test_gpu_conv.py $R/tests/test_gpu_panel.py -q -m gpu -k "not cfg4 and not long_chain" -x > $R/gpurun_out/guard_r5_tests_$mode.log 2>&1
   rc=$?; tail -2 $R/gpurun_out/guard_r5_tests_$mode.log >> $L; echo "   rc=$rc" >> $L
   if [ $rc -ne 0 ]; then cat $L; exit 1; fi
 done
